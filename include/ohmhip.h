@@ -1,0 +1,233 @@
+/*
+ * ohmhip.h -- C ABI of libohmhip.so: the MI355X (gfx950) replacement for the part of ohm's `gputil` + `ohmgpu`
+ * that sits under ohm::GpuMap::integrateRays / GpuNdtMap / GpuTsdfMap.
+ *
+ * Plain C: opaque handles, POD structs, pointers and sizes.  No C++/torch types cross this boundary and no
+ * exception does either: every function returns an int status (0 == OHMHIP_OK, negative == ohmhip error,
+ * positive == hipError_t value); ohmhip_error_string() renders it.
+ *
+ * Citations are file:line in the reference checkout (csiro-robotics/ohm).  Two groups:
+ *   1. device plumbing  -- what ohmgpu's hot path uses of gputil::Device/Queue/Event/Buffer/PinnedBuffer;
+ *   2. the typed hot path -- one resident voxel map per handle, ray batches in, region layers out.  This replaces
+ *      the generic `gputil::Kernel` variadic launch of regionRayUpdateOccupancy, regionRayUpdateNdt, covarianceHitNdt and tsdfRayUpdate
+ *      (ohmgpu/GpuMap.cpp:1130-1164, ohmgpu/GpuNdtMap.cpp:383-486, ohmgpu/GpuTsdfMap.cpp:262-263) and the
+ *      GpuLayerCache upload/download protocol (ohmgpu/GpuLayerCache.cpp:172-182, 300-321, 429-633).
+ */
+#ifndef OHMHIP_H
+#define OHMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OHMHIP_OK 0
+#define OHMHIP_ERR_INVALID_ARG (-1)
+#define OHMHIP_ERR_NO_DEVICE (-2)
+#define OHMHIP_ERR_CAPACITY (-3)    /* region pool exhausted and could not grow */
+#define OHMHIP_ERR_UNSUPPORTED (-4) /* flag / layout not supported by the HIP path */
+#define OHMHIP_ERR_NOT_FOUND (-5)
+#define OHMHIP_ERR_INTERNAL (-6)
+
+const char *ohmhip_error_string(int status);
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* 1. Device plumbing (replaces gputil)                                                                               */
+/* ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ohmhip_stream_s *ohmhip_stream_t; /* gputil::Queue  (gputil/gpuQueue.h:39)  */
+typedef struct ohmhip_event_s *ohmhip_event_t;   /* gputil::Event  (gputil/gpuEvent.h:23)  */
+typedef struct ohmhip_buffer_s *ohmhip_buffer_t; /* gputil::Buffer (gputil/gpuBuffer.h:73) */
+
+typedef struct ohmhip_device_info
+{
+  char name[256];
+  char arch[64];
+  uint64_t total_memory;      /* gputil::Device::deviceMemory()       gputil/gpuDevice.h:163-171 */
+  uint64_t max_allocation;    /* gputil::Device::maxAllocationSize()  */
+  int compute_units;
+  int lds_bytes_per_block;
+  int unified_memory;         /* gputil::Device::unifiedMemory()      */
+} ohmhip_device_info;
+
+int ohmhip_device_count(int *count);                            /* gputil/cuda/gpuDevice.cpp:108-115 */
+int ohmhip_device_select(int device);                           /* gputil/cuda/gpuKernel.cpp:33 (cudaSetDevice) */
+int ohmhip_device_get_info(int device, ohmhip_device_info *info);
+
+int ohmhip_stream_create(ohmhip_stream_t *stream);              /* gputil/cuda/gpuDevice.cpp:156 */
+int ohmhip_stream_destroy(ohmhip_stream_t stream);              /* gputil/cuda/gpuQueue.cpp:22  */
+int ohmhip_stream_finish(ohmhip_stream_t stream);               /* Queue::finish   gputil/cuda/gpuQueue.cpp:114 */
+int ohmhip_stream_wait_event(ohmhip_stream_t stream, ohmhip_event_t event); /* gputil/cuda/gpuKernel.cpp:91 */
+
+int ohmhip_event_create(ohmhip_event_t *event);                 /* gputil/cuda/gpuEvent.cpp:150 (blocking sync) */
+int ohmhip_event_destroy(ohmhip_event_t event);                 /* gputil/cuda/gpuEvent.cpp:22  */
+int ohmhip_event_record(ohmhip_event_t event, ohmhip_stream_t stream); /* Queue::mark gputil/gpuQueue.h:68-96 */
+int ohmhip_event_wait(ohmhip_event_t event);                    /* Event::wait      gputil/cuda/gpuEvent.cpp:95 */
+int ohmhip_event_is_complete(ohmhip_event_t event, int *complete); /* Event::isComplete gputil/cuda/gpuEvent.cpp:76 */
+int ohmhip_event_elapsed_ms(ohmhip_event_t start, ohmhip_event_t stop, float *ms);
+
+/* Buffer flags: gputil/gpuBuffer.h:24-45 */
+#define OHMHIP_BF_READ (1u << 0)
+#define OHMHIP_BF_WRITE (1u << 1)
+#define OHMHIP_BF_HOST_ACCESS (1u << 2) /* pinned host allocation (cudaHostAlloc, gputil/cuda/gpuBuffer.cpp:249) */
+
+int ohmhip_buffer_create(ohmhip_buffer_t *buffer, size_t bytes, unsigned flags); /* gputil/cuda/gpuBuffer.cpp:240 */
+int ohmhip_buffer_destroy(ohmhip_buffer_t buffer);                               /* :273-276 */
+int ohmhip_buffer_resize(ohmhip_buffer_t buffer, size_t bytes, size_t *actual);  /* grow-only, gpuBuffer.h:161 */
+int ohmhip_buffer_size(ohmhip_buffer_t buffer, size_t *bytes);
+int ohmhip_buffer_ptr(ohmhip_buffer_t buffer, void **device_ptr);                /* Buffer::argPtr */
+/* stream == NULL => synchronous (gputil/cuda/gpuBuffer.cpp:78); otherwise async + optional completion event (:58-67) */
+int ohmhip_buffer_write(ohmhip_buffer_t buffer, const void *src, size_t bytes, size_t dst_offset,
+                        ohmhip_stream_t stream, ohmhip_event_t block_on, ohmhip_event_t completion);
+int ohmhip_buffer_read(ohmhip_buffer_t buffer, void *dst, size_t bytes, size_t src_offset, ohmhip_stream_t stream,
+                       ohmhip_event_t block_on, ohmhip_event_t completion);
+int ohmhip_buffer_fill(ohmhip_buffer_t buffer, int byte_value, size_t bytes, size_t offset,
+                       ohmhip_stream_t stream);                                  /* gputil/cuda/gpuBuffer.cpp:206 */
+/* Pinned host staging memory (gputil::PinnedBuffer, gputil/cuda/gpuPinnedBuffer.cpp:66-131). */
+int ohmhip_host_alloc(void **ptr, size_t bytes);
+int ohmhip_host_free(void *ptr);
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* 2. The hot path: a device-resident voxel map                                                                       */
+/* ------------------------------------------------------------------------------------------------------------------ */
+
+/* Voxel layers (ohm/DefaultLayer.cpp:76-311).  Bit i <=> layer id i. */
+enum ohmhip_layer_id
+{
+  OHMHIP_LID_OCCUPANCY = 0,  /* float, clear +inf                        */
+  OHMHIP_LID_MEAN = 1,       /* VoxelMean {u32 coord, u32 count}         ohm/VoxelMeanCompute.h:29-33 */
+  OHMHIP_LID_COVARIANCE = 2, /* CovarianceVoxel float[6]                 ohm/CovarianceVoxelCompute.h:56-66 */
+  OHMHIP_LID_TRAVERSAL = 3,  /* float                                    */
+  OHMHIP_LID_TOUCH_TIME = 4, /* u32 ms since first ray                   */
+  OHMHIP_LID_INCIDENT = 5,   /* u32 packed normal                        */
+  OHMHIP_LID_INTENSITY = 6,  /* IntensityMeanCov {float, float}          */
+  OHMHIP_LID_HIT_MISS = 7,   /* HitMissCount {u32, u32}                  */
+  OHMHIP_LID_TSDF = 8,       /* VoxelTsdf {float weight, float distance} ohm/VoxelTsdfCompute.h:20-24 */
+  OHMHIP_LID_COUNT = 9
+};
+#define OHMHIP_LAYER_BIT(id) (1u << (id))
+
+/* Which update rule integrateRays applies: GpuMap / GpuNdtMap / GpuTsdfMap. */
+enum ohmhip_map_mode
+{
+  OHMHIP_MODE_OCCUPANCY = 0, /* ohmgpu/GpuMap.h:143     (CPU semantics: ohm/RayMapperOccupancy.cpp:68-339) */
+  OHMHIP_MODE_NDT_OM = 1,    /* ohmgpu/GpuNdtMap.h:63   (ohm/RayMapperNdt.cpp:84-407, NdtMode::kOccupancy)  */
+  OHMHIP_MODE_NDT_TM = 2,    /* NdtMode::kTraversability                                                   */
+  OHMHIP_MODE_TSDF = 3       /* ohmgpu/GpuTsdfMap.h:37  (ohm/RayMapperTsdf.cpp:87-182)                      */
+};
+
+/* Ray flags, bit-compatible with ohm::RayFlag (ohm/RayFlag.h:16-60). */
+#define OHMHIP_RF_DEFAULT 0u
+#define OHMHIP_RF_END_POINT_AS_FREE (1u << 0)
+#define OHMHIP_RF_STOP_ON_FIRST_OCCUPIED (1u << 1) /* order-dependent across voxels: OHMHIP_ERR_UNSUPPORTED */
+#define OHMHIP_RF_EXCLUDE_ORIGIN (1u << 2)
+#define OHMHIP_RF_EXCLUDE_SAMPLE (1u << 3)
+#define OHMHIP_RF_EXCLUDE_RAY (1u << 4)
+#define OHMHIP_RF_EXCLUDE_UNOBSERVED (1u << 5)
+#define OHMHIP_RF_EXCLUDE_FREE (1u << 6)
+#define OHMHIP_RF_EXCLUDE_OCCUPIED (1u << 7)
+#define OHMHIP_RF_REVERSE_WALK (1u << 8) /* accepted and ignored: results follow the CPU forward walk */
+
+/* Ray filter applied on device before integration (ohm/RayFilter.cpp:12-58; map default = good rays <= 1e10,
+ * ohm/OccupancyMap.cpp:215-218). */
+enum ohmhip_ray_filter
+{
+  OHMHIP_FILTER_NONE = 0,
+  OHMHIP_FILTER_GOOD = 1,
+  OHMHIP_FILTER_CLIP = 2
+};
+
+typedef struct ohmhip_map_config
+{
+  double resolution;          /* OccupancyMap::resolution()                              */
+  int region_dim[3];          /* OccupancyMap::regionVoxelDimensions(); 0 => 32          */
+  double origin[3];           /* OccupancyMap::origin()                                  */
+  unsigned layers;            /* OHMHIP_LAYER_BIT mask                                   */
+  int mode;                   /* ohmhip_map_mode                                         */
+  float hit_value;            /* OccupancyMap::hitValue()   (log odds)                   */
+  float miss_value;           /* OccupancyMap::missValue()                               */
+  float threshold_value;      /* OccupancyMap::occupancyThresholdValue()                 */
+  float min_value, max_value; /* OccupancyMap::min/maxVoxelValue()                       */
+  int saturate_at_min, saturate_at_max;
+  int ray_filter;             /* ohmhip_ray_filter                                       */
+  double ray_filter_range;
+  /* NDT (ohm/private/NdtMapDetail.h:20-45) */
+  float ndt_sensor_noise;
+  unsigned ndt_sample_threshold;
+  float ndt_adaptation_rate;
+  float ndt_reinit_threshold;
+  unsigned ndt_reinit_count;
+  float ndt_initial_intensity_cov;
+  /* TSDF (ohm/VoxelTsdf.h:27-37) */
+  float tsdf_max_weight, tsdf_trunc, tsdf_dropoff, tsdf_sparsity;
+  /* Residency: the whole map lives in HBM.  region_capacity regions are preallocated per layer (0 => derived from
+   * gpu_mem_size, itself defaulting to 4 GiB; cf. GpuCache default 1 GiB, ohmgpu/GpuCache.h:90). The pool grows by
+   * doubling when exhausted. */
+  uint64_t gpu_mem_size;
+  uint32_t region_capacity;
+} ohmhip_map_config;
+
+typedef struct ohmhip_map_s *ohmhip_map_t;
+
+/* Timing / accounting of the most recent integrate call (device side measured with hipEvents on the map's stream). */
+typedef struct ohmhip_batch_stats
+{
+  uint64_t rays_in;          /* rays submitted                                                           */
+  uint64_t rays_integrated;  /* rays that passed the filter                                              */
+  uint64_t voxel_visits;     /* exact count of miss visits + sample updates (== CPU walk visit count)    */
+  uint64_t ray_region_segments;
+  uint32_t regions_touched;
+  uint32_t regions_resident;
+  float ms_total;            /* first kernel start -> last kernel end                                    */
+  float ms_setup;            /* ray setup + region binning                                               */
+  float ms_walk;             /* the region line-walk kernel (dominant)                                   */
+  float ms_apply;            /* hit sort + ordered apply                                                 */
+} ohmhip_batch_stats;
+
+void ohmhip_map_config_default(ohmhip_map_config *config); /* reference defaults, ohm/OccupancyMap.cpp:192-223 */
+int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config); /* GpuMap ctor + gpumap::enableGpu,
+                                                                              ohmgpu/GpuMap.cpp:272, 106-122 */
+int ohmhip_map_destroy(ohmhip_map_t map);
+
+/* GpuMap::integrateRays (ohmgpu/GpuMap.cpp:416, 540-875): rays = element_count dvec3 (origin, sample pairs).
+ * Host-pointer form stages through pinned memory with hipMemcpyAsync; returns after enqueue (like the reference the
+ * call is asynchronous; ohmhip_map_sync / any read is the fence).  *integrated = points accepted (2 per ray). */
+int ohmhip_map_integrate_rays(ohmhip_map_t map, const double *rays, size_t element_count, const float *intensities,
+                              const double *timestamps, unsigned ray_flags, size_t *integrated);
+/* Same with rays (and optional intensities/timestamps) already resident in device memory. */
+int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, size_t element_count,
+                                     const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
+                                     size_t *integrated);
+/* Wait for all queued work (GpuMap::syncVoxels fence half, ohmgpu/GpuMap.cpp:308-324). */
+int ohmhip_map_sync(ohmhip_map_t map);
+int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);
+
+/* Region table (replaces GpuLayerCache::lookup, ohmgpu/GpuLayerCache.cpp:104-119). keys = int16 xyz triples. */
+int ohmhip_map_region_count(ohmhip_map_t map, size_t *count);
+int ohmhip_map_regions(ohmhip_map_t map, int16_t *keys_xyz, size_t capacity, size_t *count);
+/* Regions modified on device since the last ohmhip_map_clear_dirty (dirty-region tracking for syncVoxels). */
+int ohmhip_map_dirty_regions(ohmhip_map_t map, int16_t *keys_xyz, size_t capacity, size_t *count);
+int ohmhip_map_clear_dirty(ohmhip_map_t map);
+size_t ohmhip_layer_voxel_bytes(int layer_id);
+
+/* GpuLayerCache::syncToMainMemory (ohmgpu/GpuLayerCache.cpp:300-321, 670-696): copy `count` regions' layer blocks
+ * into dsts[i] (each region_voxels * voxel_bytes, MapChunk layout x + y*dx + z*dx*dy, ohm/MapChunk.h:33-50).
+ * Pinned staging + hipMemcpyAsync on the copy stream. */
+int ohmhip_map_read_regions(ohmhip_map_t map, int layer_id, const int16_t *keys_xyz, size_t count, void *const *dsts);
+/* GpuLayerCache::upload (ohmgpu/GpuLayerCache.cpp:172-182): make CPU-side voxel blocks resident (creates regions). */
+int ohmhip_map_write_regions(ohmhip_map_t map, int layer_id, const int16_t *keys_xyz, size_t count,
+                             const void *const *srcs);
+/* GpuCache::clear / MapRegionCache::remove (ohmgpu/GpuCache.cpp, ohm/MapRegionCache.h): drop all regions. */
+int ohmhip_map_clear(ohmhip_map_t map);
+
+/* Multi-GPU occupancy merge support: export / import additive per-region miss/hit count deltas. See
+ * DESIGN.md.  (Declared for round 2; returns OHMHIP_ERR_UNSUPPORTED until implemented.) */
+int ohmhip_map_device_layer_ptr(ohmhip_map_t map, int layer_id, void **device_ptr, size_t *region_stride_bytes);
+int ohmhip_map_region_slot(ohmhip_map_t map, const int16_t key_xyz[3], uint32_t *slot);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* OHMHIP_H */

@@ -1,0 +1,947 @@
+// occupancy_kernels.h -- the gfx950 kernels of the occupancy ray-integration path.
+//
+// Pipeline per ray batch (all on one HIP stream; see DESIGN.md for the full picture):
+//   k_ray_setup     1 lane / ray     filter, keys, fp64 line-walk set-up; enumerate the regions the ray crosses and
+//                                    count ray-region segments per region (wave-aggregated atomics)
+//   k_plan          1 block          slots for new regions, exclusive scan of segment counts, chunk work list
+//   k_ray_bin       1 lane / ray     scatter segments into per-region buckets; emit hit keys; set hit bitmask
+//   (radix sort of hit keys by region slot, voxel, ray index)
+//   k_hit_bounds    1 lane / hit     per-region [begin, end) into the sorted hit list
+//   k_region_walk   1 block / chunk  THE hot kernel: region miss-count tile in LDS, 1 lane / segment resumes the
+//                                    fp64 DDA inside the region; LDS atomics; flush tile to the region count layer
+//   k_apply_hits    1 lane / hit     ordered replay (misses-before-hit counts, hit, mean) for voxels that got samples
+//   k_apply_counts  1 block / region apply remaining miss counts to the occupancy layer, clear scratch
+//
+// Ordering argument (why integer counting reproduces the sequential CPU result exactly): every miss applies the
+// same function m(x) and every hit the same h(x) to a voxel's value.  The CPU result for a voxel is the composition
+// of its events in ray order; that composition is fully determined by the NUMBER of misses between consecutive
+// hits.  Integer atomics are order-independent, so counting is deterministic, and the float updates are then
+// replayed one voxel per lane in exactly the CPU order -> bit-identical log-odds.
+#ifndef OHMHIP_OCCUPANCY_KERNELS_H
+#define OHMHIP_OCCUPANCY_KERNELS_H
+
+#include "walk_device.h"
+
+namespace ohmhip
+{
+struct RegionTable
+{
+  unsigned long long *keys;  ///< [hash_capacity] packed region key or 0
+  uint32_t *vals;            ///< [hash_capacity] slot index
+  uint64_t *slot_keys;       ///< [slot_capacity] packed key per slot
+  uint32_t *n_slots;         ///< number of slots handed out
+  uint32_t hash_mask;
+  uint32_t slot_capacity;
+};
+
+/// Per-batch scratch indexed by hash index / slot.
+struct BatchScratch
+{
+  uint32_t *seg_count;     ///< [hash_capacity]
+  uint32_t *seg_cursor;    ///< [hash_capacity]
+  uint32_t *seg_offset;    ///< [hash_capacity]
+  uint32_t *touched_flag;  ///< [hash_capacity]
+  uint32_t *touched;       ///< [hash_capacity] list of touched hash indices
+  uint32_t *hit_begin;     ///< [slot_capacity]
+  uint32_t *hit_end;       ///< [slot_capacity]
+  uint32_t *dirty;         ///< [slot_capacity]
+  BatchInfo *info;
+};
+
+enum : uint32_t
+{
+  kErrHashFull = 1u << 0,
+  kErrSlotsFull = 1u << 1,
+  kErrSegments = 1u << 2
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Region hash table
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline uint32_t regionInsert(const RegionTable &rt, uint64_t key, uint32_t *error)
+{
+  uint32_t idx = hashRegionKey(key, rt.hash_mask);
+  for (uint32_t probe = 0; probe <= rt.hash_mask; ++probe)
+  {
+    unsigned long long prev = rt.keys[idx];
+    if (prev == 0)
+    {
+      prev = atomicCAS(&rt.keys[idx], 0ull, (unsigned long long)key);
+      if (prev == 0)
+      {
+        const uint32_t slot = atomicAdd(rt.n_slots, 1u);
+        if (slot < rt.slot_capacity)
+        {
+          rt.slot_keys[slot] = key;
+        }
+        else
+        {
+          atomicOr(error, kErrSlotsFull);
+        }
+        // Published for later kernels; nothing in this kernel reads vals[].
+        rt.vals[idx] = slot;
+        return idx;
+      }
+    }
+    if (prev == key)
+    {
+      return idx;
+    }
+    idx = (idx + 1) & rt.hash_mask;
+  }
+  atomicOr(error, kErrHashFull);
+  return 0;
+}
+
+__device__ inline uint32_t regionFind(const RegionTable &rt, uint64_t key)
+{
+  uint32_t idx = hashRegionKey(key, rt.hash_mask);
+  for (uint32_t probe = 0; probe <= rt.hash_mask; ++probe)
+  {
+    const unsigned long long k = rt.keys[idx];
+    if (k == key)
+    {
+      return idx;
+    }
+    if (k == 0)
+    {
+      break;
+    }
+    idx = (idx + 1) & rt.hash_mask;
+  }
+  return 0xffffffffu;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Region enumeration for one ray: a 3-way merge of the per-axis region-crossing steps in walk order.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RegionCursor
+{
+  int region[3];  ///< current region
+  int next_j[3];  ///< step index (1-based) of the next region crossing per axis; > total => none left
+  int dir[3];
+};
+
+__device__ inline void regionCursorInit(const MapConst &mc, const RayWalk &rw, RegionCursor &rc)
+{
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    int local;
+    splitGlobal(rw.g0[a], mc.dim[a], rc.region[a], local);
+    rc.dir[a] = rwDir(rw, a);
+    // Steps needed to leave the start region along this axis.
+    rc.next_j[a] = (rc.dir[a] > 0) ? (mc.dim[a] - local) : (local + 1);
+  }
+}
+
+/// Advance to the next region crossing.  Returns false when the ray crosses no further region boundary.
+/// On success `axis`/`j` identify the step which enters the new region and rc.region is updated.
+__device__ inline bool regionCursorNext(const MapConst &mc, const RayWalk &rw, RegionCursor &rc, int &axis, int &j)
+{
+  int best = -1;
+  double best_t = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    if (rc.next_j[a] <= rw.total[a])
+    {
+      const double t = stepTime(rw.init[a], rw.delta[a], rc.next_j[a]);
+      if (best < 0 || stepPrecedes(t, a, best_t, best))
+      {
+        best = a;
+        best_t = t;
+      }
+    }
+  }
+  if (best < 0)
+  {
+    return false;
+  }
+  axis = best;
+  j = rc.next_j[best];
+  rc.region[best] += rc.dir[best];
+  rc.next_j[best] += mc.dim[best];
+  return true;
+}
+
+/// Is the voxel reached by step (axis, j) the ray's end voxel?  (All three axes exhausted.)  True only when j is the
+/// last step on its axis and every step of the other axes precedes it.
+__device__ inline bool stepReachesEnd(const RayWalk &rw, int axis, int j)
+{
+  if (j != rw.total[axis])
+  {
+    return false;
+  }
+  const double ta = stepTime(rw.init[axis], rw.delta[axis], j);
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+  {
+    if (b != axis && rw.total[b] > 0)
+    {
+      const double tb = stepTime(rw.init[b], rw.delta[b], rw.total[b]);
+      if (!stepPrecedes(tb, b, ta, axis))
+      {
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-level aggregation: lanes with equal 64-bit keys elect a leader which performs one operation for the group.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline unsigned laneId()
+{
+  return __lane_id();
+}
+
+__device__ inline uint64_t shfl64(uint64_t v, int src)
+{
+  const uint32_t lo = __shfl(uint32_t(v), src);
+  const uint32_t hi = __shfl(uint32_t(v >> 32), src);
+  return (uint64_t(hi) << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ray_setup
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+  k_ray_setup(MapConst mc, RegionTable rt, BatchScratch bs, const double *__restrict__ rays, uint32_t n_rays,
+              unsigned ray_flags, RayWalk *__restrict__ walks)
+{
+  const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned lane = laneId();
+  RayWalk rw;
+  rw.flags = 0;
+  bool valid = false;
+  if (ray < n_rays)
+  {
+    double start[3], end[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+    {
+      start[a] = rays[size_t(ray) * 6 + a];
+      end[a] = rays[size_t(ray) * 6 + 3 + a];
+    }
+    setupRay(mc, start, end, ray_flags, rw);
+    walks[ray] = rw;
+    valid = (rw.flags & kRwValid) != 0;
+  }
+
+  // Visit accounting: Manhattan extent == number of voxels the walk reports before the end voxel.
+  unsigned long long my_visits = 0;
+  const bool walk = valid && (rw.flags & kRwWalk);
+  const int manhattan = rw.total[0] + rw.total[1] + rw.total[2];
+  if (walk)
+  {
+    my_visits += (unsigned long long)manhattan;
+    if ((rw.flags & kRwExcludeStart) && manhattan > 0)
+    {
+      --my_visits;
+    }
+    if (rw.flags & kRwIncludeEnd)
+    {
+      ++my_visits;
+    }
+  }
+  if (valid && (rw.flags & kRwApplySample))
+  {
+    ++my_visits;
+  }
+  // Wave reduce then one atomic per wave.
+  unsigned long long v = my_visits;
+  unsigned long long ok = valid ? 1ull : 0ull;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    v += shfl64(v, lane ^ off);
+    ok += shfl64(ok, lane ^ off);
+  }
+  if (lane == 0)
+  {
+    atomicAdd(&bs.info->visits, v);
+    atomicAdd(&bs.info->rays_ok, ok);
+  }
+
+  // Region enumeration.  Every iteration handles at most one (ray, region) segment per lane; lanes holding the same
+  // region are aggregated so the hash probe and the counter atomic happen once per group.
+  RegionCursor rc;
+  if (valid)
+  {
+    regionCursorInit(mc, rw, rc);
+  }
+  // phase 0: first segment (start region); phase 1: crossings; phase 2: sample region registration; 3: done
+  int phase = valid ? 0 : 3;
+  if (valid && !walk)
+  {
+    phase = 2;
+  }
+  while (__any(phase < 3))
+  {
+    bool has = false;
+    bool is_segment = false;
+    uint64_t key = 0;
+    if (phase == 0)
+    {
+      // The first segment exists if the start voxel (or, for a zero-extent ray, the end voxel) gets a miss visit.
+      const bool any_visit = manhattan > 0 || (rw.flags & kRwIncludeEnd);
+      has = any_visit;
+      is_segment = any_visit;
+      key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
+      phase = 1;
+    }
+    else if (phase == 1)
+    {
+      int axis, j;
+      if (regionCursorNext(mc, rw, rc, axis, j))
+      {
+        // Entering a region at the ray's end voxel only produces work when the end voxel is part of the ray.
+        const bool at_end = stepReachesEnd(rw, axis, j);
+        has = !at_end || (rw.flags & kRwIncludeEnd);
+        is_segment = has;
+        key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
+      }
+      else
+      {
+        phase = 2;
+      }
+    }
+    if (phase == 2 && !has)
+    {
+      if (rw.flags & kRwApplySample)
+      {
+        int r1[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+        {
+          int local;
+          splitGlobal(rw.g0[a] + rwDir(rw, a) * rw.total[a], mc.dim[a], r1[a], local);
+        }
+        has = true;
+        is_segment = false;
+        key = packRegionKey(r1[0], r1[1], r1[2]);
+      }
+      phase = 3;
+    }
+
+    unsigned long long todo = __ballot(has);
+    while (todo)
+    {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint64_t lkey = shfl64(key, leader);
+      const bool mine = has && key == lkey;
+      const unsigned long long same = __ballot(mine);
+      const unsigned long long seg_same = __ballot(mine && is_segment);
+      if (lane == unsigned(leader))
+      {
+        const uint32_t h = regionInsert(rt, lkey, &bs.info->error);
+        const uint32_t nseg = __popcll(seg_same);
+        if (nseg)
+        {
+          atomicAdd(&bs.seg_count[h], nseg);
+        }
+        if (bs.touched_flag[h] == 0 && atomicExch(&bs.touched_flag[h], 1u) == 0)
+        {
+          const uint32_t t = atomicAdd(&bs.info->n_touched, 1u);
+          bs.touched[t] = h;
+        }
+      }
+      todo &= ~same;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_plan: one block.  Exclusive scan of per-region segment counts over the touched list; build chunk list.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+  k_plan(RegionTable rt, BatchScratch bs, Chunk *__restrict__ chunks, uint32_t chunk_capacity)
+{
+  __shared__ uint32_t s_seg[1024];
+  __shared__ uint32_t s_chk[1024];
+  __shared__ uint32_t s_seg_base;
+  __shared__ uint32_t s_chk_base;
+  const uint32_t n = bs.info->n_touched;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0)
+  {
+    s_seg_base = 0;
+    s_chk_base = 0;
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024)
+  {
+    const uint32_t i = base + tid;
+    uint32_t h = 0, cnt = 0, nchk = 0;
+    if (i < n)
+    {
+      h = bs.touched[i];
+      cnt = bs.seg_count[h];
+      nchk = (cnt + kChunkSegments - 1) / kChunkSegments;
+    }
+    s_seg[tid] = cnt;
+    s_chk[tid] = nchk;
+    __syncthreads();
+    // Hillis-Steele inclusive scan (n_touched is small; this kernel is not on the critical path).
+    for (uint32_t off = 1; off < 1024; off <<= 1)
+    {
+      uint32_t a = 0, b = 0;
+      if (tid >= off)
+      {
+        a = s_seg[tid - off];
+        b = s_chk[tid - off];
+      }
+      __syncthreads();
+      s_seg[tid] += a;
+      s_chk[tid] += b;
+      __syncthreads();
+    }
+    const uint32_t seg_excl = s_seg_base + s_seg[tid] - cnt;
+    const uint32_t chk_excl = s_chk_base + s_chk[tid] - nchk;
+    if (i < n)
+    {
+      const uint32_t slot = rt.vals[h];
+      bs.seg_offset[h] = seg_excl;
+      bs.seg_cursor[h] = 0;
+      if (slot < rt.slot_capacity)
+      {
+        bs.hit_begin[slot] = 0;
+        bs.hit_end[slot] = 0;
+        bs.dirty[slot] = 1;
+      }
+      for (uint32_t c = 0; c < nchk; ++c)
+      {
+        if (chk_excl + c < chunk_capacity)
+        {
+          Chunk ch;
+          ch.slot = slot;
+          ch.seg_begin = seg_excl + c * kChunkSegments;
+          ch.seg_end = seg_excl + min(cnt, (c + 1) * kChunkSegments);
+          ch.hash_index = h;
+          chunks[chk_excl + c] = ch;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 1023)
+    {
+      s_seg_base += s_seg[1023];
+      s_chk_base += s_chk[1023];
+    }
+    __syncthreads();
+  }
+  if (tid == 0)
+  {
+    bs.info->n_segments = s_seg_base;
+    bs.info->n_chunks = s_chk_base;
+    bs.info->n_slots = *rt.n_slots;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ray_bin: scatter segments to region buckets, emit hit sort keys, set per-region hit bitmask.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+  k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
+            Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
+            uint32_t *__restrict__ hit_mask)
+{
+  const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned lane = laneId();
+  RayWalk rw;
+  rw.flags = 0;
+  if (ray < n_rays)
+  {
+    rw = walks[ray];
+  }
+  const bool valid = (rw.flags & kRwValid) != 0;
+  const bool walk = valid && (rw.flags & kRwWalk);
+  const int manhattan = rw.total[0] + rw.total[1] + rw.total[2];
+
+  // Hit key.
+  bool is_hit = false;
+  if (ray < n_rays)
+  {
+    unsigned long long hk = kHitInvalid;
+    if (valid && (rw.flags & kRwApplySample))
+    {
+      int r1[3], l1[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+      {
+        splitGlobal(rw.g0[a] + rwDir(rw, a) * rw.total[a], mc.dim[a], r1[a], l1[a]);
+      }
+      const uint32_t h = regionFind(rt, packRegionKey(r1[0], r1[1], r1[2]));
+      const uint32_t slot = (h != 0xffffffffu) ? rt.vals[h] : kSlotUnassigned;
+      if (slot < rt.slot_capacity)
+      {
+        const uint32_t vi = uint32_t(l1[0] + l1[1] * mc.dim[0] + l1[2] * mc.dim[0] * mc.dim[1]);
+        hk = ((unsigned long long)slot << kHitSlotShift) | ((unsigned long long)vi << kHitRayBits) |
+             (unsigned long long)ray;
+        atomicOr(&hit_mask[size_t(slot) * (size_t(mc.region_voxels + 31) / 32) + (vi >> 5)], 1u << (vi & 31));
+        is_hit = true;
+      }
+    }
+    hit_keys[ray] = hk;
+  }
+  {
+    const unsigned long long hit_lanes = __ballot(is_hit);
+    if (lane == 0 && hit_lanes)
+    {
+      atomicAdd(&bs.info->n_hits, uint32_t(__popcll(hit_lanes)));
+    }
+  }
+
+  RegionCursor rc;
+  if (walk)
+  {
+    regionCursorInit(mc, rw, rc);
+  }
+  int phase = walk ? 0 : 2;
+  while (__any(phase < 2))
+  {
+    bool has = false;
+    uint64_t key = 0;
+    uint32_t axis_step = 0;
+    if (phase == 0)
+    {
+      has = manhattan > 0 || (rw.flags & kRwIncludeEnd);
+      key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
+      axis_step = 3u << 30;
+      phase = 1;
+    }
+    else if (phase == 1)
+    {
+      int axis, j;
+      if (regionCursorNext(mc, rw, rc, axis, j))
+      {
+        const bool at_end = stepReachesEnd(rw, axis, j);
+        has = !at_end || (rw.flags & kRwIncludeEnd);
+        key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
+        axis_step = (uint32_t(axis) << 30) | uint32_t(j);
+      }
+      else
+      {
+        phase = 2;
+      }
+    }
+
+    unsigned long long todo = __ballot(has);
+    while (todo)
+    {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint64_t lkey = shfl64(key, leader);
+      const bool mine = has && key == lkey;
+      const unsigned long long same = __ballot(mine);
+      uint32_t base = 0;
+      if (lane == unsigned(leader))
+      {
+        const uint32_t h = regionFind(rt, lkey);
+        base = bs.seg_offset[h] + atomicAdd(&bs.seg_cursor[h], uint32_t(__popcll(same)));
+      }
+      base = __shfl(base, leader);
+      if (mine)
+      {
+        const uint32_t pos = base + __popcll(same & ((1ull << lane) - 1ull));
+        if (pos < segment_capacity)
+        {
+          Segment s;
+          s.ray = ray;
+          s.axis_step = axis_step;
+          segments[pos] = s;
+        }
+      }
+      todo &= ~same;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_hit_bounds: [begin, end) of each region slot in the sorted hit list.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+  k_hit_bounds(const unsigned long long *__restrict__ sorted, BatchScratch bs)
+{
+  const uint32_t n_hits = bs.info->n_hits;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_hits)
+  {
+    return;
+  }
+  const uint32_t slot = uint32_t(sorted[i] >> kHitSlotShift);
+  if (i == 0 || uint32_t(sorted[i - 1] >> kHitSlotShift) != slot)
+  {
+    bs.hit_begin[slot] = i;
+  }
+  if (i + 1 == n_hits || uint32_t(sorted[i + 1] >> kHitSlotShift) != slot)
+  {
+    bs.hit_end[slot] = i + 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_region_walk: the hot kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kWalkThreads = 512;
+
+__global__ void __launch_bounds__(kWalkThreads, 4)
+  k_region_walk(MapConst mc, BatchScratch bs, const Chunk *__restrict__ chunks, const Segment *__restrict__ segments,
+                const RayWalk *__restrict__ walks, const unsigned long long *__restrict__ sorted_hits,
+                const uint32_t *__restrict__ hit_mask, uint32_t *__restrict__ miss_counts,
+                uint32_t *__restrict__ interval_counts)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  // Layout: [count words: ceil(region_voxels / 2)] u16 pairs, then [mask words: ceil(region_voxels / 32)].
+  const uint32_t count_words = uint32_t(mc.region_voxels + 1) >> 1;
+  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
+  uint32_t *l_counts = lds;
+  uint32_t *l_mask = lds + count_words;
+
+  const Chunk chunk = chunks[blockIdx.x];
+  const uint32_t *g_mask = hit_mask + size_t(chunk.slot) * mask_words;
+  for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
+  {
+    l_counts[i] = 0;
+  }
+  for (uint32_t i = threadIdx.x; i < mask_words; i += kWalkThreads)
+  {
+    l_mask[i] = g_mask[i];
+  }
+  const uint32_t hb = bs.hit_begin[chunk.slot];
+  const uint32_t he = bs.hit_end[chunk.slot];
+  __syncthreads();
+
+  const int dimx = mc.dim[0];
+  const int dimxy = mc.dim[0] * mc.dim[1];
+
+  for (uint32_t si = chunk.seg_begin + threadIdx.x; si < chunk.seg_end; si += kWalkThreads)
+  {
+    const Segment seg = segments[si];
+    const RayWalk rw = walks[seg.ray];
+    const int eaxis = int(seg.axis_step >> 30);
+    const int ej = int(seg.axis_step & 0x3fffffffu);
+
+    // Resume state: steps taken per axis when the region is entered.
+    int s0 = 0, s1 = 0, s2 = 0;
+    if (eaxis < 3)
+    {
+      const double ta = stepTime(rw.init[eaxis], rw.delta[eaxis], ej);
+      s0 = (eaxis == 0) ? ej : stepsBefore(rw, 0, eaxis, ta);
+      s1 = (eaxis == 1) ? ej : stepsBefore(rw, 1, eaxis, ta);
+      s2 = (eaxis == 2) ? ej : stepsBefore(rw, 2, eaxis, ta);
+    }
+    const int d0 = rwDir(rw, 0), d1 = rwDir(rw, 1), d2 = rwDir(rw, 2);
+    int l0, l1, l2, rtmp;
+    splitGlobal(rw.g0[0] + d0 * s0, mc.dim[0], rtmp, l0);
+    splitGlobal(rw.g0[1] + d1 * s1, mc.dim[1], rtmp, l1);
+    splitGlobal(rw.g0[2] + d2 * s2, mc.dim[2], rtmp, l2);
+    int rem0 = rw.total[0] - s0, rem1 = rw.total[1] - s1, rem2 = rw.total[2] - s2;
+    // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
+    const double inf = dInf();
+    double k0 = double(s0), k1 = double(s1), k2 = double(s2);
+    double t0 = rem0 ? ((s0 == 0) ? rw.init[0] : rw.init[0] + rw.delta[0] * k0) : inf;
+    double t1 = rem1 ? ((s1 == 0) ? rw.init[1] : rw.init[1] + rw.delta[1] * k1) : inf;
+    double t2 = rem2 ? ((s2 == 0) ? rw.init[2] : rw.init[2] + rw.delta[2] * k2) : inf;
+
+    bool skip = (eaxis == 3) && (rw.flags & kRwExcludeStart);
+    const bool include_end = (rw.flags & kRwIncludeEnd) != 0;
+    const uint32_t ray_key_low = seg.ray;
+
+    while (true)
+    {
+      const bool at_end = (rem0 | rem1 | rem2) == 0;
+      if (at_end && !include_end)
+      {
+        break;
+      }
+      if (at_end || !skip)
+      {
+        const uint32_t vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
+        const bool flagged = (l_mask[vi >> 5] >> (vi & 31)) & 1u;
+        bool counted = false;
+        if (flagged)
+        {
+          // Voxel receives samples this batch: the miss must be ordered against them.  Find the first hit of this
+          // voxel whose ray index is greater than ours; the miss counts towards the interval before that hit.
+          const unsigned long long probe = ((unsigned long long)vi << kHitRayBits) | ray_key_low;
+          const unsigned long long low_mask = (1ull << kHitSlotShift) - 1ull;
+          uint32_t lo = hb, hi = he;
+          while (lo < hi)
+          {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((sorted_hits[mid] & low_mask) > probe)
+            {
+              hi = mid;
+            }
+            else
+            {
+              lo = mid + 1;
+            }
+          }
+          if (lo < he && uint32_t((sorted_hits[lo] & low_mask) >> kHitRayBits) == vi)
+          {
+            atomicAdd(&interval_counts[lo], 1u);
+            counted = true;
+          }
+        }
+        if (!counted)
+        {
+          atomicAdd(&l_counts[vi >> 1], 1u << ((vi & 1u) * 16u));
+        }
+      }
+      skip = false;
+      if (at_end)
+      {
+        break;
+      }
+      // walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
+      int axis = (t0 < t1) ? 0 : 1;
+      const double t01 = (t0 < t1) ? t0 : t1;
+      axis = (t01 < t2) ? axis : 2;
+      bool left;
+      if (axis == 0)
+      {
+        l0 += d0;
+        --rem0;
+        k0 += 1.0;
+        t0 = rem0 ? rw.init[0] + rw.delta[0] * k0 : inf;
+        left = (l0 < 0) || (l0 >= mc.dim[0]);
+      }
+      else if (axis == 1)
+      {
+        l1 += d1;
+        --rem1;
+        k1 += 1.0;
+        t1 = rem1 ? rw.init[1] + rw.delta[1] * k1 : inf;
+        left = (l1 < 0) || (l1 >= mc.dim[1]);
+      }
+      else
+      {
+        l2 += d2;
+        --rem2;
+        k2 += 1.0;
+        t2 = rem2 ? rw.init[2] + rw.delta[2] * k2 : inf;
+        left = (l2 < 0) || (l2 >= mc.dim[2]);
+      }
+      if (left)
+      {
+        break;
+      }
+    }
+  }
+  __syncthreads();
+
+  // Flush the tile: integer adds, so the merge across chunks of one region is order independent.
+  uint32_t *g_counts = miss_counts + size_t(chunk.slot) * size_t(mc.region_voxels);
+  for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
+  {
+    const uint32_t w = l_counts[i];
+    if (w)
+    {
+      const uint32_t lo = w & 0xffffu;
+      const uint32_t hi = w >> 16;
+      if (lo)
+      {
+        atomicAdd(&g_counts[2 * i], lo);
+      }
+      if (hi)
+      {
+        atomicAdd(&g_counts[2 * i + 1], hi);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Occupancy update functions (bit-for-bit the CPU mapper's per-voxel arithmetic).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline float fInf()
+{
+  return __int_as_float(0x7f800000);
+}
+
+/// One miss: ohm/RayMapperOccupancy.cpp:143-163 + ohm/VoxelOccupancyCompute.h:110-120 (null_update == false).
+__device__ inline float occMiss(const MapConst &mc, unsigned ray_flags, float initial)
+{
+  const float inf = fInf();
+  const bool unobserved = initial == inf;
+  const bool is_free = !unobserved && initial < mc.threshold_value;
+  const bool is_occ = !unobserved && initial >= mc.threshold_value;
+  float adj = mc.miss_value;
+  adj = (unobserved && (ray_flags & OHMHIP_RF_EXCLUDE_UNOBSERVED)) ? inf : adj;
+  adj = (is_free && (ray_flags & OHMHIP_RF_EXCLUDE_FREE)) ? 0.0f : adj;
+  adj = (is_occ && (ray_flags & OHMHIP_RF_EXCLUDE_OCCUPIED)) ? 0.0f : adj;
+  const float base = unobserved ? 0.0f : initial;
+  adj = (unobserved || (mc.sat_min < initial && initial < mc.sat_max)) ? adj : 0.0f;
+  return (base != inf) ? fmaxf(mc.min_value, base + adj) : base;
+}
+
+/// One hit: ohm/RayMapperOccupancy.cpp:261-281 + ohm/VoxelOccupancyCompute.h:44-54.
+__device__ inline float occHit(const MapConst &mc, unsigned ray_flags, float initial)
+{
+  const float inf = fInf();
+  const bool unobserved = initial == inf;
+  const bool is_free = !unobserved && initial < mc.threshold_value;
+  const bool is_occ = !unobserved && initial >= mc.threshold_value;
+  float adj = mc.hit_value;
+  adj = (unobserved && (ray_flags & OHMHIP_RF_EXCLUDE_UNOBSERVED)) ? inf : adj;
+  adj = (is_free && (ray_flags & OHMHIP_RF_EXCLUDE_FREE)) ? 0.0f : adj;
+  adj = (is_occ && (ray_flags & OHMHIP_RF_EXCLUDE_OCCUPIED)) ? 0.0f : adj;
+  const float base = unobserved ? 0.0f : initial;
+  adj = (unobserved || (mc.sat_min < initial && initial < mc.sat_max)) ? adj : 0.0f;
+  return (base != inf) ? fminf(base + adj, mc.max_value) : base;
+}
+
+/// n sequential misses.  The update is a deterministic function of the value alone, so once it reaches a fixed point
+/// (the min clamp) the remaining applications are the identity and can be skipped without changing the result.
+__device__ inline float occMissN(const MapConst &mc, unsigned ray_flags, float x, uint32_t n)
+{
+  for (uint32_t k = 0; k < n; ++k)
+  {
+    const float nx = occMiss(mc, ray_flags, x);
+    if (nx == x)
+    {
+      break;
+    }
+    x = nx;
+  }
+  return x;
+}
+
+/// ohm/VoxelMeanCompute.h:134-152 with Vec3 = dvec3, coord_real = double (as the CPU mappers instantiate it).
+__device__ inline uint32_t subVoxelUpdate(uint32_t coord, uint32_t point_count, const double v[3], double resolution)
+{
+  const int mean_positions = (1 << 10) - 1;
+  const double mean_resolution = resolution / double(mean_positions);
+  const double offset = double(0.5f) * resolution;
+  double mean[3];
+  mean[0] = int(coord & mean_positions) * mean_resolution - offset;
+  mean[1] = int((coord >> 10) & mean_positions) * mean_resolution - offset;
+  mean[2] = int((coord >> 20) & mean_positions) * mean_resolution - offset;
+  const double one_on_count_plus_one = double(1) / double(point_count + 1);
+  uint32_t pattern = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    mean[a] += (v[a] - mean[a]) * one_on_count_plus_one;
+    int pos = pointToRegionCoord(mean[a] + offset, mean_resolution);
+    pos = (pos >= 0 ? (pos < (1 << 10) ? pos : mean_positions) : 0);
+    pattern |= uint32_t(pos) << (10 * a);
+  }
+  return pattern | (1u << 31);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_apply_hits: one lane per sorted hit; the first hit of each voxel group replays the whole group in ray order.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+  k_apply_hits(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags,
+               const unsigned long long *__restrict__ sorted, uint32_t *__restrict__ interval_counts,
+               uint32_t *__restrict__ miss_counts, const double *__restrict__ rays, float *__restrict__ occupancy,
+               uint32_t *__restrict__ mean)
+{
+  const uint32_t n_hits = bs.info->n_hits;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_hits)
+  {
+    return;
+  }
+  const unsigned long long key = sorted[i];
+  const unsigned long long group = key >> kHitRayBits;  // slot | voxel
+  if (i > 0 && (sorted[i - 1] >> kHitRayBits) == group)
+  {
+    return;  // not the head of its voxel group
+  }
+  const uint32_t slot = uint32_t(key >> kHitSlotShift);
+  const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
+  const size_t gi = size_t(slot) * size_t(mc.region_voxels) + vi;
+  float x = occupancy[gi];
+
+  uint32_t mcoord = 0, mcount = 0;
+  double centre[3] = { 0, 0, 0 };
+  if (mean)
+  {
+    mcoord = mean[2 * gi];
+    mcount = mean[2 * gi + 1];
+    int16_t rk[3];
+    unpackRegionKey(rt.slot_keys[slot], rk);
+    const int lx = int(vi % uint32_t(mc.dim[0]));
+    const int ly = int((vi / uint32_t(mc.dim[0])) % uint32_t(mc.dim[1]));
+    const int lz = int(vi / uint32_t(mc.dim[0] * mc.dim[1]));
+    centre[0] = voxelCentreAxis(mc, 0, rk[0], lx);
+    centre[1] = voxelCentreAxis(mc, 1, rk[1], ly);
+    centre[2] = voxelCentreAxis(mc, 2, rk[2], lz);
+  }
+
+  for (uint32_t j = i; j < n_hits && (sorted[j] >> kHitRayBits) == group; ++j)
+  {
+    x = occMissN(mc, ray_flags, x, interval_counts[j]);
+    interval_counts[j] = 0;
+    x = occHit(mc, ray_flags, x);
+    if (mean)
+    {
+      const uint32_t ray = uint32_t(sorted[j] & ((1ull << kHitRayBits) - 1ull));
+      // NOTE: uses the ray's sample as submitted; the clip filter never applies a hit to a moved end point.
+      const double local[3] = { rays[size_t(ray) * 6 + 3] - centre[0], rays[size_t(ray) * 6 + 4] - centre[1],
+                                rays[size_t(ray) * 6 + 5] - centre[2] };
+      mcoord = subVoxelUpdate(mcoord, mcount, local, mc.resolution);
+      ++mcount;
+    }
+  }
+  // Misses after the last hit.
+  x = occMissN(mc, ray_flags, x, miss_counts[gi]);
+  miss_counts[gi] = 0;
+  occupancy[gi] = x;
+  if (mean)
+  {
+    mean[2 * gi] = mcoord;
+    mean[2 * gi + 1] = mcount;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_apply_counts: one block per touched region: apply plain miss counts, clear scratch.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+  k_apply_counts(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags, uint32_t *__restrict__ miss_counts,
+                 uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy)
+{
+  const uint32_t h = bs.touched[blockIdx.x];
+  const uint32_t slot = rt.vals[h];
+  const size_t base = size_t(slot) * size_t(mc.region_voxels);
+  for (uint32_t vi = threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
+  {
+    const uint32_t n = miss_counts[base + vi];
+    if (n)
+    {
+      occupancy[base + vi] = occMissN(mc, ray_flags, occupancy[base + vi], n);
+      miss_counts[base + vi] = 0;
+    }
+  }
+  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
+  for (uint32_t i = threadIdx.x; i < mask_words; i += blockDim.x)
+  {
+    hit_mask[size_t(slot) * mask_words + i] = 0;
+  }
+  if (threadIdx.x == 0)
+  {
+    bs.seg_count[h] = 0;
+    bs.seg_cursor[h] = 0;
+    bs.touched_flag[h] = 0;
+  }
+}
+
+/// Fill a float layer with a value (pool initialisation: occupancy clears to +inf, ohm/DefaultLayer.cpp:87-91).
+__global__ void k_fill_u32(uint32_t *dst, uint32_t value, size_t count)
+{
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
+  {
+    dst[i] = value;
+  }
+}
+}  // namespace ohmhip
+
+#endif  // OHMHIP_OCCUPANCY_KERNELS_H

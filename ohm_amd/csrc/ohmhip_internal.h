@@ -1,0 +1,153 @@
+// ohmhip_internal.h -- shared declarations for libohmhip.so (gfx950 only).
+#ifndef OHMHIP_INTERNAL_H
+#define OHMHIP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/ohmhip.h"
+
+#define OHMHIP_CHECK(expr)                \
+  do                                      \
+  {                                       \
+    const int err__ = static_cast<int>(expr); \
+    if (err__ != 0)                       \
+    {                                     \
+      return err__;                       \
+    }                                     \
+  } while (0)
+
+struct ohmhip_stream_s
+{
+  hipStream_t stream;
+};
+
+struct ohmhip_event_s
+{
+  hipEvent_t event;
+  bool recorded;
+};
+
+struct ohmhip_buffer_s
+{
+  void *ptr;
+  size_t bytes;
+  unsigned flags;
+};
+
+namespace ohmhip
+{
+/// Constant per-map parameters handed to every kernel by value.
+struct MapConst
+{
+  double resolution;
+  double region_dim[3];  ///< Spatial size of a region per axis (ohm/OccupancyMap.cpp:200-202).
+  double origin[3];
+  int dim[3];            ///< Voxels per region per axis.
+  int region_voxels;     ///< dim[0] * dim[1] * dim[2]
+  float hit_value;
+  float miss_value;
+  float threshold_value;
+  float min_value;
+  float max_value;
+  float sat_min;         ///< saturation_min as the CPU mapper derives it (lowest() when disabled).
+  float sat_max;
+  int filter_mode;
+  double filter_range;
+  // NDT
+  float sensor_noise;
+  unsigned sample_threshold;
+  float adaptation_rate;
+  float reinit_threshold;
+  unsigned reinit_count;
+  float initial_intensity_cov;
+  // TSDF
+  float tsdf_max_weight, tsdf_trunc, tsdf_dropoff, tsdf_sparsity;
+};
+
+/// Per-ray line-walk parameters: everything ohm/LineWalkCompute.h:260-280 derives once per ray, in fp64, plus the
+/// integer extent of the walk.  The walk state at ANY step is a pure function of the per-axis step counts because
+/// the reference recomputes `time_next = initial + delta * |stepped|` rather than accumulating it
+/// (ohm/LineWalkCompute.h:299-301).  That is what lets a region workgroup resume a ray mid-walk bit-exactly.
+struct RayWalk
+{
+  double init[3];   ///< initial_delta[]: exit time of the start voxel per axis.
+  double delta[3];  ///< step_delta[]
+  int g0[3];        ///< start voxel in global voxel coordinates (region * dim + local)
+  int total[3];     ///< |steps_remaining| at the start = Manhattan extent per axis
+  unsigned flags;   ///< kRw* bits
+  unsigned pad;
+};
+
+enum : unsigned
+{
+  kRwValid = 1u << 0,
+  kRwSign0 = 1u << 1,  ///< sign[a] (1 => negative step direction) in bits 1..3
+  kRwIncludeEnd = 1u << 4,    ///< end voxel is visited as part of the ray (clipped end / kRfEndPointAsFree)
+  kRwApplySample = 1u << 5,   ///< sample voxel receives the hit update
+  kRwExcludeStart = 1u << 6,  ///< kRfExcludeOrigin
+  kRwWalk = 1u << 7           ///< ray part is walked (not kRfExcludeRay)
+};
+
+/// One (ray, region) unit of line-walk work: "resume ray `ray` at the step that enters this region".
+/// axis == 3 => the ray's first segment (starts at the origin voxel, step 0).
+struct Segment
+{
+  uint32_t ray;
+  uint32_t axis_step;  ///< (axis << 30) | j : the j-th step along `axis` is the one that enters the region.
+};
+
+struct Chunk
+{
+  uint32_t slot;
+  uint32_t seg_begin;
+  uint32_t seg_end;
+  uint32_t hash_index;
+};
+
+/// Device-side batch summary read back by the host after the binning pass.
+struct BatchInfo
+{
+  unsigned long long visits;
+  unsigned long long rays_ok;
+  uint32_t n_touched;
+  uint32_t n_chunks;
+  uint32_t n_segments;
+  uint32_t n_slots;
+  uint32_t error;
+  uint32_t n_hits;
+};
+
+constexpr uint32_t kChunkSegments = 4096;
+constexpr uint64_t kKeyOccupied = 1ull << 63;
+constexpr uint32_t kSlotUnassigned = 0xffffffffu;
+
+// Hit sort key: [slot:20][voxel:15][ray:29]
+constexpr int kHitRayBits = 29;
+constexpr int kHitVoxelBits = 15;
+constexpr int kHitSlotShift = kHitRayBits + kHitVoxelBits;
+constexpr uint64_t kHitInvalid = ~0ull;
+
+__host__ __device__ inline uint64_t packRegionKey(int rx, int ry, int rz)
+{
+  return kKeyOccupied | uint64_t(uint16_t(rx)) | (uint64_t(uint16_t(ry)) << 16) | (uint64_t(uint16_t(rz)) << 32);
+}
+
+__host__ __device__ inline void unpackRegionKey(uint64_t key, int16_t out[3])
+{
+  out[0] = int16_t(uint16_t(key & 0xffffu));
+  out[1] = int16_t(uint16_t((key >> 16) & 0xffffu));
+  out[2] = int16_t(uint16_t((key >> 32) & 0xffffu));
+}
+
+__host__ __device__ inline uint32_t hashRegionKey(uint64_t key, uint32_t mask)
+{
+  uint64_t h = key * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  return uint32_t(h) & mask;
+}
+}  // namespace ohmhip
+
+#endif  // OHMHIP_INTERNAL_H

@@ -1,0 +1,1129 @@
+// ohmhip_map.hip -- host side of the typed hot-path C ABI: a voxel map resident in HBM, region table, ray batch
+// pipeline and region download/upload.  gfx950 / ROCm only; see include/ohmhip.h for reference citations.
+#include <cstring>
+#include <string.h>
+
+#include "occupancy_kernels.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+using namespace ohmhip;
+
+namespace
+{
+const size_t kLayerBytes[OHMHIP_LID_COUNT] = { 4, 8, 24, 4, 4, 4, 8, 8, 8 };
+
+struct DevBuf
+{
+  void *ptr = nullptr;
+  size_t bytes = 0;
+
+  int ensure(size_t want, bool zero, hipStream_t stream)
+  {
+    if (want <= bytes)
+    {
+      return OHMHIP_OK;
+    }
+    if (ptr)
+    {
+      OHMHIP_CHECK(hipStreamSynchronize(stream));
+      OHMHIP_CHECK(hipFree(ptr));
+      ptr = nullptr;
+      bytes = 0;
+    }
+    // Grow geometrically so steady-state batches never reallocate.
+    size_t alloc = std::max(want, size_t(1) << 16);
+    alloc = (alloc + (alloc >> 2) + 255) & ~size_t(255);
+    OHMHIP_CHECK(hipMalloc(&ptr, alloc));
+    bytes = alloc;
+    if (zero)
+    {
+      OHMHIP_CHECK(hipMemsetAsync(ptr, 0, alloc, stream));
+    }
+    return OHMHIP_OK;
+  }
+
+  void release()
+  {
+    if (ptr)
+    {
+      (void)hipFree(ptr);
+    }
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+}  // namespace
+
+struct ohmhip_map_s
+{
+  ohmhip_map_config config;
+  MapConst mc;
+  int device = 0;
+  hipStream_t stream = nullptr;       ///< compute stream
+  hipStream_t copy_stream = nullptr;  ///< side stream for region upload/download
+  hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+
+  uint32_t slot_capacity = 0;
+  uint32_t hash_capacity = 0;
+  uint32_t slots_committed = 0;  ///< slots in use after the last successful batch / upload
+
+  void *layers[OHMHIP_LID_COUNT] = {};
+  unsigned long long *d_keys = nullptr;
+  uint32_t *d_vals = nullptr;
+  uint64_t *d_slot_keys = nullptr;
+  uint32_t *d_n_slots = nullptr;
+  // scratch
+  uint32_t *d_seg_count = nullptr, *d_seg_cursor = nullptr, *d_seg_offset = nullptr, *d_touched_flag = nullptr,
+           *d_touched = nullptr;
+  uint32_t *d_hit_begin = nullptr, *d_hit_end = nullptr, *d_dirty = nullptr;
+  BatchInfo *d_info = nullptr;
+  BatchInfo *h_info = nullptr;  ///< pinned
+  uint32_t *d_miss_counts = nullptr;
+  uint32_t *d_hit_mask = nullptr;
+  Chunk *d_chunks = nullptr;
+  uint32_t chunk_capacity = 0;
+
+  DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev;
+  void *h_stage = nullptr;  ///< pinned staging for host rays / region copies
+  size_t h_stage_bytes = 0;
+
+  // host mirror of the region table
+  std::unordered_map<uint64_t, uint32_t> region_slots;
+  std::vector<uint64_t> slot_keys_host;
+
+  ohmhip_batch_stats stats = {};
+  bool stats_pending = false;
+};
+
+namespace
+{
+RegionTable regionTable(ohmhip_map_t m)
+{
+  RegionTable rt;
+  rt.keys = m->d_keys;
+  rt.vals = m->d_vals;
+  rt.slot_keys = m->d_slot_keys;
+  rt.n_slots = m->d_n_slots;
+  rt.hash_mask = m->hash_capacity - 1;
+  rt.slot_capacity = m->slot_capacity;
+  return rt;
+}
+
+BatchScratch batchScratch(ohmhip_map_t m)
+{
+  BatchScratch bs;
+  bs.seg_count = m->d_seg_count;
+  bs.seg_cursor = m->d_seg_cursor;
+  bs.seg_offset = m->d_seg_offset;
+  bs.touched_flag = m->d_touched_flag;
+  bs.touched = m->d_touched;
+  bs.hit_begin = m->d_hit_begin;
+  bs.hit_end = m->d_hit_end;
+  bs.dirty = m->d_dirty;
+  bs.info = m->d_info;
+  return bs;
+}
+
+__global__ void k_rehash(RegionTable rt, uint32_t n)
+{
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n)
+  {
+    return;
+  }
+  const uint64_t key = rt.slot_keys[slot];
+  uint32_t idx = hashRegionKey(key, rt.hash_mask);
+  while (true)
+  {
+    const unsigned long long prev = atomicCAS(&rt.keys[idx], 0ull, (unsigned long long)key);
+    if (prev == 0)
+    {
+      rt.vals[idx] = slot;
+      return;
+    }
+    idx = (idx + 1) & rt.hash_mask;
+  }
+}
+
+uint32_t nextPow2(uint32_t v)
+{
+  uint32_t p = 1;
+  while (p < v)
+  {
+    p <<= 1;
+  }
+  return p;
+}
+
+size_t bytesPerRegionAllLayers(const ohmhip_map_config &c, int region_voxels)
+{
+  size_t b = 0;
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    if (c.layers & (1u << l))
+    {
+      b += kLayerBytes[l] * size_t(region_voxels);
+    }
+  }
+  // + miss count layer + hit mask
+  b += 4 * size_t(region_voxels) + size_t((region_voxels + 31) / 32) * 4;
+  return b;
+}
+
+void freePool(ohmhip_map_t m)
+{
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    if (m->layers[l])
+    {
+      (void)hipFree(m->layers[l]);
+      m->layers[l] = nullptr;
+    }
+  }
+  void *ptrs[] = { m->d_keys,       m->d_vals,        m->d_slot_keys, m->d_seg_count, m->d_seg_cursor,
+                   m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_hit_begin, m->d_hit_end,
+                   m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks };
+  for (void *p : ptrs)
+  {
+    if (p)
+    {
+      (void)hipFree(p);
+    }
+  }
+  m->d_keys = nullptr;
+  m->d_vals = nullptr;
+  m->d_slot_keys = nullptr;
+  m->d_seg_count = m->d_seg_cursor = m->d_seg_offset = m->d_touched_flag = m->d_touched = nullptr;
+  m->d_hit_begin = m->d_hit_end = m->d_dirty = nullptr;
+  m->d_miss_counts = m->d_hit_mask = nullptr;
+  m->d_chunks = nullptr;
+}
+
+/// (Re)allocate the region pool for `capacity` regions, preserving the first `keep` slots' contents.
+int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
+{
+  const size_t rv = size_t(m->mc.region_voxels);
+  const uint32_t hash_cap = nextPow2(std::max<uint32_t>(1024u, capacity * 2u));
+  hipStream_t s = m->stream;
+
+  void *new_layers[OHMHIP_LID_COUNT] = {};
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    if (!(m->config.layers & (1u << l)))
+    {
+      continue;
+    }
+    const size_t stride = rv * kLayerBytes[l];
+    OHMHIP_CHECK(hipMalloc(&new_layers[l], stride * capacity));
+    if (keep && m->layers[l])
+    {
+      OHMHIP_CHECK(hipMemcpyAsync(new_layers[l], m->layers[l], stride * keep, hipMemcpyDeviceToDevice, s));
+    }
+    char *tail = static_cast<char *>(new_layers[l]) + stride * keep;
+    const size_t tail_bytes = stride * (capacity - keep);
+    if (l == OHMHIP_LID_OCCUPANCY)
+    {
+      // Occupancy clears to +inf == unobserved (ohm/DefaultLayer.cpp:87-91, ohm/VoxelOccupancy.h:42-45).
+      const size_t count = tail_bytes / 4;
+      if (count)
+      {
+        hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint32_t *>(tail), 0x7f800000u,
+                           count);
+      }
+    }
+    else if (tail_bytes)
+    {
+      OHMHIP_CHECK(hipMemsetAsync(tail, 0, tail_bytes, s));
+    }
+  }
+
+  uint64_t *new_slot_keys = nullptr;
+  OHMHIP_CHECK(hipMalloc(&new_slot_keys, sizeof(uint64_t) * capacity));
+  OHMHIP_CHECK(hipMemsetAsync(new_slot_keys, 0, sizeof(uint64_t) * capacity, s));
+  if (keep && m->d_slot_keys)
+  {
+    OHMHIP_CHECK(hipMemcpyAsync(new_slot_keys, m->d_slot_keys, sizeof(uint64_t) * keep, hipMemcpyDeviceToDevice, s));
+  }
+  uint32_t *new_dirty = nullptr;
+  OHMHIP_CHECK(hipMalloc(&new_dirty, sizeof(uint32_t) * capacity));
+  OHMHIP_CHECK(hipMemsetAsync(new_dirty, 0, sizeof(uint32_t) * capacity, s));
+  if (keep && m->d_dirty)
+  {
+    OHMHIP_CHECK(hipMemcpyAsync(new_dirty, m->d_dirty, sizeof(uint32_t) * keep, hipMemcpyDeviceToDevice, s));
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+
+  // Swap in: free everything old except what we carried over.
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    if (m->layers[l])
+    {
+      (void)hipFree(m->layers[l]);
+    }
+    m->layers[l] = new_layers[l];
+  }
+  void *old[] = { m->d_keys,       m->d_vals,         m->d_slot_keys, m->d_seg_count, m->d_seg_cursor,
+                  m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_hit_begin, m->d_hit_end,
+                  m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks };
+  for (void *p : old)
+  {
+    if (p)
+    {
+      (void)hipFree(p);
+    }
+  }
+  m->d_slot_keys = new_slot_keys;
+  m->d_dirty = new_dirty;
+  m->slot_capacity = capacity;
+  m->hash_capacity = hash_cap;
+
+  auto zalloc = [&](void **p, size_t bytes) -> int {
+    OHMHIP_CHECK(hipMalloc(p, bytes));
+    OHMHIP_CHECK(hipMemsetAsync(*p, 0, bytes, s));
+    return OHMHIP_OK;
+  };
+  int err = OHMHIP_OK;
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_keys), sizeof(unsigned long long) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_vals), sizeof(uint32_t) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_count), sizeof(uint32_t) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_cursor), sizeof(uint32_t) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_offset), sizeof(uint32_t) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_touched_flag), sizeof(uint32_t) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_touched), sizeof(uint32_t) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_begin), sizeof(uint32_t) * capacity);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_end), sizeof(uint32_t) * capacity);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_miss_counts), sizeof(uint32_t) * rv * capacity);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_mask), sizeof(uint32_t) * ((rv + 31) / 32) * capacity);
+  m->chunk_capacity = capacity + (1u << 16);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_chunks), sizeof(Chunk) * m->chunk_capacity);
+  if (err)
+  {
+    return err;
+  }
+  OHMHIP_CHECK(hipMemcpyAsync(m->d_n_slots, &keep, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  if (keep)
+  {
+    hipLaunchKernelGGL(k_rehash, dim3((keep + 255) / 256), dim3(256), 0, s, regionTable(m), keep);
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+  OHMHIP_CHECK(hipGetLastError());
+  return OHMHIP_OK;
+}
+
+/// Restore the region table after a batch that overflowed the pool: drop regions the failed batch inserted.
+int rollbackAndGrow(ohmhip_map_t m, uint32_t needed)
+{
+  uint32_t cap = m->slot_capacity;
+  while (cap < needed)
+  {
+    cap *= 2;
+  }
+  // Check memory budget: refuse if the new pool cannot fit in free device memory.
+  size_t free_b = 0, total_b = 0;
+  OHMHIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  const size_t need_b = bytesPerRegionAllLayers(m->config, m->mc.region_voxels) * size_t(cap);
+  if (need_b > free_b)
+  {
+    return OHMHIP_ERR_CAPACITY;
+  }
+  return allocPool(m, cap, m->slots_committed);
+}
+
+int refreshHostRegionTable(ohmhip_map_t m)
+{
+  const uint32_t n = m->slots_committed;
+  if (m->slot_keys_host.size() == n)
+  {
+    return OHMHIP_OK;
+  }
+  const size_t old = m->slot_keys_host.size();
+  m->slot_keys_host.resize(n);
+  if (n > old)
+  {
+    OHMHIP_CHECK(hipMemcpy(m->slot_keys_host.data() + old, m->d_slot_keys + old, sizeof(uint64_t) * (n - old),
+                           hipMemcpyDeviceToHost));
+    for (size_t i = old; i < n; ++i)
+    {
+      m->region_slots[m->slot_keys_host[i]] = uint32_t(i);
+    }
+  }
+  return OHMHIP_OK;
+}
+
+int ensureStage(ohmhip_map_t m, size_t bytes)
+{
+  if (bytes <= m->h_stage_bytes)
+  {
+    return OHMHIP_OK;
+  }
+  if (m->h_stage)
+  {
+    OHMHIP_CHECK(hipHostFree(m->h_stage));
+    m->h_stage = nullptr;
+    m->h_stage_bytes = 0;
+  }
+  OHMHIP_CHECK(hipHostMalloc(&m->h_stage, bytes, hipHostMallocDefault));
+  m->h_stage_bytes = bytes;
+  return OHMHIP_OK;
+}
+
+/// The occupancy batch pipeline.  d_rays: device pointer to 6 doubles per ray.
+int integrateOccupancy(ohmhip_map_t m, const double *d_rays, uint32_t n_rays, unsigned ray_flags)
+{
+  hipStream_t s = m->stream;
+  const uint32_t ray_blocks = (n_rays + 255) / 256;
+
+  OHMHIP_CHECK(m->walks.ensure(sizeof(RayWalk) * size_t(n_rays), false, s));
+  OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
+  OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
+  OHMHIP_CHECK(m->interval_counts.ensure(sizeof(uint32_t) * size_t(n_rays), true, s));
+  size_t sort_bytes = 0;
+  OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, static_cast<unsigned long long *>(m->hit_keys_a.ptr),
+                                        static_cast<unsigned long long *>(m->hit_keys_b.ptr), size_t(n_rays), 0, 64,
+                                        s));
+  OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
+
+  for (int attempt = 0; attempt < 8; ++attempt)
+  {
+    OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, sizeof(BatchInfo), s));
+    OHMHIP_CHECK(hipEventRecord(m->ev[0], s));
+    hipLaunchKernelGGL(k_ray_setup, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
+                       n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr));
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
+                       m->chunk_capacity);
+    OHMHIP_CHECK(hipMemcpyAsync(m->h_info, m->d_info, sizeof(BatchInfo), hipMemcpyDeviceToHost, s));
+    OHMHIP_CHECK(hipStreamSynchronize(s));
+    OHMHIP_CHECK(hipGetLastError());
+    const BatchInfo info = *m->h_info;
+    if ((info.error & (kErrSlotsFull | kErrHashFull)) || info.n_slots > m->slot_capacity ||
+        info.n_chunks > m->chunk_capacity)
+    {
+      // Pool exhausted: forget what this batch inserted, grow, retry.
+      const int err = rollbackAndGrow(m, std::max(info.n_slots, m->slot_capacity * 2u));
+      if (err)
+      {
+        return err;
+      }
+      continue;
+    }
+
+    m->slots_committed = info.n_slots;
+    OHMHIP_CHECK(m->segments.ensure(sizeof(Segment) * size_t(std::max<uint32_t>(info.n_segments, 1u)), false, s));
+    const uint32_t seg_cap = uint32_t(std::min<size_t>(m->segments.bytes / sizeof(Segment), 0xffffffffu));
+
+    hipLaunchKernelGGL(k_ray_bin, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
+                       static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
+                       seg_cap, static_cast<unsigned long long *>(m->hit_keys_a.ptr), m->d_hit_mask);
+    OHMHIP_CHECK(hipEventRecord(m->ev[1], s));
+    size_t temp_bytes = m->sort_temp.bytes;
+    OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes,
+                                          static_cast<unsigned long long *>(m->hit_keys_a.ptr),
+                                          static_cast<unsigned long long *>(m->hit_keys_b.ptr), size_t(n_rays), 0, 64,
+                                          s));
+    const unsigned long long *sorted = static_cast<const unsigned long long *>(m->hit_keys_b.ptr);
+    hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m));
+    OHMHIP_CHECK(hipEventRecord(m->ev[2], s));
+    if (info.n_chunks)
+    {
+      const size_t lds_bytes =
+        (size_t((m->mc.region_voxels + 1) / 2) + size_t((m->mc.region_voxels + 31) / 32)) * sizeof(uint32_t);
+      hipLaunchKernelGGL(k_region_walk, dim3(info.n_chunks), dim3(kWalkThreads), lds_bytes, s, m->mc, batchScratch(m),
+                         m->d_chunks, static_cast<const Segment *>(m->segments.ptr),
+                         static_cast<const RayWalk *>(m->walks.ptr), sorted, m->d_hit_mask, m->d_miss_counts,
+                         static_cast<uint32_t *>(m->interval_counts.ptr));
+    }
+    OHMHIP_CHECK(hipEventRecord(m->ev[3], s));
+    hipLaunchKernelGGL(k_apply_hits, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
+                       ray_flags, sorted, static_cast<uint32_t *>(m->interval_counts.ptr), m->d_miss_counts, d_rays,
+                       static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
+                       static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]));
+    if (info.n_touched)
+    {
+      hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
+                         ray_flags, m->d_miss_counts, m->d_hit_mask,
+                         static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]));
+    }
+    OHMHIP_CHECK(hipEventRecord(m->ev[4], s));
+    OHMHIP_CHECK(hipGetLastError());
+
+    m->stats = {};
+    m->stats.rays_in = n_rays;
+    m->stats.rays_integrated = info.rays_ok;
+    m->stats.voxel_visits = info.visits;
+    m->stats.ray_region_segments = info.n_segments;
+    m->stats.regions_touched = info.n_touched;
+    m->stats.regions_resident = info.n_slots;
+    m->stats_pending = true;
+    return OHMHIP_OK;
+  }
+  return OHMHIP_ERR_CAPACITY;
+}
+}  // namespace
+
+extern "C" {
+
+size_t ohmhip_layer_voxel_bytes(int layer_id)
+{
+  return (layer_id >= 0 && layer_id < OHMHIP_LID_COUNT) ? kLayerBytes[layer_id] : 0;
+}
+
+void ohmhip_map_config_default(ohmhip_map_config *c)
+{
+  if (!c)
+  {
+    return;
+  }
+  std::memset(c, 0, sizeof(*c));
+  c->resolution = 0.1;
+  c->region_dim[0] = c->region_dim[1] = c->region_dim[2] = 32;  // ohm/OccupancyMap.h:24-26
+  c->layers = OHMHIP_LAYER_BIT(OHMHIP_LID_OCCUPANCY);
+  c->mode = OHMHIP_MODE_OCCUPANCY;
+  // ohm/OccupancyMap.cpp:205-213; probabilityToValue (ohm/MapProbability.h:33-36) in float.
+  c->hit_value = std::log(0.9f / (1.0f - 0.9f));
+  c->miss_value = std::log(0.45f / (1.0f - 0.45f));
+  c->threshold_value = std::log(0.5f / (1.0f - 0.5f));
+  c->min_value = -2.0f;
+  c->max_value = 3.511f;
+  c->ray_filter = OHMHIP_FILTER_GOOD;  // ohm/OccupancyMap.cpp:215-218
+  c->ray_filter_range = 1e10;
+  // ohm/private/NdtMapDetail.h:20-45
+  c->ndt_sensor_noise = 0.05f;
+  c->ndt_sample_threshold = 3;
+  {
+    // NdtMap ctor: adaptation rate from the map's miss probability (ohm/NdtMap.cpp:31-36, ohm/NdtMap.h:146-149).
+    const float miss_probability = 1.0f - (1.0f / (1.0f + std::exp(c->miss_value)));
+    c->ndt_adaptation_rate = std::max(0.0f, std::min(2.0f * (1.0f - 2.0f * miss_probability), 1.0f));
+  }
+  c->ndt_reinit_threshold = std::log(0.2f / (1.0f - 0.2f));
+  c->ndt_reinit_count = 100;
+  c->ndt_initial_intensity_cov = 1.0f;
+  // ohm/VoxelTsdf.h:27-37
+  c->tsdf_max_weight = 1e4f;
+  c->tsdf_trunc = 0.1f;
+  c->tsdf_dropoff = 0.0f;
+  c->tsdf_sparsity = 1.0f;
+  c->gpu_mem_size = 0;
+  c->region_capacity = 0;
+}
+
+int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
+{
+  if (!map || !config || !(config->resolution > 0))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  int count = 0;
+  const int derr = ohmhip_device_count(&count);
+  if (derr || count == 0)
+  {
+    return derr ? derr : OHMHIP_ERR_NO_DEVICE;
+  }
+  ohmhip_map_t m = new (std::nothrow) ohmhip_map_s;
+  if (!m)
+  {
+    return OHMHIP_ERR_INTERNAL;
+  }
+  m->config = *config;
+  for (int a = 0; a < 3; ++a)
+  {
+    if (m->config.region_dim[a] <= 0)
+    {
+      m->config.region_dim[a] = 32;
+    }
+    if (m->config.region_dim[a] > 255)
+    {
+      delete m;
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+  }
+  MapConst &mc = m->mc;
+  std::memset(&mc, 0, sizeof(mc));
+  mc.resolution = m->config.resolution;
+  for (int a = 0; a < 3; ++a)
+  {
+    mc.dim[a] = m->config.region_dim[a];
+    mc.region_dim[a] = mc.dim[a] * mc.resolution;  // ohm/OccupancyMap.cpp:200-202
+    mc.origin[a] = m->config.origin[a];
+  }
+  mc.region_voxels = mc.dim[0] * mc.dim[1] * mc.dim[2];
+  if (mc.region_voxels > (1 << kHitVoxelBits))
+  {
+    delete m;
+    return OHMHIP_ERR_UNSUPPORTED;  // region tile must fit the LDS count tile / 15-bit voxel index
+  }
+  mc.hit_value = m->config.hit_value;
+  mc.miss_value = m->config.miss_value;
+  mc.threshold_value = m->config.threshold_value;
+  mc.min_value = m->config.min_value;
+  mc.max_value = m->config.max_value;
+  // ohm/RayMapperOccupancy.cpp:92-93
+  mc.sat_min = m->config.saturate_at_min ? mc.min_value : std::numeric_limits<float>::lowest();
+  mc.sat_max = m->config.saturate_at_max ? mc.max_value : std::numeric_limits<float>::max();
+  mc.filter_mode = m->config.ray_filter;
+  mc.filter_range = m->config.ray_filter_range;
+  mc.sensor_noise = m->config.ndt_sensor_noise;
+  mc.sample_threshold = m->config.ndt_sample_threshold;
+  mc.adaptation_rate = m->config.ndt_adaptation_rate;
+  mc.reinit_threshold = m->config.ndt_reinit_threshold;
+  mc.reinit_count = m->config.ndt_reinit_count;
+  mc.initial_intensity_cov = m->config.ndt_initial_intensity_cov;
+  mc.tsdf_max_weight = m->config.tsdf_max_weight;
+  mc.tsdf_trunc = m->config.tsdf_trunc;
+  mc.tsdf_dropoff = m->config.tsdf_dropoff;
+  mc.tsdf_sparsity = m->config.tsdf_sparsity;
+
+  int err = OHMHIP_OK;
+  auto fail = [&](int e) {
+    ohmhip_map_destroy(m);
+    return e;
+  };
+  if (hipGetDevice(&m->device) != hipSuccess)
+  {
+    return fail(OHMHIP_ERR_NO_DEVICE);
+  }
+  if ((err = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)) != 0)
+  {
+    return fail(err);
+  }
+  if ((err = hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking)) != 0)
+  {
+    return fail(err);
+  }
+  for (auto &e : m->ev)
+  {
+    if ((err = hipEventCreate(&e)) != 0)
+    {
+      return fail(err);
+    }
+  }
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_n_slots), sizeof(uint32_t))) != 0)
+  {
+    return fail(err);
+  }
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_info), sizeof(BatchInfo))) != 0)
+  {
+    return fail(err);
+  }
+  if ((err = hipHostMalloc(reinterpret_cast<void **>(&m->h_info), sizeof(BatchInfo), hipHostMallocDefault)) != 0)
+  {
+    return fail(err);
+  }
+
+  uint32_t capacity = m->config.region_capacity;
+  if (capacity == 0)
+  {
+    const uint64_t budget = m->config.gpu_mem_size ? m->config.gpu_mem_size : (uint64_t(4) << 30);
+    capacity = uint32_t(std::max<uint64_t>(64, budget / bytesPerRegionAllLayers(m->config, mc.region_voxels)));
+  }
+  capacity = std::min<uint32_t>(capacity, (1u << 20) - 2);  // 20-bit slot field of the hit key
+  if ((err = allocPool(m, capacity, 0)) != 0)
+  {
+    return fail(err);
+  }
+  // The walk kernel stages a region's count tile + hit mask in LDS (68 KiB for 32^3).
+  const size_t lds_bytes = (size_t((mc.region_voxels + 1) / 2) + size_t((mc.region_voxels + 31) / 32)) * 4;
+  if ((err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_walk),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
+  {
+    return fail(err);
+  }
+  *map = m;
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_destroy(ohmhip_map_t m)
+{
+  if (!m)
+  {
+    return OHMHIP_OK;
+  }
+  if (m->stream)
+  {
+    (void)hipStreamSynchronize(m->stream);
+  }
+  if (m->copy_stream)
+  {
+    (void)hipStreamSynchronize(m->copy_stream);
+  }
+  freePool(m);
+  m->walks.release();
+  m->hit_keys_a.release();
+  m->hit_keys_b.release();
+  m->interval_counts.release();
+  m->segments.release();
+  m->sort_temp.release();
+  m->rays_dev.release();
+  m->intens_dev.release();
+  m->times_dev.release();
+  if (m->d_n_slots)
+  {
+    (void)hipFree(m->d_n_slots);
+  }
+  if (m->d_info)
+  {
+    (void)hipFree(m->d_info);
+  }
+  if (m->h_info)
+  {
+    (void)hipHostFree(m->h_info);
+  }
+  if (m->h_stage)
+  {
+    (void)hipHostFree(m->h_stage);
+  }
+  for (auto &e : m->ev)
+  {
+    if (e)
+    {
+      (void)hipEventDestroy(e);
+    }
+  }
+  if (m->stream)
+  {
+    (void)hipStreamDestroy(m->stream);
+  }
+  if (m->copy_stream)
+  {
+    (void)hipStreamDestroy(m->copy_stream);
+  }
+  delete m;
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_t element_count,
+                                     const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
+                                     size_t *integrated)
+{
+  (void)d_intensities;
+  (void)d_timestamps;
+  if (integrated)
+  {
+    *integrated = 0;
+  }
+  if (!m || (!d_rays && element_count))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED)
+  {
+    return OHMHIP_ERR_UNSUPPORTED;
+  }
+  const size_t n_rays = element_count / 2;
+  if (n_rays == 0)
+  {
+    return OHMHIP_OK;
+  }
+  if (n_rays >= (size_t(1) << kHitRayBits))
+  {
+    return OHMHIP_ERR_INVALID_ARG;  // split larger batches at the caller (29-bit ray index in the hit key)
+  }
+  int err = OHMHIP_ERR_UNSUPPORTED;
+  switch (m->config.mode)
+  {
+  case OHMHIP_MODE_OCCUPANCY:
+    if (!m->layers[OHMHIP_LID_OCCUPANCY])
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+    err = integrateOccupancy(m, d_rays, uint32_t(n_rays), ray_flags);
+    break;
+  default:
+    break;
+  }
+  if (err == OHMHIP_OK && integrated)
+  {
+    *integrated = size_t(m->stats.rays_integrated) * 2;
+  }
+  return err;
+}
+
+int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
+                              const double *timestamps, unsigned ray_flags, size_t *integrated)
+{
+  if (integrated)
+  {
+    *integrated = 0;
+  }
+  if (!m || (!rays && element_count))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  const size_t n_rays = element_count / 2;
+  if (n_rays == 0)
+  {
+    return OHMHIP_OK;
+  }
+  hipStream_t s = m->stream;
+  const size_t ray_bytes = n_rays * 6 * sizeof(double);
+  OHMHIP_CHECK(m->rays_dev.ensure(ray_bytes, false, s));
+  // The previous batch may still be reading the staging buffer's device copy; the stream orders the copies.
+  int err = ensureStage(m, ray_bytes);
+  if (err)
+  {
+    return err;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(s));  // staging buffer reuse fence
+  std::memcpy(m->h_stage, rays, ray_bytes);
+  OHMHIP_CHECK(hipMemcpyAsync(m->rays_dev.ptr, m->h_stage, ray_bytes, hipMemcpyHostToDevice, s));
+  const float *d_int = nullptr;
+  const double *d_ts = nullptr;
+  if (intensities)
+  {
+    OHMHIP_CHECK(m->intens_dev.ensure(n_rays * sizeof(float), false, s));
+    OHMHIP_CHECK(hipMemcpyAsync(m->intens_dev.ptr, intensities, n_rays * sizeof(float), hipMemcpyHostToDevice, s));
+    d_int = static_cast<const float *>(m->intens_dev.ptr);
+  }
+  if (timestamps)
+  {
+    OHMHIP_CHECK(m->times_dev.ensure(n_rays * sizeof(double), false, s));
+    OHMHIP_CHECK(hipMemcpyAsync(m->times_dev.ptr, timestamps, n_rays * sizeof(double), hipMemcpyHostToDevice, s));
+    d_ts = static_cast<const double *>(m->times_dev.ptr);
+  }
+  return ohmhip_map_integrate_rays_device(m, static_cast<const double *>(m->rays_dev.ptr), element_count, d_int, d_ts,
+                                          ray_flags, integrated);
+}
+
+int ohmhip_map_sync(ohmhip_map_t m)
+{
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_last_stats(ohmhip_map_t m, ohmhip_batch_stats *stats)
+{
+  if (!m || !stats)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (m->stats_pending)
+  {
+    OHMHIP_CHECK(hipEventSynchronize(m->ev[4]));
+    float ms = 0;
+    OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[0], m->ev[4]));
+    m->stats.ms_total = ms;
+    OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
+    m->stats.ms_setup = ms;
+    OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[2], m->ev[3]));
+    m->stats.ms_walk = ms;
+    float ms_sort = 0, ms_apply = 0;
+    OHMHIP_CHECK(hipEventElapsedTime(&ms_sort, m->ev[1], m->ev[2]));
+    OHMHIP_CHECK(hipEventElapsedTime(&ms_apply, m->ev[3], m->ev[4]));
+    m->stats.ms_apply = ms_sort + ms_apply;
+    m->stats_pending = false;
+  }
+  *stats = m->stats;
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_region_count(ohmhip_map_t m, size_t *count)
+{
+  if (!m || !count)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  *count = m->slots_committed;
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity, size_t *count)
+{
+  if (!m || !count)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  const int err = refreshHostRegionTable(m);
+  if (err)
+  {
+    return err;
+  }
+  *count = m->slot_keys_host.size();
+  for (size_t i = 0; i < m->slot_keys_host.size() && i < capacity && keys_xyz; ++i)
+  {
+    unpackRegionKey(m->slot_keys_host[i], keys_xyz + 3 * i);
+  }
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_dirty_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity, size_t *count)
+{
+  if (!m || !count)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  int err = refreshHostRegionTable(m);
+  if (err)
+  {
+    return err;
+  }
+  std::vector<uint32_t> dirty(m->slots_committed);
+  if (!dirty.empty())
+  {
+    OHMHIP_CHECK(hipMemcpy(dirty.data(), m->d_dirty, sizeof(uint32_t) * dirty.size(), hipMemcpyDeviceToHost));
+  }
+  size_t n = 0;
+  for (size_t i = 0; i < dirty.size(); ++i)
+  {
+    if (dirty[i])
+    {
+      if (keys_xyz && n < capacity)
+      {
+        unpackRegionKey(m->slot_keys_host[i], keys_xyz + 3 * n);
+      }
+      ++n;
+    }
+  }
+  *count = n;
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_clear_dirty(ohmhip_map_t m)
+{
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_CHECK(hipMemsetAsync(m->d_dirty, 0, sizeof(uint32_t) * m->slot_capacity, m->stream));
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_region_slot(ohmhip_map_t m, const int16_t key_xyz[3], uint32_t *slot)
+{
+  if (!m || !key_xyz || !slot)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  const int err = refreshHostRegionTable(m);
+  if (err)
+  {
+    return err;
+  }
+  const auto it = m->region_slots.find(packRegionKey(key_xyz[0], key_xyz[1], key_xyz[2]));
+  if (it == m->region_slots.end())
+  {
+    return OHMHIP_ERR_NOT_FOUND;
+  }
+  *slot = it->second;
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_device_layer_ptr(ohmhip_map_t m, int layer_id, void **device_ptr, size_t *region_stride_bytes)
+{
+  if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || !device_ptr)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (!m->layers[layer_id])
+  {
+    return OHMHIP_ERR_NOT_FOUND;
+  }
+  *device_ptr = m->layers[layer_id];
+  if (region_stride_bytes)
+  {
+    *region_stride_bytes = size_t(m->mc.region_voxels) * kLayerBytes[layer_id];
+  }
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_read_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, size_t count, void *const *dsts)
+{
+  if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || (count && (!keys_xyz || !dsts)))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (!m->layers[layer_id])
+  {
+    return OHMHIP_ERR_NOT_FOUND;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));  // fence: all queued integration done
+  int err = refreshHostRegionTable(m);
+  if (err)
+  {
+    return err;
+  }
+  const size_t stride = size_t(m->mc.region_voxels) * kLayerBytes[layer_id];
+  // Pinned double-buffered staging on the copy stream, 64 regions per burst.
+  const size_t burst = 64;
+  err = ensureStage(m, std::max(m->h_stage_bytes, 2 * burst * stride));
+  if (err)
+  {
+    return err;
+  }
+  char *stage[2] = { static_cast<char *>(m->h_stage), static_cast<char *>(m->h_stage) + burst * stride };
+  hipEvent_t done[2] = { m->ev[5], nullptr };
+  OHMHIP_CHECK(hipEventCreate(&done[1]));
+  size_t pending_base[2] = { 0, 0 };
+  size_t pending_n[2] = { 0, 0 };
+  int status = OHMHIP_OK;
+  auto drain = [&](int b) -> int {
+    if (pending_n[b])
+    {
+      OHMHIP_CHECK(hipEventSynchronize(done[b]));
+      for (size_t k = 0; k < pending_n[b]; ++k)
+      {
+        std::memcpy(dsts[pending_base[b] + k], stage[b] + k * stride, stride);
+      }
+      pending_n[b] = 0;
+    }
+    return OHMHIP_OK;
+  };
+  int b = 0;
+  for (size_t base = 0; base < count && status == OHMHIP_OK; base += burst, b ^= 1)
+  {
+    status = drain(b);
+    if (status)
+    {
+      break;
+    }
+    const size_t n = std::min(burst, count - base);
+    for (size_t k = 0; k < n; ++k)
+    {
+      const int16_t *key = keys_xyz + 3 * (base + k);
+      const auto it = m->region_slots.find(packRegionKey(key[0], key[1], key[2]));
+      if (it == m->region_slots.end())
+      {
+        status = OHMHIP_ERR_NOT_FOUND;
+        break;
+      }
+      const char *src = static_cast<const char *>(m->layers[layer_id]) + size_t(it->second) * stride;
+      const hipError_t e = hipMemcpyAsync(stage[b] + k * stride, src, stride, hipMemcpyDeviceToHost, m->copy_stream);
+      if (e != hipSuccess)
+      {
+        status = int(e);
+        break;
+      }
+    }
+    if (status == OHMHIP_OK)
+    {
+      const hipError_t e = hipEventRecord(done[b], m->copy_stream);
+      if (e != hipSuccess)
+      {
+        status = int(e);
+      }
+      pending_base[b] = base;
+      pending_n[b] = n;
+    }
+  }
+  if (status == OHMHIP_OK)
+  {
+    status = drain(0);
+  }
+  if (status == OHMHIP_OK)
+  {
+    status = drain(1);
+  }
+  (void)hipStreamSynchronize(m->copy_stream);
+  (void)hipEventDestroy(done[1]);
+  return status;
+}
+
+int ohmhip_map_write_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, size_t count,
+                             const void *const *srcs)
+{
+  if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || (count && (!keys_xyz || !srcs)))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (!m->layers[layer_id])
+  {
+    return OHMHIP_ERR_NOT_FOUND;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  int err = refreshHostRegionTable(m);
+  if (err)
+  {
+    return err;
+  }
+  const size_t stride = size_t(m->mc.region_voxels) * kLayerBytes[layer_id];
+  // Create any regions which are not resident yet (host-side insert, then rebuild the device hash).
+  std::vector<uint64_t> new_keys;
+  for (size_t i = 0; i < count; ++i)
+  {
+    const uint64_t key = packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]);
+    if (m->region_slots.find(key) == m->region_slots.end())
+    {
+      m->region_slots[key] = uint32_t(m->slot_keys_host.size());
+      m->slot_keys_host.push_back(key);
+      new_keys.push_back(key);
+    }
+  }
+  if (!new_keys.empty())
+  {
+    const uint32_t total = uint32_t(m->slot_keys_host.size());
+    const uint32_t old = m->slots_committed;
+    if (total > m->slot_capacity)
+    {
+      uint32_t cap = m->slot_capacity;
+      while (cap < total)
+      {
+        cap *= 2;
+      }
+      err = allocPool(m, cap, old);
+      if (err)
+      {
+        return err;
+      }
+    }
+    OHMHIP_CHECK(hipMemcpy(m->d_slot_keys + old, m->slot_keys_host.data() + old, sizeof(uint64_t) * (total - old),
+                           hipMemcpyHostToDevice));
+    // Rebuild the hash from slot_keys (cheap: one lane per region).
+    OHMHIP_CHECK(hipMemsetAsync(m->d_keys, 0, sizeof(unsigned long long) * m->hash_capacity, m->stream));
+    OHMHIP_CHECK(hipMemcpyAsync(m->d_n_slots, &total, sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_rehash, dim3((total + 255) / 256), dim3(256), 0, m->stream, regionTable(m), total);
+    OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+    m->slots_committed = total;
+  }
+  const size_t burst = 64;
+  err = ensureStage(m, std::max(m->h_stage_bytes, burst * stride));
+  if (err)
+  {
+    return err;
+  }
+  for (size_t base = 0; base < count; base += burst)
+  {
+    const size_t n = std::min(burst, count - base);
+    for (size_t k = 0; k < n; ++k)
+    {
+      const int16_t *key = keys_xyz + 3 * (base + k);
+      const uint32_t slot = m->region_slots[packRegionKey(key[0], key[1], key[2])];
+      std::memcpy(static_cast<char *>(m->h_stage) + k * stride, srcs[base + k], stride);
+      OHMHIP_CHECK(hipMemcpyAsync(static_cast<char *>(m->layers[layer_id]) + size_t(slot) * stride,
+                                  static_cast<char *>(m->h_stage) + k * stride, stride, hipMemcpyHostToDevice,
+                                  m->copy_stream));
+    }
+    OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
+  }
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_clear(ohmhip_map_t m)
+{
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  m->slots_committed = 0;
+  m->region_slots.clear();
+  m->slot_keys_host.clear();
+  return allocPool(m, m->slot_capacity, 0);
+}
+
+}  // extern "C"

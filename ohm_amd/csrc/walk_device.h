@@ -1,0 +1,258 @@
+// walk_device.h -- fp64 device maths shared by the gfx950 kernels: voxel keys, voxel centres, line-walk set-up and
+// the closed-form "resume the walk at step (axis, j)" that lets a region workgroup pick a ray up mid-walk.
+//
+// Everything here follows the CPU instantiation of the reference's shared compute headers (WalkReal = double) with
+// the same operation order; the library is compiled with -ffp-contract=off so no FMA is formed, and fp64 divide /
+// sqrt are IEEE on gfx950.  Citations are reference file:line.
+#ifndef OHMHIP_WALK_DEVICE_H
+#define OHMHIP_WALK_DEVICE_H
+
+#include "ohmhip_internal.h"
+
+namespace ohmhip
+{
+__device__ inline double dInf()
+{
+  return __longlong_as_double(0x7ff0000000000000ll);
+}
+
+/// ohm/MapCoord.h:85-93
+__device__ inline int pointToRegionCoord(double coord, double resolution)
+{
+  return int(floor(coord / resolution + 0.5));
+}
+
+/// ohm/MapCoord.h:45-80
+__device__ inline int pointToRegionVoxel(double coord, double voxel_resolution, double region_resolution)
+{
+  const double epsilon = double(1e-6f);
+  if (-epsilon <= coord && coord < 0)
+  {
+    coord = 0;
+  }
+  else if (coord >= region_resolution && coord - epsilon < region_resolution)
+  {
+    coord -= epsilon;
+  }
+  return int(floor(coord / voxel_resolution));
+}
+
+/// ohm/OccupancyMap.cpp:859-886 -> ohm/MapRegion.cpp:32-69.  Returns false for a null key.
+/// @param[out] region Region coordinate per axis.
+/// @param[out] local Local voxel coordinate per axis.
+__device__ inline bool voxelKey(const MapConst &mc, const double p[3], int region[3], int local[3])
+{
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    const int coord = pointToRegionCoord(p[a] - mc.origin[a], mc.region_dim[a]);
+    // The reference stores the region coordinate in an int16; anything outside is not addressable.
+    ok = ok && coord > -32768 && coord <= 32767;
+    const double centre = coord * mc.region_dim[a];
+    const double region_min = centre - 0.5 * mc.region_dim[a];
+    const double pl = p[a] - mc.origin[a] - region_min;
+    const int q = pointToRegionVoxel(pl, mc.resolution, mc.region_dim[a]);
+    ok = ok && 0 <= q && q < mc.dim[a];
+    region[a] = coord;
+    local[a] = q;
+  }
+  return ok;
+}
+
+/// ohm/OccupancyMap.h:757-778 (one axis).
+__device__ inline double voxelCentreAxis(const MapConst &mc, int a, int region, int local)
+{
+  double v = double(float(region));
+  v *= mc.region_dim[a];
+  v -= 0.5 * mc.region_dim[a];
+  v += mc.origin[a];
+  v += double(local) * mc.resolution;
+  v += 0.5 * mc.resolution;
+  return v;
+}
+
+/// floor division / modulo for global voxel coordinate -> (region, local).
+__device__ inline void splitGlobal(int g, int dim, int &region, int &local)
+{
+  int q = g / dim;
+  int r = g - q * dim;
+  if (r < 0)
+  {
+    r += dim;
+    --q;
+  }
+  region = q;
+  local = r;
+}
+
+/// Time at which the j-th step (j >= 1) along an axis is taken: the value `time_next[axis]` holds after j-1 steps on
+/// that axis (ohm/LineWalkCompute.h:299-301 and :375-378).
+__device__ inline double stepTime(double init, double delta, int j)
+{
+  return (j <= 1) ? init : init + delta * double(j - 1);
+}
+
+/// Does the i-th step of axis b come before the j-th step of axis a in the walk?  The walk always takes the smallest
+/// time_next, ties going to the HIGHER axis index (ohm/LineWalkCompute.h:282-289).
+__device__ inline bool stepPrecedes(double tb, int b, double ta, int a)
+{
+  return tb < ta || (tb == ta && b > a);
+}
+
+/// Number of steps already taken along axis b at the moment the j-th step of axis a is about to be taken.
+/// T_b(i) is non-decreasing in i so the preceding steps form a prefix [1, n]; estimate n by division and fix up with
+/// the exact predicate so the result is identical to running the reference walk step by step.
+__device__ inline int stepsBefore(const RayWalk &rw, int b, int a, double ta)
+{
+  const int total = rw.total[b];
+  if (total == 0)
+  {
+    return 0;
+  }
+  const double init = rw.init[b];
+  const double delta = rw.delta[b];
+  int n;
+  if (delta > 0 && delta < dInf())
+  {
+    const double x = (ta - init) / delta;
+    // T_b(i) <= ta  <=>  i - 1 <= x
+    n = (x < 0) ? 0 : ((x >= double(total)) ? total : int(x) + 1);
+    n = (n > total) ? total : n;
+    while (n < total && stepPrecedes(stepTime(init, delta, n + 1), b, ta, a))
+    {
+      ++n;
+    }
+    while (n > 0 && !stepPrecedes(stepTime(init, delta, n), b, ta, a))
+    {
+      --n;
+    }
+    return n;
+  }
+  // Degenerate deltas (zero-length rays): binary search on the monotone predicate.
+  int lo = 0;
+  int hi = total;
+  while (lo < hi)
+  {
+    const int mid = (lo + hi + 1) >> 1;
+    if (stepPrecedes(stepTime(init, delta, mid), b, ta, a))
+    {
+      lo = mid;
+    }
+    else
+    {
+      hi = mid - 1;
+    }
+  }
+  return lo;
+}
+
+/// Ray filter + key + line-walk set-up for one ray.  Mirrors, in order:
+///   ohm/RayFilter.cpp:12-58 (goodRayFilter / clipRayFilter), ohm/LineWalk.h:112-129 (walkSegmentKeys),
+///   ohm/LineWalkCompute.h:188-248 (walkInitRay) and :260-280 (walkCalculateSteps).
+/// `start`/`end` may be modified by the clip filter.
+__device__ inline void setupRay(const MapConst &mc, double start[3], double end[3], unsigned ray_flags, RayWalk &rw)
+{
+  rw.flags = 0;
+  rw.pad = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    rw.init[a] = rw.delta[a] = 0;
+    rw.g0[a] = rw.total[a] = 0;
+  }
+
+  bool clipped_end = false;
+  if (mc.filter_mode != OHMHIP_FILTER_NONE)
+  {
+    bool good = isfinite(start[0]) && isfinite(start[1]) && isfinite(start[2]) && isfinite(end[0]) &&
+                isfinite(end[1]) && isfinite(end[2]);
+    const double rx = end[0] - start[0];
+    const double ry = end[1] - start[1];
+    const double rz = end[2] - start[2];
+    const double len2 = (rx * rx + ry * ry) + rz * rz;
+    if (mc.filter_mode == OHMHIP_FILTER_GOOD)
+    {
+      good = good && (mc.filter_range <= 0 || len2 <= mc.filter_range * mc.filter_range);
+    }
+    else if (good && mc.filter_range > 0 && len2 > mc.filter_range * mc.filter_range)
+    {
+      const double len = sqrt(len2);
+      end[0] = start[0] + (rx / len) * mc.filter_range;
+      end[1] = start[1] + (ry / len) * mc.filter_range;
+      end[2] = start[2] + (rz / len) * mc.filter_range;
+      clipped_end = true;
+    }
+    if (!good)
+    {
+      return;
+    }
+  }
+
+  int r0[3], l0[3], r1[3], l1[3];
+  const bool ok0 = voxelKey(mc, start, r0, l0);
+  const bool ok1 = voxelKey(mc, end, r1, l1);
+  if (!ok0 || !ok1)
+  {
+    return;  // walkSegmentKeys returns 0 for null keys (ohm/LineWalk.h:119-122).
+  }
+
+  // walkInitRay
+  double dir[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    dir[a] = end[a] - start[a];
+  }
+  double length = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+  length = (length > 1e-6) ? sqrt(length) : 0;
+  unsigned flags = kRwValid;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    const int sign = dir[a] < 0;
+    flags |= sign ? (kRwSign0 << a) : 0u;
+    dir[a] /= length;
+    const double dir_inv = (length > 0) ? 1 / dir[a] : 0;
+    const double centre = voxelCentreAxis(mc, a, r0[a], l0[a]);
+    double vmin = centre - 0.5 * mc.resolution;
+    double vmax = centre + 0.5 * mc.resolution;
+    const double exit0 = ((sign ? vmin : vmax) - start[a]) * dir_inv;
+    const double shift = double(-2 * sign + 1) * mc.resolution;
+    vmin += shift;
+    vmax += shift;
+    double exit1 = ((sign ? vmin : vmax) - start[a]) * dir_inv;
+    if (exit1 != dInf())
+    {
+      exit1 -= exit0;
+    }
+    rw.init[a] = exit0;
+    rw.delta[a] = exit1;
+    rw.g0[a] = r0[a] * mc.dim[a] + l0[a];
+    const int g1 = r1[a] * mc.dim[a] + l1[a];
+    const int diff = g1 - rw.g0[a];
+    rw.total[a] = diff < 0 ? -diff : diff;
+    // The step direction the reference uses comes from the sign of the ray direction, while the step COUNT comes
+    // from the key difference.  They agree whenever there is at least one step to take.
+  }
+
+  const bool include_end = clipped_end || (ray_flags & OHMHIP_RF_END_POINT_AS_FREE);
+  flags |= include_end ? kRwIncludeEnd : 0u;
+  flags |= (!include_end && !(ray_flags & OHMHIP_RF_EXCLUDE_SAMPLE)) ? kRwApplySample : 0u;
+  flags |= (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) ? kRwExcludeStart : 0u;
+  flags |= !(ray_flags & OHMHIP_RF_EXCLUDE_RAY) ? kRwWalk : 0u;
+  rw.flags = flags;
+}
+
+__device__ inline int rwSign(const RayWalk &rw, int a)
+{
+  return (rw.flags >> (1 + a)) & 1u;
+}
+
+__device__ inline int rwDir(const RayWalk &rw, int a)
+{
+  return 1 - 2 * rwSign(rw, a);
+}
+}  // namespace ohmhip
+
+#endif  // OHMHIP_WALK_DEVICE_H

@@ -1,0 +1,392 @@
+"""Host-side mirror (Python) of the reference interface for the ray-integration path.
+
+Names, argument meaning and error behaviour follow the reference so the parity tests read like the reference's own
+(tests/ohmtestgpu/GpuMapTest.cpp):
+
+  ohm::OccupancyMap  (ohm/OccupancyMap.h:291)  -> OccupancyMap   : parameters + MapChunk/VoxelBlock-layout host blocks
+  ohm::RayMapper     (ohm/RayMapper.h:22-65)   -> RayMapper
+  ohm::GpuMap        (ohmgpu/GpuMap.h:143-384) -> GpuMap
+  ohm::GpuNdtMap     (ohmgpu/GpuNdtMap.h:63)   -> GpuNdtMap
+  ohm::GpuTsdfMap    (ohmgpu/GpuTsdfMap.h:37)  -> GpuTsdfMap
+
+All compute goes through libohmhip.so (include/ohmhip.h).  There is no CPU implementation here.
+The C++14 mirror of the same classes lives in ohm_amd/host/ (header-only, over the same C ABI).
+"""
+import ctypes as C
+import enum
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+
+class RayFlag(enum.IntFlag):
+    """ohm/RayFlag.h:16-60"""
+    kRfDefault = 0
+    kRfEndPointAsFree = 1 << 0
+    kRfStopOnFirstOccupied = 1 << 1
+    kRfExcludeOrigin = 1 << 2
+    kRfExcludeSample = 1 << 3
+    kRfExcludeRay = 1 << 4
+    kRfExcludeUnobserved = 1 << 5
+    kRfExcludeFree = 1 << 6
+    kRfExcludeOccupied = 1 << 7
+    kRfReverseWalk = 1 << 8
+
+
+class NdtMode(enum.IntEnum):
+    """ohm/NdtMode.h"""
+    kNone = 0
+    kOccupancy = 1
+    kTraversability = 2
+
+
+# Layer name -> (layer id, numpy dtype, components).  ohm/DefaultLayer.cpp:76-311
+LAYERS = {
+    "occupancy": (L.LID_OCCUPANCY, np.float32, 1),
+    "mean": (L.LID_MEAN, np.uint32, 2),
+    "covariance": (L.LID_COVARIANCE, np.float32, 6),
+    "traversal": (L.LID_TRAVERSAL, np.float32, 1),
+    "touch_time": (L.LID_TOUCH_TIME, np.uint32, 1),
+    "incident_normal": (L.LID_INCIDENT, np.uint32, 1),
+    "intensity": (L.LID_INTENSITY, np.float32, 2),
+    "hit_miss_count": (L.LID_HIT_MISS, np.uint32, 2),
+    "tsdf": (L.LID_TSDF, np.float32, 2),
+}
+
+
+_libm = C.CDLL("libm.so.6")
+_libm.logf.restype = C.c_float
+_libm.logf.argtypes = [C.c_float]
+_libm.expf.restype = C.c_float
+_libm.expf.argtypes = [C.c_float]
+
+
+def probability_to_value(p):
+    """ohm/MapProbability.h:33-36, float instantiation: std::log(float) == libm logf (numpy's float32 log is not
+    bit-identical to libm, and these constants must match the C++ host / CPU mapper exactly)."""
+    p = np.float32(p)
+    return np.float32(_libm.logf(float(p / (np.float32(1.0) - p))))
+
+
+def value_to_probability(v):
+    """ohm/MapProbability.h:20-27"""
+    v = np.float32(v)
+    if v == -np.inf:
+        return np.float32(0)
+    return np.float32(1) - (np.float32(1) / (np.float32(1) + np.float32(_libm.expf(float(v)))))
+
+
+class OccupancyMap:
+    """Host-side map description + chunk storage in the reference's MapChunk layout.
+
+    chunks[(rx, ry, rz)][layer_name] is a flat numpy array indexed x + y*dx + z*dx*dy (ohm/MapChunk.h:33-50), i.e. the
+    bytes of VoxelBlock::voxelBytes() for that layer (ohm/VoxelBlock.h:270-278).
+    """
+
+    def __init__(self, resolution=0.1, region_voxel_dimensions=(32, 32, 32), layers=("occupancy",)):
+        self.resolution = float(resolution)
+        self.region_voxel_dimensions = tuple(int(d) if d > 0 else 32 for d in region_voxel_dimensions)
+        self.origin = (0.0, 0.0, 0.0)
+        self.layers = list(layers)
+        # ohm/OccupancyMap.cpp:205-213
+        self.min_voxel_value = np.float32(-2.0)
+        self.max_voxel_value = np.float32(3.511)
+        self.hit_value = probability_to_value(0.9)
+        self.miss_value = probability_to_value(0.45)
+        self.occupancy_threshold_value = probability_to_value(0.5)
+        self.saturate_at_min_value = False
+        self.saturate_at_max_value = False
+        self.ray_filter = ("good", 1e10)  # ohm/OccupancyMap.cpp:215-218
+        self.chunks = {}
+
+    # -- ohm::OccupancyMap setters used by the tests ---------------------------------------------------------------
+    def setOrigin(self, origin):
+        self.origin = tuple(float(v) for v in origin)
+
+    def setHitProbability(self, p):
+        self.hit_value = probability_to_value(p)
+
+    def setMissProbability(self, p):
+        self.miss_value = probability_to_value(p)
+
+    def setOccupancyThresholdProbability(self, p):
+        self.occupancy_threshold_value = probability_to_value(p)
+
+    def hitValue(self):
+        return self.hit_value
+
+    def missValue(self):
+        return self.miss_value
+
+    def missProbability(self):
+        return value_to_probability(self.miss_value)
+
+    def regionVoxelVolume(self):
+        d = self.region_voxel_dimensions
+        return d[0] * d[1] * d[2]
+
+    def addLayer(self, name):
+        if name not in LAYERS:
+            raise KeyError(name)
+        if name not in self.layers:
+            self.layers.append(name)
+
+    def regionCount(self):
+        return len(self.chunks)
+
+
+class RayMapper:
+    """ohm/RayMapper.h:22-65"""
+
+    def valid(self):
+        raise NotImplementedError
+
+    def integrateRays(self, rays, intensities=None, timestamps=None, ray_update_flags=RayFlag.kRfDefault):
+        raise NotImplementedError
+
+
+class GpuMap(RayMapper):
+    """ohm::GpuMap (ohmgpu/GpuMap.h:143-384) over libohmhip.so.
+
+    integrateRays() is asynchronous like the reference (returns once the batch is queued); syncVoxels() is the fence
+    and copies modified regions back into map.chunks.
+    """
+    _mode = L.MODE_OCCUPANCY
+
+    def __init__(self, map_, borrowed_map=True, expected_element_count=2048, gpu_mem_size=0, region_capacity=0):
+        self._map = map_
+        self._borrowed = borrowed_map
+        self._handle = L._vp()
+        self._ok = False
+        self._ray_segment_length = 0.0
+        self._configure_layers()
+        cfg = L.MapConfig()
+        L.lib.ohmhip_map_config_default(C.byref(cfg))
+        cfg.resolution = map_.resolution
+        for a in range(3):
+            cfg.region_dim[a] = map_.region_voxel_dimensions[a]
+            cfg.origin[a] = map_.origin[a]
+        layer_bits = 0
+        for name in map_.layers:
+            layer_bits |= 1 << LAYERS[name][0]
+        cfg.layers = layer_bits
+        cfg.mode = self._mode
+        cfg.hit_value = float(map_.hit_value)
+        cfg.miss_value = float(map_.miss_value)
+        cfg.threshold_value = float(map_.occupancy_threshold_value)
+        cfg.min_value = float(map_.min_voxel_value)
+        cfg.max_value = float(map_.max_voxel_value)
+        cfg.saturate_at_min = int(map_.saturate_at_min_value)
+        cfg.saturate_at_max = int(map_.saturate_at_max_value)
+        mode, rng = map_.ray_filter if map_.ray_filter else ("none", 0.0)
+        cfg.ray_filter = {"none": L.FILTER_NONE, "good": L.FILTER_GOOD, "clip": L.FILTER_CLIP}[mode]
+        cfg.ray_filter_range = float(rng)
+        cfg.gpu_mem_size = int(gpu_mem_size)
+        cfg.region_capacity = int(region_capacity)
+        self._fill_config(cfg)
+        self._cfg = cfg
+        status = L.lib.ohmhip_map_create(C.byref(self._handle), C.byref(cfg))
+        # gputil::Exception from the ctor on allocation failure (ohmgpu/GpuMap.h:53-54,159-160)
+        L.check(status, "GpuMap: ohmhip_map_create")
+        self._ok = True
+        self._upload_existing()
+
+    # hooks for subclasses ---------------------------------------------------------------------------------------
+    def _configure_layers(self):
+        if "occupancy" not in self._map.layers:
+            self._map.addLayer("occupancy")
+
+    def _fill_config(self, cfg):
+        pass
+
+    # ------------------------------------------------------------------------------------------------------------
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def close(self):
+        if self._handle:
+            L.lib.ohmhip_map_destroy(self._handle)
+            self._handle = L._vp()
+            self._ok = False
+
+    def gpuOk(self):
+        return self._ok
+
+    def valid(self):
+        return self._ok
+
+    def map(self):
+        return self._map
+
+    def borrowedMap(self):
+        return self._borrowed
+
+    def hitValue(self):
+        return self._map.hit_value
+
+    def missValue(self):
+        return self._map.miss_value
+
+    def setRaySegmentLength(self, length):
+        """ohmgpu/GpuMap.h:246-262.  Segmentation exists in the reference to balance GPU threads; this backend bins
+        rays per region instead, so the value is stored and otherwise ignored (results follow the CPU mapper)."""
+        self._ray_segment_length = float(length)
+
+    def raySegmentLength(self):
+        return self._ray_segment_length
+
+    def integrateRays(self, rays, intensities=None, timestamps=None, ray_update_flags=RayFlag.kRfDefault):
+        """rays: (2N, 3) float64 origin/sample pairs.  Returns number of POINTS integrated (2 per ray), 0 on failure
+        (ohmgpu/GpuMap.cpp:416, 548-551, 874)."""
+        if not self._ok:
+            return 0
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 3)
+        element_count = rays.shape[0]
+        if element_count < 2:
+            return 0
+        ints = None if intensities is None else np.ascontiguousarray(intensities, dtype=np.float32)
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, dtype=np.float64)
+        done = C.c_size_t(0)
+        status = L.lib.ohmhip_map_integrate_rays(
+            self._handle, rays.ctypes.data, element_count, None if ints is None else ints.ctypes.data,
+            None if ts is None else ts.ctypes.data, int(ray_update_flags), C.byref(done))
+        if status == L.ERR_UNSUPPORTED:
+            raise L.OhmHipError(status, "GpuMap.integrateRays")
+        if status != L.OK:
+            self._last_error = status
+            return 0
+        return int(done.value)
+
+    def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=RayFlag.kRfDefault):
+        """Rays already resident in HBM (bench path): d_rays_ptr is a raw device pointer to element_count dvec3."""
+        done = C.c_size_t(0)
+        status = L.lib.ohmhip_map_integrate_rays_device(self._handle, d_rays_ptr, element_count, None, None,
+                                                        int(ray_update_flags), C.byref(done))
+        L.check(status, "GpuMap.integrateRaysDevice")
+        return int(done.value)
+
+    def stats(self):
+        st = L.BatchStats()
+        L.check(L.lib.ohmhip_map_last_stats(self._handle, C.byref(st)), "stats")
+        return {name: getattr(st, name) for name, _ in L.BatchStats._fields_}
+
+    def wait(self):
+        L.check(L.lib.ohmhip_map_sync(self._handle), "sync")
+
+    def regionKeys(self, dirty_only=False):
+        n = C.c_size_t(0)
+        fn = L.lib.ohmhip_map_dirty_regions if dirty_only else L.lib.ohmhip_map_regions
+        L.check(fn(self._handle, None, 0, C.byref(n)), "regions")
+        keys = np.zeros((n.value, 3), dtype=np.int16)
+        if n.value:
+            L.check(fn(self._handle, keys.ctypes.data, n.value, C.byref(n)), "regions")
+        return keys
+
+    def syncVoxels(self, layer_names=None):
+        """ohmgpu/GpuMap.cpp:308-324: fence + copy modified regions back into the host MapChunk blocks."""
+        if not self._ok:
+            return
+        keys = self.regionKeys(dirty_only=True)
+        names = layer_names if layer_names is not None else self._map.layers
+        rv = self._map.regionVoxelVolume()
+        for name in names:
+            lid, dtype, comps = LAYERS[name]
+            blocks = []
+            for k in keys:
+                chunk = self._map.chunks.setdefault((int(k[0]), int(k[1]), int(k[2])), {})
+                if name not in chunk:
+                    chunk[name] = np.zeros(rv * comps, dtype=dtype)
+                blocks.append(chunk[name])
+            if not blocks:
+                continue
+            ptrs = (C.c_void_p * len(blocks))(*[b.ctypes.data for b in blocks])
+            L.check(L.lib.ohmhip_map_read_regions(self._handle, lid, keys.ctypes.data, len(blocks), ptrs),
+                    "syncVoxels")
+        L.check(L.lib.ohmhip_map_clear_dirty(self._handle), "clear_dirty")
+        self.wait()
+
+    def _upload_existing(self):
+        """gpumap::enableGpu + GpuLayerCache::upload for regions the CPU map already holds."""
+        if not self._map.chunks:
+            return
+        keys = np.array(sorted(self._map.chunks.keys()), dtype=np.int16).reshape(-1, 3)
+        for name in self._map.layers:
+            lid, dtype, comps = LAYERS[name]
+            blocks = [np.ascontiguousarray(self._map.chunks[tuple(int(v) for v in k)][name], dtype=dtype) for k in keys]
+            ptrs = (C.c_void_p * len(blocks))(*[b.ctypes.data for b in blocks])
+            L.check(L.lib.ohmhip_map_write_regions(self._handle, lid, keys.ctypes.data, len(blocks), ptrs), "upload")
+
+
+class GpuNdtMap(GpuMap):
+    """ohm::GpuNdtMap (ohmgpu/GpuNdtMap.h:63-132)."""
+    _mode = L.MODE_NDT_OM
+
+    def __init__(self, map_, borrowed_map=True, expected_element_count=2048, gpu_mem_size=0,
+                 ndt_mode=NdtMode.kOccupancy, region_capacity=0):
+        self._ndt_mode = NdtMode(ndt_mode)
+        self._mode = L.MODE_NDT_TM if self._ndt_mode == NdtMode.kTraversability else L.MODE_NDT_OM
+        # ohm/private/NdtMapDetail.h:20-45
+        self.sensor_noise = 0.05
+        self.sample_threshold = 3
+        mp = float(map_.missProbability())
+        # ohm/NdtMap.h:146-149
+        self.adaptation_rate = float(np.float32(max(0.0, min(np.float32(2.0) * (np.float32(1.0) - np.float32(2.0) *
+                                                                                   np.float32(mp)), 1.0))))
+        self.reinitialise_covariance_threshold = float(probability_to_value(0.2))
+        self.reinitialise_covariance_point_count = 100
+        self.initial_intensity_covariance = 1.0
+        super().__init__(map_, borrowed_map, expected_element_count, gpu_mem_size, region_capacity)
+
+    def _configure_layers(self):
+        # NdtMap::enableNdt adds mean + covariance (+ intensity, hit/miss for TM). ohm/NdtMap.cpp:194-213
+        for name in ("occupancy", "mean", "covariance"):
+            self._map.addLayer(name)
+        if self._ndt_mode == NdtMode.kTraversability:
+            self._map.addLayer("intensity")
+            self._map.addLayer("hit_miss_count")
+
+    def _fill_config(self, cfg):
+        cfg.ndt_sensor_noise = self.sensor_noise
+        cfg.ndt_sample_threshold = self.sample_threshold
+        cfg.ndt_adaptation_rate = self.adaptation_rate
+        cfg.ndt_reinit_threshold = self.reinitialise_covariance_threshold
+        cfg.ndt_reinit_count = self.reinitialise_covariance_point_count
+        cfg.ndt_initial_intensity_cov = self.initial_intensity_covariance
+
+    def setSensorNoise(self, noise):
+        raise L.OhmHipError(L.ERR_UNSUPPORTED, "setSensorNoise after construction; set .sensor_noise before")
+
+
+class GpuTsdfMap(GpuMap):
+    """ohm::GpuTsdfMap (ohmgpu/GpuTsdfMap.h:37-94)."""
+    _mode = L.MODE_TSDF
+
+    def __init__(self, map_, borrowed_map=True, expected_element_count=2048, gpu_mem_size=0, max_weight=1e4,
+                 default_truncation_distance=0.1, dropoff_epsilon=0.0, sparsity_compensation_factor=1.0,
+                 region_capacity=0):
+        self.tsdf_options = (max_weight, default_truncation_distance, dropoff_epsilon, sparsity_compensation_factor)
+        super().__init__(map_, borrowed_map, expected_element_count, gpu_mem_size, region_capacity)
+
+    def _configure_layers(self):
+        self._map.addLayer("tsdf")
+
+    def _fill_config(self, cfg):
+        (cfg.tsdf_max_weight, cfg.tsdf_trunc, cfg.tsdf_dropoff, cfg.tsdf_sparsity) = self.tsdf_options
+
+
+def device_count():
+    n = C.c_int(0)
+    status = L.lib.ohmhip_device_count(C.byref(n))
+    return n.value if status == L.OK else 0
+
+
+def device_info(device=0):
+    info = L.DeviceInfo()
+    L.check(L.lib.ohmhip_device_get_info(device, C.byref(info)), "device_get_info")
+    return {"name": info.name.decode(), "arch": info.arch.decode(), "total_memory": info.total_memory,
+            "compute_units": info.compute_units, "lds_bytes_per_block": info.lds_bytes_per_block}

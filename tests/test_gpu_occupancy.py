@@ -1,0 +1,118 @@
+"""-m gpu: HIP occupancy integration vs the CPU oracle on identical rays (bit-exact values expected: the device
+replays each voxel's float updates in CPU order).  Cases follow tests/ohmtestgpu/GpuMapTest.cpp."""
+import numpy as np
+import pytest
+
+import ohm_amd
+from ohm_amd import GpuMap, OccupancyMap, RayFlag, synth
+
+from parity import assert_parity, compare_maps, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(rays, resolution=0.1, dims=(32, 32, 32), layers=("occupancy",), batch=None, flags=0, origin=None,
+             ray_filter=None, region_capacity=0):
+    map_ = OccupancyMap(resolution, dims, layers=layers)
+    if origin is not None:
+        map_.setOrigin(origin)
+    if ray_filter is not None:
+        map_.ray_filter = ray_filter
+    gm = GpuMap(map_, region_capacity=region_capacity)
+    om = make_oracle(map_)
+    n_points = rays.shape[0]
+    step = n_points if batch is None else 2 * batch
+    total = 0
+    for i in range(0, n_points, step):
+        chunk = rays[i:i + step]
+        total += gm.integrateRays(chunk, ray_update_flags=flags)
+        om.integrate_occupancy(chunk, flags=int(flags))
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True)
+    stats["visits_cpu"] = om.visit_count()
+    return stats, gm, om, total
+
+
+def test_populate_tiny(gpu):
+    # GpuMapTest.cpp:317 PopulateTiny: 2 rays
+    rays = np.array([[0.3, 0, 0], [1.1, 0, 0], [-5, 0, 0], [0.11, 0, 0]], dtype=np.float64)
+    stats, gm, om, total = run_case(rays)
+    assert total == 4
+    assert_parity(stats)
+
+
+def test_populate_small(gpu):
+    # GpuMapTest.cpp:333 PopulateSmall: 64 rays within +-50 m
+    rays = synth.random_rays(64, extent=50.0, seed=11)
+    stats, gm, om, total = run_case(rays)
+    assert total == 128
+    assert_parity(stats)
+
+
+def test_populate_large_batched(gpu):
+    # GpuMapTest.cpp:354 PopulateLarge: 131072 rays +-25 m in batches of 2048 (scaled to 32768 rays here)
+    rays = synth.random_rays(32768, extent=25.0, seed=12)
+    stats, gm, om, total = run_case(rays, batch=2048)
+    assert total == 2 * 32768
+    assert_parity(stats)
+
+
+def test_lidar_contention_with_mean(gpu):
+    # Many rays through shared voxels from one origin (the contended case) + voxel mean layer.
+    rays = synth.rays_c1(n=60000, max_range=12.0)
+    stats, gm, om, total = run_case(rays, layers=("occupancy", "mean"))
+    assert_parity(stats)
+    st = gm.stats()
+    assert st["voxel_visits"] == stats["visits_cpu"]
+
+
+def test_two_passes_saturation(gpu):
+    # Integrate the same set twice: clamps at min/max interact with ordering.
+    rays = synth.rays_c0(n=20000, length=6.0)
+    stats, gm, om, total = run_case(np.concatenate([rays, rays]), batch=20000)
+    assert_parity(stats)
+
+
+def test_small_regions_and_origin(gpu):
+    # GpuMapTest.cpp:525 Compare uses 16^3 regions; also a non-zero map origin.
+    rays = synth.random_rays(4000, extent=6.0, seed=5, origin_spread=0.5)
+    stats, gm, om, total = run_case(rays, resolution=0.25, dims=(16, 16, 16), origin=(0.125, -0.3, 1.0))
+    assert_parity(stats)
+
+
+def test_flags(gpu):
+    rays = synth.random_rays(3000, extent=5.0, seed=6)
+    for flags in (RayFlag.kRfEndPointAsFree, RayFlag.kRfExcludeOrigin, RayFlag.kRfExcludeSample,
+                  RayFlag.kRfExcludeRay, RayFlag.kRfExcludeUnobserved):
+        stats, gm, om, total = run_case(rays, flags=flags)
+        assert_parity(stats)
+
+
+def test_clip_filter_and_bad_rays(gpu):
+    rays = synth.random_rays(2000, extent=20.0, seed=7)
+    rays[10] = np.nan
+    rays[33, 1] = np.inf
+    stats, gm, om, total = run_case(rays, ray_filter=("clip", 8.0))
+    assert total == 2 * (2000 - 2)
+    assert_parity(stats)
+
+
+def test_zero_length_and_tiny_rays(gpu):
+    # GpuMapTest.cpp:817 CheckBadRays: sub-epsilon rays straddling voxel boundaries must not hang.
+    pts = []
+    for k in range(200):
+        c = np.array([0.1 * (k % 7), 0.1 * (k % 5), 0.1 * (k % 3)])
+        pts += [c - 1e-9, c + 1e-9]
+    for k in range(100):
+        c = np.array([0.05 + 0.1 * k, 0.05, 0.05])
+        pts += [c, c]
+    rays = np.array(pts, dtype=np.float64)
+    stats, gm, om, total = run_case(rays)
+    assert_parity(stats)
+
+
+def test_pool_growth(gpu):
+    # More regions than the initial pool: the map must grow and keep earlier results.
+    rays = synth.rays_c0(n=4000, length=9.0)
+    stats, gm, om, total = run_case(rays, batch=1000, region_capacity=64)
+    assert_parity(stats)
