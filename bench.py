@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: rays/s integrated by the HIP occupancy path (BASELINE.json configs[1]) + roofline.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one GpuMap::integrateRays pass over one 1 M-ray synthetic lidar batch (C1) whose rays are already
+resident in HBM when the timed region starts.  At N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank integrates the C4 shard of its own sensor origin into its own resident map (ray shards by sensor origin, no
+data-path collective: "weak" scaling); value = rays of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def cpu_baseline(rays, resolution, sample_rays):
+    """Oracle (bit-identical CPU port of RayMapperOccupancy) timed single-threaded on a bounded sample."""
+    from oracle.oracle import OracleMap
+    sample = rays[: 2 * sample_rays]
+    best = None
+    for _ in range(2):
+        om = OracleMap(resolution, (32, 32, 32), layers=("occupancy",))
+        t0 = time.perf_counter()
+        om.integrate_occupancy(sample)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": sample_rays / best, "unit": "rays/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample_rays} rays of the same C1 batch, fresh map, best of 2, {best:.2f} s",
+            "visits_per_s": om.visit_count() / best}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import ohm_amd
+    from ohm_amd import _lib as L
+    from ohm_amd import synth
+
+    L.check(L.lib.ohmhip_device_select(local_rank), "device_select")
+    resolution = 0.1
+    n_rays = args.rays
+    if world == 1:
+        rays = synth.rays_c1(n=n_rays)
+        workload = "C1: GpuMap occupancy-only, 0.1 m voxels, 32^3 regions, 1M-ray 64-beam lidar batch, 7.5-30 m"
+    else:
+        rays = synth.rays_c4_shard(rank, n=n_rays)
+        workload = ("C4: GpuMap occupancy, 0.1 m voxels, 1M-ray lidar batch per sensor origin, one origin per GPU, "
+                    "replicated maps (no merge in the timed region)")
+
+    map_ = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+    gm = ohm_amd.GpuMap(map_, gpu_mem_size=8 << 30)
+
+    # Rays resident in HBM.
+    buf = L._vp()
+    L.check(L.lib.ohmhip_buffer_create(C.byref(buf), rays.nbytes, 3), "buffer_create")
+    L.check(L.lib.ohmhip_buffer_write(buf, rays.ctypes.data, rays.nbytes, 0, None, None, None), "buffer_write")
+    dptr = L._vp()
+    L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(dptr)), "buffer_ptr")
+
+    def barrier():
+        gm.wait()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        gm.integrateRaysDevice(dptr, rays.shape[0])
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    walk_ms = []
+    total_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = gm.stats()  # hipEvent timings recorded on the map's stream around each kernel phase
+        walk_ms.append(st["ms_walk"])
+        total_ms.append(st["ms_total"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = gm.stats()
+    visits = int(st["voxel_visits"])
+    rays_ok = int(st["rays_integrated"])
+    # Algorithmic bytes: 44 B per ray + 8 B per voxel visit (4 B read + 4 B write of the log-odds).
+    b_alg = 44.0 * rays_ok + 8.0 * visits
+    t_walk = float(np.mean(walk_ms)) * 1e-3
+    t_dev = float(np.mean(total_ms)) * 1e-3
+    achieved = b_alg / t_walk / 1e9
+    out = {
+        "metric": "rays/sec integrated (occupancy)",
+        "value": world * n_rays * args.steps / elapsed,
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64 line walk + f32 log-odds",
+        "data": "synthetic",
+        "config": {"workload": workload, "rays_per_step_per_gpu": n_rays, "voxel_visits_per_step": visits,
+                   "regions": int(st["regions_resident"]), "ray_region_segments": int(st["ray_region_segments"])},
+        "roofline": {"bound": "hbm", "kernel": "k_region_walk", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": b_alg, "kernel_ms": t_walk * 1e3,
+                     "pipeline_ms": t_dev * 1e3, "pipeline_frac": b_alg / t_dev / 1e9 / HBM_PEAK_GBPS},
+        "device_ms": {"setup_bin": float(st["ms_setup"]), "walk": float(st["ms_walk"]),
+                      "sort_apply": float(st["ms_apply"]), "total": float(st["ms_total"])},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(rays, resolution, min(args.cpu_sample, n_rays))
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    L.lib.ohmhip_buffer_destroy(buf)
+    gm.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

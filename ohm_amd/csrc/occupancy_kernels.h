@@ -159,9 +159,23 @@ __device__ inline bool regionCursorNext(const MapConst &mc, const RayWalk &rw, R
     return false;
   }
   axis = best;
-  j = rc.next_j[best];
-  rc.region[best] += rc.dir[best];
-  rc.next_j[best] += mc.dim[best];
+  j = sel3(best, rc.next_j[0], rc.next_j[1], rc.next_j[2]);
+  // Per-axis updates spelled out: a run-time index here would push the cursor into scratch memory.
+  if (best == 0)
+  {
+    rc.region[0] += rc.dir[0];
+    rc.next_j[0] += mc.dim[0];
+  }
+  else if (best == 1)
+  {
+    rc.region[1] += rc.dir[1];
+    rc.next_j[1] += mc.dim[1];
+  }
+  else
+  {
+    rc.region[2] += rc.dir[2];
+    rc.next_j[2] += mc.dim[2];
+  }
   return true;
 }
 
@@ -169,24 +183,23 @@ __device__ inline bool regionCursorNext(const MapConst &mc, const RayWalk &rw, R
 /// last step on its axis and every step of the other axes precedes it.
 __device__ inline bool stepReachesEnd(const RayWalk &rw, int axis, int j)
 {
-  if (j != rw.total[axis])
+  if (j != sel3(axis, rw.total[0], rw.total[1], rw.total[2]))
   {
     return false;
   }
-  const double ta = stepTime(rw.init[axis], rw.delta[axis], j);
+  const double ta =
+    stepTime(sel3(axis, rw.init[0], rw.init[1], rw.init[2]), sel3(axis, rw.delta[0], rw.delta[1], rw.delta[2]), j);
+  bool all_before = true;
 #pragma unroll
   for (int b = 0; b < 3; ++b)
   {
-    if (b != axis && rw.total[b] > 0)
+    if (rw.total[b] > 0)
     {
       const double tb = stepTime(rw.init[b], rw.delta[b], rw.total[b]);
-      if (!stepPrecedes(tb, b, ta, axis))
-      {
-        return false;
-      }
+      all_before = all_before && (b == axis || stepPrecedes(tb, b, ta, axis));
     }
   }
-  return true;
+  return all_before;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -583,21 +596,71 @@ __global__ void __launch_bounds__(256)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_region_walk: the hot kernel.
+//
+// One workgroup (16 waves) per chunk of <= kChunkSegments ray-region segments of ONE region.  The region's miss-count
+// tile (u16 per voxel, 64 KiB for 32^3) and its hit bitmask live in LDS.  Every lane resumes one ray's fp64 walk at
+// the step that enters the region and walks until the ray leaves the region or ends.  Idle lanes are refilled in
+// batches from a workgroup-wide LDS cursor so waves stay mostly full although segments differ in length.
+//
+// A miss on a voxel which ALSO receives samples in this batch must be ordered against those samples.  Resolving that
+// needs a search in the region's sorted hit list (global memory latency), so such visits are not resolved here: they
+// are appended to a per-wave LDS queue (no atomics: the queue cursor is wave-uniform) which is flushed to a global
+// event list in coalesced bursts and resolved by k_flagged_events with full memory-level parallelism.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kWalkThreads = 512;
+constexpr int kWalkThreads = 1024;
+constexpr int kWalkWaves = kWalkThreads / 64;
+constexpr int kQueueCap = 256;     ///< deferred events per wave (8 B each)
+constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
 
-__global__ void __launch_bounds__(kWalkThreads, 4)
+/// Resolve one deferred miss event: find the first sample of the same voxel with a larger ray index; the miss counts
+/// towards the interval before that sample, or towards the voxel's trailing count if there is none.
+__device__ inline void resolveFlaggedMiss(unsigned long long key, const BatchScratch &bs,
+                                          const unsigned long long *__restrict__ sorted_hits,
+                                          uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts,
+                                          int region_voxels)
+{
+  const uint32_t slot = uint32_t(key >> kHitSlotShift);
+  const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
+  const uint32_t he = bs.hit_end[slot];
+  uint32_t lo = bs.hit_begin[slot];
+  uint32_t hi = he;
+  while (lo < hi)
+  {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sorted_hits[mid] > key)
+    {
+      hi = mid;
+    }
+    else
+    {
+      lo = mid + 1;
+    }
+  }
+  if (lo < he && (sorted_hits[lo] >> kHitRayBits) == (key >> kHitRayBits))
+  {
+    atomicAdd(&interval_counts[lo], 1u);
+  }
+  else
+  {
+    atomicAdd(&miss_counts[size_t(slot) * size_t(region_voxels) + vi], 1u);
+  }
+}
+
+__global__ void __launch_bounds__(kWalkThreads)
   k_region_walk(MapConst mc, BatchScratch bs, const Chunk *__restrict__ chunks, const Segment *__restrict__ segments,
                 const RayWalk *__restrict__ walks, const unsigned long long *__restrict__ sorted_hits,
                 const uint32_t *__restrict__ hit_mask, uint32_t *__restrict__ miss_counts,
-                uint32_t *__restrict__ interval_counts)
+                uint32_t *__restrict__ interval_counts, unsigned long long *__restrict__ events,
+                uint32_t event_capacity, uint32_t *__restrict__ event_count)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  // Layout: [count words: ceil(region_voxels / 2)] u16 pairs, then [mask words: ceil(region_voxels / 32)].
+  // Layout: [queues: kWalkWaves * kQueueCap u64][count words: ceil(region_voxels / 2)][mask words][cursor]
   const uint32_t count_words = uint32_t(mc.region_voxels + 1) >> 1;
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
-  uint32_t *l_counts = lds;
-  uint32_t *l_mask = lds + count_words;
+  unsigned long long *l_queues = reinterpret_cast<unsigned long long *>(lds);
+  uint32_t *l_counts = lds + 2 * kWalkWaves * kQueueCap;
+  uint32_t *l_mask = l_counts + count_words;
+  uint32_t *l_cursor = l_mask + mask_words;
 
   const Chunk chunk = chunks[blockIdx.x];
   const uint32_t *g_mask = hit_mask + size_t(chunk.slot) * mask_words;
@@ -609,125 +672,212 @@ __global__ void __launch_bounds__(kWalkThreads, 4)
   {
     l_mask[i] = g_mask[i];
   }
-  const uint32_t hb = bs.hit_begin[chunk.slot];
-  const uint32_t he = bs.hit_end[chunk.slot];
+  if (threadIdx.x == 0)
+  {
+    *l_cursor = 0;
+  }
   __syncthreads();
 
+  const unsigned lane = laneId();
+  const unsigned wave = threadIdx.x >> 6;
+  unsigned long long *queue = l_queues + wave * kQueueCap;
+  const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
   const int dimx = mc.dim[0];
   const int dimxy = mc.dim[0] * mc.dim[1];
+  const double inf = dInf();
+  const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
 
-  for (uint32_t si = chunk.seg_begin + threadIdx.x; si < chunk.seg_end; si += kWalkThreads)
+  // Per-lane walk state (all named scalars: no run-time indexed arrays).
+  bool active = false;
+  bool skip = false;
+  bool include_end = false;
+  double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
+  double t0 = 0, t1 = 0, t2 = 0, k0 = 0, k1 = 0, k2 = 0;  // time_next / steps taken per axis
+  int l0 = 0, l1 = 0, l2 = 0, rem0 = 0, rem1 = 0, rem2 = 0;
+  int sx = 0, sy = 0, sz = 0, d0 = 0, d1 = 0, d2 = 0;
+  uint32_t vi = 0;
+  uint32_t ray = 0;
+  uint32_t qcount = 0;  // wave-uniform
+  bool exhausted = false;  // wave-uniform
+
+  while (true)
   {
-    const Segment seg = segments[si];
-    const RayWalk rw = walks[seg.ray];
-    const int eaxis = int(seg.axis_step >> 30);
-    const int ej = int(seg.axis_step & 0x3fffffffu);
-
-    // Resume state: steps taken per axis when the region is entered.
-    int s0 = 0, s1 = 0, s2 = 0;
-    if (eaxis < 3)
+    // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
+    const unsigned long long idle = __ballot(!active);
+    const int n_idle = __popcll(idle);
+    if (!exhausted && (n_idle >= kRefillMinIdle))
     {
-      const double ta = stepTime(rw.init[eaxis], rw.delta[eaxis], ej);
-      s0 = (eaxis == 0) ? ej : stepsBefore(rw, 0, eaxis, ta);
-      s1 = (eaxis == 1) ? ej : stepsBefore(rw, 1, eaxis, ta);
-      s2 = (eaxis == 2) ? ej : stepsBefore(rw, 2, eaxis, ta);
+      uint32_t base = 0;
+      if (lane == 0)
+      {
+        base = atomicAdd(l_cursor, uint32_t(n_idle));
+      }
+      base = __shfl(base, 0);
+      exhausted = base + uint32_t(n_idle) >= n_seg;
+      const uint32_t mine = base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+      if (!active && mine < n_seg)
+      {
+        const Segment seg = segments[chunk.seg_begin + mine];
+        const RayWalk rw = walks[seg.ray];
+        const int eaxis = int(seg.axis_step >> 30);
+        const int ej = int(seg.axis_step & 0x3fffffffu);
+        i0 = rw.init[0];
+        i1 = rw.init[1];
+        i2 = rw.init[2];
+        e0 = rw.delta[0];
+        e1 = rw.delta[1];
+        e2 = rw.delta[2];
+        // Resume state: steps taken per axis when the region is entered.
+        int s0 = 0, s1 = 0, s2 = 0;
+        if (eaxis < 3)
+        {
+          const double ta = stepTime(sel3(eaxis, i0, i1, i2), sel3(eaxis, e0, e1, e2), ej);
+          s0 = (eaxis == 0) ? ej : stepsBefore(i0, e0, rw.total[0], 0, eaxis, ta);
+          s1 = (eaxis == 1) ? ej : stepsBefore(i1, e1, rw.total[1], 1, eaxis, ta);
+          s2 = (eaxis == 2) ? ej : stepsBefore(i2, e2, rw.total[2], 2, eaxis, ta);
+        }
+        d0 = rwDir(rw, 0);
+        d1 = rwDir(rw, 1);
+        d2 = rwDir(rw, 2);
+        int rtmp;
+        splitGlobal(rw.g0[0] + d0 * s0, mc.dim[0], rtmp, l0);
+        splitGlobal(rw.g0[1] + d1 * s1, mc.dim[1], rtmp, l1);
+        splitGlobal(rw.g0[2] + d2 * s2, mc.dim[2], rtmp, l2);
+        rem0 = rw.total[0] - s0;
+        rem1 = rw.total[1] - s1;
+        rem2 = rw.total[2] - s2;
+        k0 = double(s0);
+        k1 = double(s1);
+        k2 = double(s2);
+        // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
+        t0 = rem0 ? ((s0 == 0) ? i0 : i0 + e0 * k0) : inf;
+        t1 = rem1 ? ((s1 == 0) ? i1 : i1 + e1 * k1) : inf;
+        t2 = rem2 ? ((s2 == 0) ? i2 : i2 + e2 * k2) : inf;
+        sx = d0;
+        sy = d1 * dimx;
+        sz = d2 * dimxy;
+        vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
+        skip = (eaxis == 3) && (rw.flags & kRwExcludeStart);
+        include_end = (rw.flags & kRwIncludeEnd) != 0;
+        ray = seg.ray;
+        active = true;
+      }
     }
-    const int d0 = rwDir(rw, 0), d1 = rwDir(rw, 1), d2 = rwDir(rw, 2);
-    int l0, l1, l2, rtmp;
-    splitGlobal(rw.g0[0] + d0 * s0, mc.dim[0], rtmp, l0);
-    splitGlobal(rw.g0[1] + d1 * s1, mc.dim[1], rtmp, l1);
-    splitGlobal(rw.g0[2] + d2 * s2, mc.dim[2], rtmp, l2);
-    int rem0 = rw.total[0] - s0, rem1 = rw.total[1] - s1, rem2 = rw.total[2] - s2;
-    // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
-    const double inf = dInf();
-    double k0 = double(s0), k1 = double(s1), k2 = double(s2);
-    double t0 = rem0 ? ((s0 == 0) ? rw.init[0] : rw.init[0] + rw.delta[0] * k0) : inf;
-    double t1 = rem1 ? ((s1 == 0) ? rw.init[1] : rw.init[1] + rw.delta[1] * k1) : inf;
-    double t2 = rem2 ? ((s2 == 0) ? rw.init[2] : rw.init[2] + rw.delta[2] * k2) : inf;
-
-    bool skip = (eaxis == 3) && (rw.flags & kRwExcludeStart);
-    const bool include_end = (rw.flags & kRwIncludeEnd) != 0;
-    const uint32_t ray_key_low = seg.ray;
-
-    while (true)
+    if (!__any(active))
     {
-      const bool at_end = (rem0 | rem1 | rem2) == 0;
-      if (at_end && !include_end)
+      break;
+    }
+
+    // ---- one walk step for every active lane (predicated, wave-uniform control flow) -------------------------------
+    const bool at_end = (rem0 | rem1 | rem2) == 0;
+    const bool visit = active && (at_end ? include_end : !skip);
+    bool flagged = false;
+    if (visit)
+    {
+      flagged = (l_mask[vi >> 5] >> (vi & 31)) & 1u;
+      if (!flagged)
       {
-        break;
+        atomicAdd(&l_counts[vi >> 1], 1u << ((vi & 1u) * 16u));
       }
-      if (at_end || !skip)
+    }
+    const unsigned long long fm = __ballot(flagged);
+    if (fm)
+    {
+      if (flagged)
       {
-        const uint32_t vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
-        const bool flagged = (l_mask[vi >> 5] >> (vi & 31)) & 1u;
-        bool counted = false;
-        if (flagged)
+        queue[qcount + uint32_t(__popcll(fm & ((1ull << lane) - 1ull)))] =
+          slot_bits | ((unsigned long long)vi << kHitRayBits) | (unsigned long long)ray;
+      }
+      qcount += uint32_t(__popcll(fm));
+      if (qcount > uint32_t(kQueueCap - 64))
+      {
+        // Flush this wave's queue: one global atomic for the burst, coalesced 8-byte stores.
+        uint32_t gbase = 0;
+        if (lane == 0)
         {
-          // Voxel receives samples this batch: the miss must be ordered against them.  Find the first hit of this
-          // voxel whose ray index is greater than ours; the miss counts towards the interval before that hit.
-          const unsigned long long probe = ((unsigned long long)vi << kHitRayBits) | ray_key_low;
-          const unsigned long long low_mask = (1ull << kHitSlotShift) - 1ull;
-          uint32_t lo = hb, hi = he;
-          while (lo < hi)
+          gbase = atomicAdd(event_count, qcount);
+        }
+        gbase = __shfl(gbase, 0);
+        for (uint32_t q = lane; q < qcount; q += 64)
+        {
+          const unsigned long long ev = queue[q];
+          if (gbase + q < event_capacity)
           {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((sorted_hits[mid] & low_mask) > probe)
-            {
-              hi = mid;
-            }
-            else
-            {
-              lo = mid + 1;
-            }
+            events[gbase + q] = ev;
           }
-          if (lo < he && uint32_t((sorted_hits[lo] & low_mask) >> kHitRayBits) == vi)
+          else
           {
-            atomicAdd(&interval_counts[lo], 1u);
-            counted = true;
+            resolveFlaggedMiss(ev, bs, sorted_hits, miss_counts, interval_counts, mc.region_voxels);
           }
         }
-        if (!counted)
-        {
-          atomicAdd(&l_counts[vi >> 1], 1u << ((vi & 1u) * 16u));
-        }
+        qcount = 0;
       }
-      skip = false;
+    }
+    skip = false;
+    if (active)
+    {
       if (at_end)
       {
-        break;
-      }
-      // walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
-      int axis = (t0 < t1) ? 0 : 1;
-      const double t01 = (t0 < t1) ? t0 : t1;
-      axis = (t01 < t2) ? axis : 2;
-      bool left;
-      if (axis == 0)
-      {
-        l0 += d0;
-        --rem0;
-        k0 += 1.0;
-        t0 = rem0 ? rw.init[0] + rw.delta[0] * k0 : inf;
-        left = (l0 < 0) || (l0 >= mc.dim[0]);
-      }
-      else if (axis == 1)
-      {
-        l1 += d1;
-        --rem1;
-        k1 += 1.0;
-        t1 = rem1 ? rw.init[1] + rw.delta[1] * k1 : inf;
-        left = (l1 < 0) || (l1 >= mc.dim[1]);
+        active = false;
       }
       else
       {
-        l2 += d2;
-        --rem2;
-        k2 += 1.0;
-        t2 = rem2 ? rw.init[2] + rw.delta[2] * k2 : inf;
-        left = (l2 < 0) || (l2 >= mc.dim[2]);
+        // walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
+        const bool c01 = t0 < t1;
+        const double t01 = c01 ? t0 : t1;
+        const bool c2 = t01 < t2;
+        bool left;
+        if (!c2)
+        {
+          l2 += d2;
+          --rem2;
+          k2 += 1.0;
+          t2 = rem2 ? i2 + e2 * k2 : inf;
+          vi += uint32_t(sz);
+          left = (l2 < 0) || (l2 >= mc.dim[2]);
+        }
+        else if (c01)
+        {
+          l0 += d0;
+          --rem0;
+          k0 += 1.0;
+          t0 = rem0 ? i0 + e0 * k0 : inf;
+          vi += uint32_t(sx);
+          left = (l0 < 0) || (l0 >= mc.dim[0]);
+        }
+        else
+        {
+          l1 += d1;
+          --rem1;
+          k1 += 1.0;
+          t1 = rem1 ? i1 + e1 * k1 : inf;
+          vi += uint32_t(sy);
+          left = (l1 < 0) || (l1 >= mc.dim[1]);
+        }
+        active = !left;
       }
-      if (left)
+    }
+  }
+
+  // Final queue flush.
+  if (qcount)
+  {
+    uint32_t gbase = 0;
+    if (lane == 0)
+    {
+      gbase = atomicAdd(event_count, qcount);
+    }
+    gbase = __shfl(gbase, 0);
+    for (uint32_t q = lane; q < qcount; q += 64)
+    {
+      const unsigned long long ev = queue[q];
+      if (gbase + q < event_capacity)
       {
-        break;
+        events[gbase + q] = ev;
+      }
+      else
+      {
+        resolveFlaggedMiss(ev, bs, sorted_hits, miss_counts, interval_counts, mc.region_voxels);
       }
     }
   }
@@ -751,6 +901,20 @@ __global__ void __launch_bounds__(kWalkThreads, 4)
         atomicAdd(&g_counts[2 * i + 1], hi);
       }
     }
+  }
+}
+
+/// Resolve the deferred miss events (grid-stride; the event count lives in device memory).
+__global__ void __launch_bounds__(256)
+  k_flagged_events(BatchScratch bs, const unsigned long long *__restrict__ events, uint32_t event_capacity,
+                   const uint32_t *__restrict__ event_count, const unsigned long long *__restrict__ sorted_hits,
+                   uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts, int region_voxels)
+{
+  const uint32_t n = min(*event_count, event_capacity);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  {
+    resolveFlaggedMiss(events[i], bs, sorted_hits, miss_counts, interval_counts, region_voxels);
   }
 }
 

@@ -71,7 +71,7 @@ struct ohmhip_map_s
   int device = 0;
   hipStream_t stream = nullptr;       ///< compute stream
   hipStream_t copy_stream = nullptr;  ///< side stream for region upload/download
-  hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 
   uint32_t slot_capacity = 0;
   uint32_t hash_capacity = 0;
@@ -93,7 +93,9 @@ struct ohmhip_map_s
   Chunk *d_chunks = nullptr;
   uint32_t chunk_capacity = 0;
 
-  DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev;
+  DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev, events;
+  uint32_t *d_event_count = nullptr;
+  uint32_t event_demand = 0;  ///< events the previous batch produced (sizes the next batch's list)
   void *h_stage = nullptr;  ///< pinned staging for host rays / region copies
   size_t h_stage_bytes = 0;
 
@@ -377,6 +379,12 @@ int ensureStage(ohmhip_map_t m, size_t bytes)
   return OHMHIP_OK;
 }
 
+size_t walkLdsBytes(const MapConst &mc)
+{
+  return (size_t(2 * kWalkWaves * kQueueCap) + size_t((mc.region_voxels + 1) / 2) + size_t((mc.region_voxels + 31) / 32) + 4) *
+         sizeof(uint32_t);
+}
+
 /// The occupancy batch pipeline.  d_rays: device pointer to 6 doubles per ray.
 int integrateOccupancy(ohmhip_map_t m, const double *d_rays, uint32_t n_rays, unsigned ray_flags)
 {
@@ -435,12 +443,29 @@ int integrateOccupancy(ohmhip_map_t m, const double *d_rays, uint32_t n_rays, un
     OHMHIP_CHECK(hipEventRecord(m->ev[2], s));
     if (info.n_chunks)
     {
-      const size_t lds_bytes =
-        (size_t((m->mc.region_voxels + 1) / 2) + size_t((m->mc.region_voxels + 31) / 32)) * sizeof(uint32_t);
-      hipLaunchKernelGGL(k_region_walk, dim3(info.n_chunks), dim3(kWalkThreads), lds_bytes, s, m->mc, batchScratch(m),
-                         m->d_chunks, static_cast<const Segment *>(m->segments.ptr),
+      // Deferred-event list: sized from the visit count (a quarter of all visits, or what the last batch needed).
+      const uint64_t want_events =
+        std::min<uint64_t>(std::max<uint64_t>({ uint64_t(1) << 20, info.visits / 4, uint64_t(m->event_demand) * 5 / 4 }),
+                           0xfffffff0ull);
+      OHMHIP_CHECK(m->events.ensure(sizeof(unsigned long long) * size_t(want_events), false, s));
+      const uint32_t event_capacity =
+        uint32_t(std::min<size_t>(m->events.bytes / sizeof(unsigned long long), 0xfffffff0u));
+      OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k_region_walk, dim3(info.n_chunks), dim3(kWalkThreads), walkLdsBytes(m->mc), s, m->mc,
+                         batchScratch(m), m->d_chunks, static_cast<const Segment *>(m->segments.ptr),
                          static_cast<const RayWalk *>(m->walks.ptr), sorted, m->d_hit_mask, m->d_miss_counts,
-                         static_cast<uint32_t *>(m->interval_counts.ptr));
+                         static_cast<uint32_t *>(m->interval_counts.ptr),
+                         static_cast<unsigned long long *>(m->events.ptr), event_capacity, m->d_event_count);
+      OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
+      hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m),
+                         static_cast<const unsigned long long *>(m->events.ptr), event_capacity, m->d_event_count,
+                         sorted, m->d_miss_counts, static_cast<uint32_t *>(m->interval_counts.ptr),
+                         m->mc.region_voxels);
+      OHMHIP_CHECK(hipMemcpyAsync(&m->h_info[1], m->d_event_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    else
+    {
+      OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
     }
     OHMHIP_CHECK(hipEventRecord(m->ev[3], s));
     hipLaunchKernelGGL(k_apply_hits, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
@@ -614,7 +639,11 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   {
     return fail(err);
   }
-  if ((err = hipHostMalloc(reinterpret_cast<void **>(&m->h_info), sizeof(BatchInfo), hipHostMallocDefault)) != 0)
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_event_count), sizeof(uint32_t))) != 0)
+  {
+    return fail(err);
+  }
+  if ((err = hipHostMalloc(reinterpret_cast<void **>(&m->h_info), 2 * sizeof(BatchInfo), hipHostMallocDefault)) != 0)
   {
     return fail(err);
   }
@@ -631,7 +660,7 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
     return fail(err);
   }
   // The walk kernel stages a region's count tile + hit mask in LDS (68 KiB for 32^3).
-  const size_t lds_bytes = (size_t((mc.region_voxels + 1) / 2) + size_t((mc.region_voxels + 31) / 32)) * 4;
+  const size_t lds_bytes = walkLdsBytes(mc);
   if ((err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_walk),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
   {
@@ -665,6 +694,11 @@ int ohmhip_map_destroy(ohmhip_map_t m)
   m->rays_dev.release();
   m->intens_dev.release();
   m->times_dev.release();
+  m->events.release();
+  if (m->d_event_count)
+  {
+    (void)hipFree(m->d_event_count);
+  }
   if (m->d_n_slots)
   {
     (void)hipFree(m->d_n_slots);
@@ -818,11 +852,13 @@ int ohmhip_map_last_stats(ohmhip_map_t m, ohmhip_batch_stats *stats)
     m->stats.ms_total = ms;
     OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
     m->stats.ms_setup = ms;
-    OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[2], m->ev[3]));
+    OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[2], m->ev[5]));
     m->stats.ms_walk = ms;
+    // The previous batch's deferred-event demand sizes the next batch's event list.
+    m->event_demand = *reinterpret_cast<const uint32_t *>(&m->h_info[1]);
     float ms_sort = 0, ms_apply = 0;
     OHMHIP_CHECK(hipEventElapsedTime(&ms_sort, m->ev[1], m->ev[2]));
-    OHMHIP_CHECK(hipEventElapsedTime(&ms_apply, m->ev[3], m->ev[4]));
+    OHMHIP_CHECK(hipEventElapsedTime(&ms_apply, m->ev[5], m->ev[4]));
     m->stats.ms_apply = ms_sort + ms_apply;
     m->stats_pending = false;
   }
@@ -967,7 +1003,7 @@ int ohmhip_map_read_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xy
     return err;
   }
   char *stage[2] = { static_cast<char *>(m->h_stage), static_cast<char *>(m->h_stage) + burst * stride };
-  hipEvent_t done[2] = { m->ev[5], nullptr };
+  hipEvent_t done[2] = { m->ev[6], nullptr };
   OHMHIP_CHECK(hipEventCreate(&done[1]));
   size_t pending_base[2] = { 0, 0 };
   size_t pending_n[2] = { 0, 0 };

@@ -100,18 +100,23 @@ __device__ inline bool stepPrecedes(double tb, int b, double ta, int a)
   return tb < ta || (tb == ta && b > a);
 }
 
-/// Number of steps already taken along axis b at the moment the j-th step of axis a is about to be taken.
+/// Select one of three per-axis values without indexing an array at run time (run-time indexed locals end up in
+/// scratch memory on gfx950; every per-axis quantity in the kernels is therefore a named scalar).
+template <typename T>
+__device__ inline T sel3(int axis, T v0, T v1, T v2)
+{
+  return (axis == 0) ? v0 : ((axis == 1) ? v1 : v2);
+}
+
+/// Number of steps already taken along axis b at the moment the j-th step of axis a (time ta) is about to be taken.
 /// T_b(i) is non-decreasing in i so the preceding steps form a prefix [1, n]; estimate n by division and fix up with
 /// the exact predicate so the result is identical to running the reference walk step by step.
-__device__ inline int stepsBefore(const RayWalk &rw, int b, int a, double ta)
+__device__ inline int stepsBefore(double init, double delta, int total, int b, int a, double ta)
 {
-  const int total = rw.total[b];
   if (total == 0)
   {
     return 0;
   }
-  const double init = rw.init[b];
-  const double delta = rw.delta[b];
   int n;
   if (delta > 0 && delta < dInf())
   {
