@@ -370,7 +370,8 @@ __global__ void __launch_bounds__(256)
 // k_plan: one block.  Exclusive scan of per-region segment counts over the touched list; build chunk list.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-  k_plan(RegionTable rt, BatchScratch bs, Chunk *__restrict__ chunks, uint32_t chunk_capacity)
+  k_plan(RegionTable rt, BatchScratch bs, Chunk *__restrict__ chunks, uint32_t chunk_capacity,
+         uint32_t chunk_segments)
 {
   __shared__ uint32_t s_seg[1024];
   __shared__ uint32_t s_chk[1024];
@@ -392,7 +393,7 @@ __global__ void __launch_bounds__(1024)
     {
       h = bs.touched[i];
       cnt = bs.seg_count[h];
-      nchk = (cnt + kChunkSegments - 1) / kChunkSegments;
+      nchk = (cnt + chunk_segments - 1) / chunk_segments;
     }
     s_seg[tid] = cnt;
     s_chk[tid] = nchk;
@@ -430,8 +431,8 @@ __global__ void __launch_bounds__(1024)
         {
           Chunk ch;
           ch.slot = slot;
-          ch.seg_begin = seg_excl + c * kChunkSegments;
-          ch.seg_end = seg_excl + min(cnt, (c + 1) * kChunkSegments);
+          ch.seg_begin = seg_excl + c * chunk_segments;
+          ch.seg_end = seg_excl + min(cnt, (c + 1) * chunk_segments);
           ch.hash_index = h;
           chunks[chk_excl + c] = ch;
         }
@@ -651,7 +652,7 @@ __global__ void __launch_bounds__(kWalkThreads)
                 const RayWalk *__restrict__ walks, const unsigned long long *__restrict__ sorted_hits,
                 const uint32_t *__restrict__ hit_mask, uint32_t *__restrict__ miss_counts,
                 uint32_t *__restrict__ interval_counts, unsigned long long *__restrict__ events,
-                uint32_t event_capacity, uint32_t *__restrict__ event_count)
+                uint32_t event_capacity, uint32_t *__restrict__ event_count, int refill_min_idle, unsigned dbg)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   // Layout: [queues: kWalkWaves * kQueueCap u64][count words: ceil(region_voxels / 2)][mask words][cursor]
@@ -693,8 +694,8 @@ __global__ void __launch_bounds__(kWalkThreads)
   bool include_end = false;
   double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
   double t0 = 0, t1 = 0, t2 = 0, k0 = 0, k1 = 0, k2 = 0;  // time_next / steps taken per axis
-  int l0 = 0, l1 = 0, l2 = 0, rem0 = 0, rem1 = 0, rem2 = 0;
-  int sx = 0, sy = 0, sz = 0, d0 = 0, d1 = 0, d2 = 0;
+  int room0 = 0, room1 = 0, room2 = 0, rem0 = 0, rem1 = 0, rem2 = 0;
+  int sx = 0, sy = 0, sz = 0;
   uint32_t vi = 0;
   uint32_t ray = 0;
   uint32_t qcount = 0;  // wave-uniform
@@ -705,7 +706,7 @@ __global__ void __launch_bounds__(kWalkThreads)
     // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
     const unsigned long long idle = __ballot(!active);
     const int n_idle = __popcll(idle);
-    if (!exhausted && (n_idle >= kRefillMinIdle))
+    if (!exhausted && (n_idle >= refill_min_idle))
     {
       uint32_t base = 0;
       if (lane == 0)
@@ -736,13 +737,16 @@ __global__ void __launch_bounds__(kWalkThreads)
           s1 = (eaxis == 1) ? ej : stepsBefore(i1, e1, rw.total[1], 1, eaxis, ta);
           s2 = (eaxis == 2) ? ej : stepsBefore(i2, e2, rw.total[2], 2, eaxis, ta);
         }
-        d0 = rwDir(rw, 0);
-        d1 = rwDir(rw, 1);
-        d2 = rwDir(rw, 2);
-        int rtmp;
+        const int d0 = rwDir(rw, 0);
+        const int d1 = rwDir(rw, 1);
+        const int d2 = rwDir(rw, 2);
+        int rtmp, l0, l1, l2;
         splitGlobal(rw.g0[0] + d0 * s0, mc.dim[0], rtmp, l0);
         splitGlobal(rw.g0[1] + d1 * s1, mc.dim[1], rtmp, l1);
         splitGlobal(rw.g0[2] + d2 * s2, mc.dim[2], rtmp, l2);
+        room0 = (d0 > 0) ? (mc.dim[0] - 1 - l0) : l0;
+        room1 = (d1 > 0) ? (mc.dim[1] - 1 - l1) : l1;
+        room2 = (d2 > 0) ? (mc.dim[2] - 1 - l2) : l2;
         rem0 = rw.total[0] - s0;
         rem1 = rw.total[1] - s1;
         rem2 = rw.total[2] - s2;
@@ -760,7 +764,7 @@ __global__ void __launch_bounds__(kWalkThreads)
         skip = (eaxis == 3) && (rw.flags & kRwExcludeStart);
         include_end = (rw.flags & kRwIncludeEnd) != 0;
         ray = seg.ray;
-        active = true;
+        active = !(dbg & 16u);
       }
     }
     if (!__any(active))
@@ -774,11 +778,12 @@ __global__ void __launch_bounds__(kWalkThreads)
     bool flagged = false;
     if (visit)
     {
-      flagged = (l_mask[vi >> 5] >> (vi & 31)) & 1u;
-      if (!flagged)
+      flagged = (dbg & 2u) ? false : bool((l_mask[vi >> 5] >> (vi & 31)) & 1u);
+      if (!flagged && !(dbg & 1u))
       {
         atomicAdd(&l_counts[vi >> 1], 1u << ((vi & 1u) * 16u));
       }
+      flagged = flagged && !(dbg & 8u);
     }
     const unsigned long long fm = __ballot(flagged);
     if (fm)
@@ -814,48 +819,38 @@ __global__ void __launch_bounds__(kWalkThreads)
       }
     }
     skip = false;
-    if (active)
     {
-      if (at_end)
-      {
-        active = false;
-      }
-      else
-      {
-        // walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
-        const bool c01 = t0 < t1;
-        const double t01 = c01 ? t0 : t1;
-        const bool c2 = t01 < t2;
-        bool left;
-        if (!c2)
-        {
-          l2 += d2;
-          --rem2;
-          k2 += 1.0;
-          t2 = rem2 ? i2 + e2 * k2 : inf;
-          vi += uint32_t(sz);
-          left = (l2 < 0) || (l2 >= mc.dim[2]);
-        }
-        else if (c01)
-        {
-          l0 += d0;
-          --rem0;
-          k0 += 1.0;
-          t0 = rem0 ? i0 + e0 * k0 : inf;
-          vi += uint32_t(sx);
-          left = (l0 < 0) || (l0 >= mc.dim[0]);
-        }
-        else
-        {
-          l1 += d1;
-          --rem1;
-          k1 += 1.0;
-          t1 = rem1 ? i1 + e1 * k1 : inf;
-          vi += uint32_t(sy);
-          left = (l1 < 0) || (l1 >= mc.dim[1]);
-        }
-        active = !left;
-      }
+      // One branch-free walk step for every lane that still has steps to take.  All three axes' candidate updates are
+      // computed (independent fp64 chains, no exec-mask juggling) and the selected axis' values are committed with
+      // selects.  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
+      const bool stepping = active && !at_end;
+      const bool c01 = t0 < t1;
+      const double t01 = c01 ? t0 : t1;
+      const bool c2 = t01 < t2;
+      const bool is2 = stepping && !c2;
+      const bool is0 = stepping && c2 && c01;
+      const bool is1 = stepping && c2 && !c01;
+      const double k0n = k0 + 1.0;
+      const double k1n = k1 + 1.0;
+      const double k2n = k2 + 1.0;
+      const double t0n = i0 + e0 * k0n;  // ohm/LineWalkCompute.h:299-301
+      const double t1n = i1 + e1 * k1n;
+      const double t2n = i2 + e2 * k2n;
+      rem0 -= int(is0);
+      rem1 -= int(is1);
+      rem2 -= int(is2);
+      room0 -= int(is0);
+      room1 -= int(is1);
+      room2 -= int(is2);
+      k0 = is0 ? k0n : k0;
+      k1 = is1 ? k1n : k1;
+      k2 = is2 ? k2n : k2;
+      t0 = is0 ? (rem0 ? t0n : inf) : t0;
+      t1 = is1 ? (rem1 ? t1n : inf) : t1;
+      t2 = is2 ? (rem2 ? t2n : inf) : t2;
+      vi += uint32_t(is0 ? sx : (is1 ? sy : (is2 ? sz : 0)));
+      // room* counts the steps that can still be taken along an axis before the ray leaves the region.
+      active = stepping && ((room0 | room1 | room2) >= 0);
     }
   }
 
@@ -887,7 +882,7 @@ __global__ void __launch_bounds__(kWalkThreads)
   uint32_t *g_counts = miss_counts + size_t(chunk.slot) * size_t(mc.region_voxels);
   for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
   {
-    const uint32_t w = l_counts[i];
+    const uint32_t w = (dbg & 4u) ? 0u : l_counts[i];
     if (w)
     {
       const uint32_t lo = w & 0xffffu;

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -95,7 +96,10 @@ struct ohmhip_map_s
 
   DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev, events;
   uint32_t *d_event_count = nullptr;
-  uint32_t event_demand = 0;  ///< events the previous batch produced (sizes the next batch's list)
+  uint32_t event_demand = 0;
+  uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= 65535 (u16 LDS counters)
+  unsigned debug_flags = 0;  ///< OHMHIP_DEBUG_FLAGS: timing experiments only (breaks results)
+  int refill_min_idle = kRefillMinIdle;      ///< tunable (OHMHIP_REFILL_MIN_IDLE)  ///< events the previous batch produced (sizes the next batch's list)
   void *h_stage = nullptr;  ///< pinned staging for host rays / region copies
   size_t h_stage_bytes = 0;
 
@@ -408,7 +412,7 @@ int integrateOccupancy(ohmhip_map_t m, const double *d_rays, uint32_t n_rays, un
     hipLaunchKernelGGL(k_ray_setup, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
                        n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr));
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
-                       m->chunk_capacity);
+                       m->chunk_capacity, m->chunk_segments);
     OHMHIP_CHECK(hipMemcpyAsync(m->h_info, m->d_info, sizeof(BatchInfo), hipMemcpyDeviceToHost, s));
     OHMHIP_CHECK(hipStreamSynchronize(s));
     OHMHIP_CHECK(hipGetLastError());
@@ -455,7 +459,8 @@ int integrateOccupancy(ohmhip_map_t m, const double *d_rays, uint32_t n_rays, un
                          batchScratch(m), m->d_chunks, static_cast<const Segment *>(m->segments.ptr),
                          static_cast<const RayWalk *>(m->walks.ptr), sorted, m->d_hit_mask, m->d_miss_counts,
                          static_cast<uint32_t *>(m->interval_counts.ptr),
-                         static_cast<unsigned long long *>(m->events.ptr), event_capacity, m->d_event_count);
+                         static_cast<unsigned long long *>(m->events.ptr), event_capacity, m->d_event_count,
+                         m->refill_min_idle, m->debug_flags);
       OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
       hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m),
                          static_cast<const unsigned long long *>(m->events.ptr), event_capacity, m->d_event_count,
@@ -665,6 +670,18 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
   {
     return fail(err);
+  }
+  if (const char *env = std::getenv("OHMHIP_CHUNK_SEGMENTS"))
+  {
+    m->chunk_segments = uint32_t(std::max(64, std::min(65535, std::atoi(env))));
+  }
+  if (const char *env = std::getenv("OHMHIP_DEBUG_FLAGS"))
+  {
+    m->debug_flags = unsigned(std::atoi(env));
+  }
+  if (const char *env = std::getenv("OHMHIP_REFILL_MIN_IDLE"))
+  {
+    m->refill_min_idle = std::max(1, std::min(64, std::atoi(env)));
   }
   *map = m;
   return OHMHIP_OK;

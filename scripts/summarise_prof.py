@@ -1,7 +1,8 @@
-"""Summarise rocprofv3 outputs (kernel stats + PMC counter CSVs) into a small text table."""
+"""Summarise rocprofv3 CSV outputs (kernel stats + PMC counter CSVs) into a small text table."""
 import csv
 import glob
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -12,28 +13,34 @@ def find(pattern):
     return sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
 
 
+def short(name):
+    m = re.search(r"(k_[a-z_]+|radix_sort[a-z_]*|merge_sort[a-z_]*|fillBuffer\w*|copyBuffer\w*)", name)
+    return m.group(1) if m else name[:50]
+
+
 for f in find("*kernel_stats.csv"):
-    print("== kernel stats:", os.path.relpath(f, out))
+    print("== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, out))
     with open(f) as fh:
-        for i, row in enumerate(csv.reader(fh)):
-            if i < 14:
-                print("  ", ", ".join(row[:8]))
+        rows = list(csv.DictReader(fh))
+    print(f"   {'kernel':34s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    for r in rows[:16]:
+        print(f"   {short(r['Name']):34s} {r['Calls']:>6s} {float(r['TotalDurationNs']) / 1e3:12.1f} "
+              f"{float(r['AverageNs']) / 1e3:10.1f} {float(r['MinNs']) / 1e3:10.1f} {float(r['MaxNs']) / 1e3:10.1f} "
+              f"{float(r['Percentage']):6.2f}")
 
 for f in find("*counter_collection.csv"):
     print("== counters:", os.path.relpath(f, out))
     agg = defaultdict(lambda: defaultdict(float))
-    cnt = defaultdict(int)
+    launches = defaultdict(set)
     with open(f) as fh:
-        rd = csv.DictReader(fh)
-        for row in rd:
-            k = row.get("Kernel_Name", "?")[:60]
-            c = row.get("Counter_Name")
-            v = float(row.get("Counter_Value", 0) or 0)
-            agg[k][c] += v
-            if c == list(agg[k].keys())[0]:
-                cnt[k] += 1
+        for row in csv.DictReader(fh):
+            k = short(row.get("Kernel_Name", "?"))
+            agg[k][row["Counter_Name"]] += float(row["Counter_Value"] or 0)
+            launches[k].add(row.get("Dispatch_Id"))
     for k, cs in agg.items():
-        n = max(cnt[k], 1)
-        print("  ", k, "launches", n)
+        if not k.startswith("k_"):
+            continue
+        n = max(len(launches[k]), 1)
+        print(f"   {k}  launches={n}")
         for c, v in cs.items():
-            print(f"      {c:28s} per-launch {v / n:18.1f}")
+            print(f"      {c:26s} per-launch {v / n:18.1f}")
