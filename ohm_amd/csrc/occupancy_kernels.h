@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(1024)
 __global__ void __launch_bounds__(256)
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
-            uint32_t *__restrict__ hit_mask)
+            uint32_t *__restrict__ hit_mask, int ray_shift)
 {
   const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned lane = laneId();
@@ -492,8 +492,9 @@ __global__ void __launch_bounds__(256)
       if (slot < rt.slot_capacity)
       {
         const uint32_t vi = uint32_t(l1[0] + l1[1] * mc.dim[0] + l1[2] * mc.dim[0] * mc.dim[1]);
+        // ray_shift == 1 (NDT / TSDF event streams): the low bit tags the key as a sample (hit) event.
         hk = ((unsigned long long)slot << kHitSlotShift) | ((unsigned long long)vi << kHitRayBits) |
-             (unsigned long long)ray;
+             ((unsigned long long)ray << ray_shift) | (unsigned long long)(ray_shift ? 1u : 0u);
         atomicOr(&hit_mask[size_t(slot) * (size_t(mc.region_voxels + 31) / 32) + (vi >> 5)], 1u << (vi & 31));
         is_hit = true;
       }
@@ -570,6 +571,38 @@ __global__ void __launch_bounds__(256)
       todo &= ~same;
     }
   }
+}
+
+/// Rewrite only the sample (hit) keys of a batch (used when the NDT / TSDF key buffer had to be re-allocated).
+__global__ void __launch_bounds__(256)
+  k_rekey_samples(MapConst mc, RegionTable rt, const RayWalk *__restrict__ walks, uint32_t n_rays,
+                  unsigned long long *__restrict__ hit_keys, int ray_shift)
+{
+  const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n_rays)
+  {
+    return;
+  }
+  const RayWalk rw = walks[ray];
+  unsigned long long hk = kHitInvalid;
+  if ((rw.flags & kRwValid) && (rw.flags & kRwApplySample))
+  {
+    int r1[3], l1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+    {
+      splitGlobal(rw.g0[a] + rwDir(rw, a) * rw.total[a], mc.dim[a], r1[a], l1[a]);
+    }
+    const uint32_t h = regionFind(rt, packRegionKey(r1[0], r1[1], r1[2]));
+    const uint32_t slot = (h != 0xffffffffu) ? rt.vals[h] : kSlotUnassigned;
+    if (slot < rt.slot_capacity)
+    {
+      const uint32_t vi = uint32_t(l1[0] + l1[1] * mc.dim[0] + l1[2] * mc.dim[0] * mc.dim[1]);
+      hk = ((unsigned long long)slot << kHitSlotShift) | ((unsigned long long)vi << kHitRayBits) |
+           ((unsigned long long)ray << ray_shift) | (unsigned long long)(ray_shift ? 1u : 0u);
+    }
+  }
+  hit_keys[ray] = hk;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -652,7 +685,8 @@ __global__ void __launch_bounds__(kWalkThreads)
                 const RayWalk *__restrict__ walks, const unsigned long long *__restrict__ sorted_hits,
                 const uint32_t *__restrict__ hit_mask, uint32_t *__restrict__ miss_counts,
                 uint32_t *__restrict__ interval_counts, unsigned long long *__restrict__ events,
-                uint32_t event_capacity, uint32_t *__restrict__ event_count, int refill_min_idle, unsigned dbg)
+                uint32_t event_capacity, uint32_t *__restrict__ event_count, int refill_min_idle, unsigned dbg, int ray_shift,
+                int defer_all)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   // Layout: [queues: kWalkWaves * kQueueCap u64][count words: ceil(region_voxels / 2)][mask words][cursor]
@@ -791,7 +825,7 @@ __global__ void __launch_bounds__(kWalkThreads)
       if (flagged)
       {
         queue[qcount + uint32_t(__popcll(fm & ((1ull << lane) - 1ull)))] =
-          slot_bits | ((unsigned long long)vi << kHitRayBits) | (unsigned long long)ray;
+          slot_bits | ((unsigned long long)vi << kHitRayBits) | ((unsigned long long)ray << ray_shift);
       }
       qcount += uint32_t(__popcll(fm));
       if (qcount > uint32_t(kQueueCap - 64))
@@ -810,7 +844,7 @@ __global__ void __launch_bounds__(kWalkThreads)
           {
             events[gbase + q] = ev;
           }
-          else
+          else if (!defer_all)
           {
             resolveFlaggedMiss(ev, bs, sorted_hits, miss_counts, interval_counts, mc.region_voxels);
           }
@@ -870,7 +904,7 @@ __global__ void __launch_bounds__(kWalkThreads)
       {
         events[gbase + q] = ev;
       }
-      else
+      else if (!defer_all)
       {
         resolveFlaggedMiss(ev, bs, sorted_hits, miss_counts, interval_counts, mc.region_voxels);
       }
@@ -1065,7 +1099,8 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
   k_apply_counts(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags, uint32_t *__restrict__ miss_counts,
-                 uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy)
+                 uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy, int clear_mask,
+                 uint32_t *__restrict__ hit_miss_counts)
 {
   const uint32_t h = bs.touched[blockIdx.x];
   const uint32_t slot = rt.vals[h];
@@ -1077,12 +1112,20 @@ __global__ void __launch_bounds__(256)
     {
       occupancy[base + vi] = occMissN(mc, ray_flags, occupancy[base + vi], n);
       miss_counts[base + vi] = 0;
+      if (hit_miss_counts)
+      {
+        // NDT-TM: every plain miss increments HitMissCount::miss_count (ohm/RayMapperNdt.cpp:171-178).
+        hit_miss_counts[2 * (base + vi) + 1] += n;
+      }
     }
   }
-  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
-  for (uint32_t i = threadIdx.x; i < mask_words; i += blockDim.x)
+  if (clear_mask)
   {
-    hit_mask[size_t(slot) * mask_words + i] = 0;
+    const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
+    for (uint32_t i = threadIdx.x; i < mask_words; i += blockDim.x)
+    {
+      hit_mask[size_t(slot) * mask_words + i] = 0;
+    }
   }
   if (threadIdx.x == 0)
   {

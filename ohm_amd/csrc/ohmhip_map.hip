@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "occupancy_kernels.h"
+#include "replay_kernels.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -389,21 +390,50 @@ size_t walkLdsBytes(const MapConst &mc)
          sizeof(uint32_t);
 }
 
-/// The occupancy batch pipeline.  d_rays: device pointer to 6 doubles per ray.
-int integrateOccupancy(ohmhip_map_t m, const double *d_rays, uint32_t n_rays, unsigned ray_flags)
+__global__ void k_clear_counts(MapConst mc, RegionTable rt, BatchScratch bs, uint32_t *__restrict__ miss_counts)
+{
+  const uint32_t slot = rt.vals[bs.touched[blockIdx.x]];
+  const size_t base = size_t(slot) * size_t(mc.region_voxels);
+  for (uint32_t vi = threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
+  {
+    miss_counts[base + vi] = 0;
+  }
+}
+
+/// One ray batch through the pipeline (all map modes).  d_rays: device pointer to 6 doubles per ray.
+int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensities, uint32_t n_rays,
+                   unsigned ray_flags)
 {
   hipStream_t s = m->stream;
   const uint32_t ray_blocks = (n_rays + 255) / 256;
+  const int mode = m->config.mode;
+  const bool occupancy_mode = mode == OHMHIP_MODE_OCCUPANCY;
+  const bool ndt_mode = mode == OHMHIP_MODE_NDT_OM || mode == OHMHIP_MODE_NDT_TM;
+  const bool tsdf_mode = mode == OHMHIP_MODE_TSDF;
+  if (ndt_mode)
+  {
+    // RayMapperNdt honours only kRfEndPointAsFree / kRfExcludeOrigin / kRfExcludeRay (ohm/RayMapperNdt.cpp:238-262).
+    ray_flags &= (OHMHIP_RF_END_POINT_AS_FREE | OHMHIP_RF_EXCLUDE_ORIGIN | OHMHIP_RF_EXCLUDE_RAY);
+  }
+  if (tsdf_mode)
+  {
+    // RayMapperTsdf ignores the flags and walks start..end inclusive (ohm/RayMapperTsdf.cpp:87-88, 176).
+    ray_flags = OHMHIP_RF_END_POINT_AS_FREE;
+  }
+  const int ray_shift = occupancy_mode ? 0 : kEvRayShift;
 
   OHMHIP_CHECK(m->walks.ensure(sizeof(RayWalk) * size_t(n_rays), false, s));
-  OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
-  OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
-  OHMHIP_CHECK(m->interval_counts.ensure(sizeof(uint32_t) * size_t(n_rays), true, s));
-  size_t sort_bytes = 0;
-  OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, static_cast<unsigned long long *>(m->hit_keys_a.ptr),
-                                        static_cast<unsigned long long *>(m->hit_keys_b.ptr), size_t(n_rays), 0, 64,
-                                        s));
-  OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
+  if (occupancy_mode)
+  {
+    OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
+    OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
+    OHMHIP_CHECK(m->interval_counts.ensure(sizeof(uint32_t) * size_t(n_rays), true, s));
+    size_t sort_bytes = 0;
+    OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, static_cast<unsigned long long *>(m->hit_keys_a.ptr),
+                                          static_cast<unsigned long long *>(m->hit_keys_b.ptr), size_t(n_rays), 0, 64,
+                                          s));
+    OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
+  }
 
   for (int attempt = 0; attempt < 8; ++attempt)
   {
@@ -433,55 +463,161 @@ int integrateOccupancy(ohmhip_map_t m, const double *d_rays, uint32_t n_rays, un
     OHMHIP_CHECK(m->segments.ensure(sizeof(Segment) * size_t(std::max<uint32_t>(info.n_segments, 1u)), false, s));
     const uint32_t seg_cap = uint32_t(std::min<size_t>(m->segments.bytes / sizeof(Segment), 0xffffffffu));
 
+    // Deferred-event list.  Occupancy: sized from the visit count or the previous batch's demand, with an inline
+    // fallback in the kernel.  NDT / TSDF: events share one key buffer with the sample keys and are sorted together.
+    uint64_t want_events =
+      std::max<uint64_t>({ uint64_t(1) << 20, info.visits / 4, uint64_t(m->event_demand) * 5 / 4 });
+    want_events = std::min<uint64_t>(want_events, 0xfffffff0ull - n_rays);
+    unsigned long long *keys_a = nullptr;
+    unsigned long long *keys_b = nullptr;
+    unsigned long long *events = nullptr;
+    uint32_t event_capacity = 0;
+    if (occupancy_mode)
+    {
+      OHMHIP_CHECK(m->events.ensure(sizeof(unsigned long long) * size_t(want_events), false, s));
+      keys_a = static_cast<unsigned long long *>(m->hit_keys_a.ptr);
+      keys_b = static_cast<unsigned long long *>(m->hit_keys_b.ptr);
+      events = static_cast<unsigned long long *>(m->events.ptr);
+      event_capacity = uint32_t(std::min<size_t>(m->events.bytes / sizeof(unsigned long long), 0xfffffff0u));
+    }
+    else
+    {
+      const size_t total = size_t(n_rays) + size_t(want_events);
+      OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * total, false, s));
+      OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * total, false, s));
+      keys_a = static_cast<unsigned long long *>(m->hit_keys_a.ptr);
+      keys_b = static_cast<unsigned long long *>(m->hit_keys_b.ptr);
+      events = keys_a + n_rays;
+      const size_t cap_a = m->hit_keys_a.bytes / sizeof(unsigned long long) - n_rays;
+      const size_t cap_b = m->hit_keys_b.bytes / sizeof(unsigned long long) - n_rays;
+      event_capacity = uint32_t(std::min<size_t>(std::min(cap_a, cap_b), 0xfffffff0u - n_rays));
+    }
+
     hipLaunchKernelGGL(k_ray_bin, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
                        static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
-                       seg_cap, static_cast<unsigned long long *>(m->hit_keys_a.ptr), m->d_hit_mask);
+                       seg_cap, keys_a, m->d_hit_mask, ray_shift);
+    if (tsdf_mode)
+    {
+      hipLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
+                         static_cast<const RayWalk *>(m->walks.ptr), d_rays, n_rays, m->d_hit_mask);
+    }
     OHMHIP_CHECK(hipEventRecord(m->ev[1], s));
-    size_t temp_bytes = m->sort_temp.bytes;
-    OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes,
-                                          static_cast<unsigned long long *>(m->hit_keys_a.ptr),
-                                          static_cast<unsigned long long *>(m->hit_keys_b.ptr), size_t(n_rays), 0, 64,
-                                          s));
-    const unsigned long long *sorted = static_cast<const unsigned long long *>(m->hit_keys_b.ptr);
-    hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m));
+    const unsigned long long *sorted = keys_b;
+    if (occupancy_mode)
+    {
+      size_t temp_bytes = m->sort_temp.bytes;
+      OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays), 0, 64, s));
+      hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m));
+    }
     OHMHIP_CHECK(hipEventRecord(m->ev[2], s));
+
+    uint32_t n_events = 0;
     if (info.n_chunks)
     {
-      // Deferred-event list: sized from the visit count (a quarter of all visits, or what the last batch needed).
-      const uint64_t want_events =
-        std::min<uint64_t>(std::max<uint64_t>({ uint64_t(1) << 20, info.visits / 4, uint64_t(m->event_demand) * 5 / 4 }),
-                           0xfffffff0ull);
-      OHMHIP_CHECK(m->events.ensure(sizeof(unsigned long long) * size_t(want_events), false, s));
-      const uint32_t event_capacity =
-        uint32_t(std::min<size_t>(m->events.bytes / sizeof(unsigned long long), 0xfffffff0u));
-      OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, sizeof(uint32_t), s));
-      hipLaunchKernelGGL(k_region_walk, dim3(info.n_chunks), dim3(kWalkThreads), walkLdsBytes(m->mc), s, m->mc,
-                         batchScratch(m), m->d_chunks, static_cast<const Segment *>(m->segments.ptr),
-                         static_cast<const RayWalk *>(m->walks.ptr), sorted, m->d_hit_mask, m->d_miss_counts,
-                         static_cast<uint32_t *>(m->interval_counts.ptr),
-                         static_cast<unsigned long long *>(m->events.ptr), event_capacity, m->d_event_count,
-                         m->refill_min_idle, m->debug_flags);
-      OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
-      hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m),
-                         static_cast<const unsigned long long *>(m->events.ptr), event_capacity, m->d_event_count,
-                         sorted, m->d_miss_counts, static_cast<uint32_t *>(m->interval_counts.ptr),
-                         m->mc.region_voxels);
-      OHMHIP_CHECK(hipMemcpyAsync(&m->h_info[1], m->d_event_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      for (int walk_attempt = 0; walk_attempt < 4; ++walk_attempt)
+      {
+        OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_region_walk, dim3(info.n_chunks), dim3(kWalkThreads), walkLdsBytes(m->mc), s, m->mc,
+                           batchScratch(m), m->d_chunks, static_cast<const Segment *>(m->segments.ptr),
+                           static_cast<const RayWalk *>(m->walks.ptr), sorted, m->d_hit_mask, m->d_miss_counts,
+                           static_cast<uint32_t *>(m->interval_counts.ptr), events, event_capacity, m->d_event_count,
+                           m->refill_min_idle, m->debug_flags, ray_shift, occupancy_mode ? 0 : 1);
+        OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
+        if (occupancy_mode)
+        {
+          hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m), events, event_capacity,
+                             m->d_event_count, sorted, m->d_miss_counts,
+                             static_cast<uint32_t *>(m->interval_counts.ptr), m->mc.region_voxels);
+          OHMHIP_CHECK(hipMemcpyAsync(&m->h_info[1], m->d_event_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+          break;
+        }
+        // NDT / TSDF: the host needs the event count to size the sort; an overflowing list is re-walked.
+        OHMHIP_CHECK(hipMemcpyAsync(&m->h_info[1], m->d_event_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        OHMHIP_CHECK(hipStreamSynchronize(s));
+        n_events = *reinterpret_cast<const uint32_t *>(&m->h_info[1]);
+        m->event_demand = n_events;
+        if (n_events <= event_capacity)
+        {
+          break;
+        }
+        // Overflow: undo the count flush, grow the key buffers (sample keys must be regenerated) and walk again.
+        hipLaunchKernelGGL(k_clear_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
+                           batchScratch(m), m->d_miss_counts);
+        const size_t total = size_t(n_rays) + size_t(n_events) + (size_t(n_events) >> 3) + 1024;
+        OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * total, false, s));
+        OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * total, false, s));
+        keys_a = static_cast<unsigned long long *>(m->hit_keys_a.ptr);
+        keys_b = static_cast<unsigned long long *>(m->hit_keys_b.ptr);
+        sorted = keys_b;
+        events = keys_a + n_rays;
+        event_capacity = uint32_t(std::min<size_t>(total - n_rays, 0xfffffff0u - n_rays));
+        // k_ray_bin also fills the segment buckets: only the sample keys are rewritten here (cursors already reset).
+        OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, sizeof(BatchInfo), s));
+        hipLaunchKernelGGL(k_rekey_samples, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
+                           static_cast<const RayWalk *>(m->walks.ptr), n_rays, keys_a, ray_shift);
+        if (walk_attempt == 3)
+        {
+          return OHMHIP_ERR_INTERNAL;
+        }
+      }
     }
     else
     {
       OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
     }
     OHMHIP_CHECK(hipEventRecord(m->ev[3], s));
-    hipLaunchKernelGGL(k_apply_hits, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
-                       ray_flags, sorted, static_cast<uint32_t *>(m->interval_counts.ptr), m->d_miss_counts, d_rays,
-                       static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
-                       static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]));
-    if (info.n_touched)
+
+    if (occupancy_mode)
     {
-      hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
-                         ray_flags, m->d_miss_counts, m->d_hit_mask,
-                         static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]));
+      hipLaunchKernelGGL(k_apply_hits, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
+                         ray_flags, sorted, static_cast<uint32_t *>(m->interval_counts.ptr), m->d_miss_counts, d_rays,
+                         static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
+                         static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]));
+      if (info.n_touched)
+      {
+        hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
+                           batchScratch(m), ray_flags, m->d_miss_counts, m->d_hit_mask,
+                           static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]), 1,
+                           static_cast<uint32_t *>(nullptr));
+      }
+    }
+    else
+    {
+      const size_t total = size_t(n_rays) + size_t(n_events);
+      size_t sort_bytes = 0;
+      OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, keys_a, keys_b, total, 0, 64, s));
+      OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
+      size_t temp_bytes = m->sort_temp.bytes;
+      OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, total, 0, 64, s));
+      const uint32_t replay_blocks = uint32_t((total + 127) / 128);
+      if (ndt_mode)
+      {
+        const bool tm = mode == OHMHIP_MODE_NDT_TM;
+        hipLaunchKernelGGL(k_replay_ndt, dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
+                           uint32_t(total), d_rays, d_intensities,
+                           static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
+                           static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]),
+                           static_cast<float *>(m->layers[OHMHIP_LID_COVARIANCE]),
+                           tm ? static_cast<float *>(m->layers[OHMHIP_LID_INTENSITY]) : nullptr,
+                           tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr);
+        if (info.n_touched)
+        {
+          hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
+                             batchScratch(m), 0u, m->d_miss_counts, m->d_hit_mask,
+                             static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]), 0,
+                             tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr);
+        }
+      }
+      else
+      {
+        hipLaunchKernelGGL(k_replay_tsdf, dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
+                           uint32_t(total), d_rays, static_cast<float *>(m->layers[OHMHIP_LID_TSDF]));
+        if (info.n_touched)
+        {
+          hipLaunchKernelGGL(k_apply_counts_tsdf, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
+                             batchScratch(m), m->d_miss_counts, static_cast<float *>(m->layers[OHMHIP_LID_TSDF]));
+        }
+      }
     }
     OHMHIP_CHECK(hipEventRecord(m->ev[4], s));
     OHMHIP_CHECK(hipGetLastError());
@@ -755,7 +891,6 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
                                      size_t *integrated)
 {
-  (void)d_intensities;
   (void)d_timestamps;
   if (integrated)
   {
@@ -774,7 +909,7 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
   {
     return OHMHIP_OK;
   }
-  if (n_rays >= (size_t(1) << kHitRayBits))
+  if (n_rays >= (size_t(1) << (kHitRayBits - 1)))
   {
     return OHMHIP_ERR_INVALID_ARG;  // split larger batches at the caller (29-bit ray index in the hit key)
   }
@@ -786,7 +921,30 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
     {
       return OHMHIP_ERR_INVALID_ARG;
     }
-    err = integrateOccupancy(m, d_rays, uint32_t(n_rays), ray_flags);
+    err = integrateBatch(m, d_rays, d_intensities, uint32_t(n_rays), ray_flags);
+    break;
+  case OHMHIP_MODE_NDT_OM:
+  case OHMHIP_MODE_NDT_TM:
+    if (!m->layers[OHMHIP_LID_OCCUPANCY] || !m->layers[OHMHIP_LID_MEAN] || !m->layers[OHMHIP_LID_COVARIANCE])
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+    if (m->config.mode == OHMHIP_MODE_NDT_TM && (!m->layers[OHMHIP_LID_INTENSITY] || !m->layers[OHMHIP_LID_HIT_MISS]))
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+    err = integrateBatch(m, d_rays, d_intensities, uint32_t(n_rays), ray_flags);
+    break;
+  case OHMHIP_MODE_TSDF:
+    if (!m->layers[OHMHIP_LID_TSDF])
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+    if (m->config.tsdf_dropoff > 0)
+    {
+      return OHMHIP_ERR_UNSUPPORTED;  // weight drop-off makes free-space updates value dependent
+    }
+    err = integrateBatch(m, d_rays, d_intensities, uint32_t(n_rays), ray_flags);
     break;
   default:
     break;
@@ -1162,6 +1320,21 @@ int ohmhip_map_write_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_x
                                   m->copy_stream));
     }
     OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
+  }
+  // NDT / TSDF keep a persistent per-voxel "ordered replay" mask derived from the stored state: rebuild it for the
+  // uploaded regions when the layer that defines it was written.
+  const bool ndt = m->config.mode == OHMHIP_MODE_NDT_OM || m->config.mode == OHMHIP_MODE_NDT_TM;
+  const bool tsdf = m->config.mode == OHMHIP_MODE_TSDF;
+  if ((ndt && layer_id == OHMHIP_LID_MEAN) || (tsdf && layer_id == OHMHIP_LID_TSDF))
+  {
+    for (size_t i = 0; i < count; ++i)
+    {
+      const uint32_t slot = m->region_slots[packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2])];
+      hipLaunchKernelGGL(k_rebuild_mask, dim3(4), dim3(256), 0, m->stream, m->mc, slot,
+                         ndt ? static_cast<const uint32_t *>(m->layers[OHMHIP_LID_MEAN]) : nullptr,
+                         tsdf ? static_cast<const float *>(m->layers[OHMHIP_LID_TSDF]) : nullptr, m->d_hit_mask);
+    }
+    OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   }
   return OHMHIP_OK;
 }

@@ -1,0 +1,371 @@
+// replay_kernels.h -- ordered per-voxel event replay for the NDT and TSDF mappers (gfx950).
+//
+// Voxels whose update depends on more than a miss COUNT (voxels which hold / receive samples for NDT; voxels near a
+// surface for TSDF) get every event of the batch as a 64-bit key [slot:20][voxel:15][ray:28][is_sample:1].  The keys
+// (sample keys from k_ray_bin + deferred visit keys from k_region_walk) are radix sorted, which groups them per voxel
+// in ray order -- exactly the order in which the single-threaded CPU mapper applies them -- and one lane per voxel
+// group replays the group sequentially with the CPU mapper's arithmetic.  Everything else in those layers is updated
+// from integer visit counts (k_apply_counts*), which are order independent.
+#ifndef OHMHIP_REPLAY_KERNELS_H
+#define OHMHIP_REPLAY_KERNELS_H
+
+#include "ndt_tsdf_device.h"
+#include "occupancy_kernels.h"
+
+namespace ohmhip
+{
+constexpr int kEvRayShift = 1;
+constexpr unsigned long long kEvRayMask = (1ull << kHitRayBits) - 1ull;
+
+__device__ inline void voxelCentreOf(const MapConst &mc, const RegionTable &rt, uint32_t slot, uint32_t vi,
+                                     double centre[3])
+{
+  int16_t rk[3];
+  unpackRegionKey(rt.slot_keys[slot], rk);
+  const int lx = int(vi % uint32_t(mc.dim[0]));
+  const int ly = int((vi / uint32_t(mc.dim[0])) % uint32_t(mc.dim[1]));
+  const int lz = int(vi / uint32_t(mc.dim[0] * mc.dim[1]));
+  centre[0] = voxelCentreAxis(mc, 0, rk[0], lx);
+  centre[1] = voxelCentreAxis(mc, 1, rk[1], ly);
+  centre[2] = voxelCentreAxis(mc, 2, rk[2], lz);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NDT: RayMapperNdt::integrateRays per-voxel semantics (ohm/RayMapperNdt.cpp:135-230 misses, :262-402 sample).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+  k_replay_ndt(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
+               const double *__restrict__ rays, const float *__restrict__ intensities, float *__restrict__ occupancy,
+               uint32_t *__restrict__ mean_layer, float *__restrict__ cov_layer, float *__restrict__ intensity_layer,
+               uint32_t *__restrict__ hit_miss_layer)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_events)
+  {
+    return;
+  }
+  const unsigned long long key = sorted[i];
+  if (key == kHitInvalid)
+  {
+    return;
+  }
+  const unsigned long long group = key >> kHitRayBits;
+  if (i > 0 && (sorted[i - 1] >> kHitRayBits) == group)
+  {
+    return;  // not the first event of its voxel
+  }
+  const uint32_t slot = uint32_t(key >> kHitSlotShift);
+  const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
+  const size_t gi = size_t(slot) * size_t(mc.region_voxels) + vi;
+
+  double centre_a[3];
+  voxelCentreOf(mc, rt, slot, vi, centre_a);
+  const D3 centre = d3(centre_a[0], centre_a[1], centre_a[2]);
+
+  float occ = occupancy[gi];
+  uint32_t mcoord = mean_layer[2 * gi];
+  uint32_t mcount = mean_layer[2 * gi + 1];
+  Cov6 cov;
+  cov.c0 = cov_layer[6 * gi + 0];
+  cov.c1 = cov_layer[6 * gi + 1];
+  cov.c2 = cov_layer[6 * gi + 2];
+  cov.c3 = cov_layer[6 * gi + 3];
+  cov.c4 = cov_layer[6 * gi + 4];
+  cov.c5 = cov_layer[6 * gi + 5];
+  float int_mean = 0, int_cov = 0;
+  uint32_t hm_hit = 0, hm_miss = 0;
+  if (hit_miss_layer)
+  {
+    int_mean = intensity_layer[2 * gi];
+    int_cov = intensity_layer[2 * gi + 1];
+    hm_hit = hit_miss_layer[2 * gi];
+    hm_miss = hit_miss_layer[2 * gi + 1];
+  }
+
+  for (uint32_t j = i; j < n_events; ++j)
+  {
+    const unsigned long long kj = sorted[j];
+    if ((kj >> kHitRayBits) != group)
+    {
+      break;
+    }
+    const uint32_t ray = uint32_t((kj & kEvRayMask) >> kEvRayShift);
+    const bool is_sample = (kj & 1ull) != 0;
+    double start[3], end[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+    {
+      start[a] = rays[size_t(ray) * 6 + a];
+      end[a] = rays[size_t(ray) * 6 + 3 + a];
+    }
+    bool clipped = false;
+    filterRay(mc, start, end, clipped);  // clip filter may move the end point used by the miss maths
+    const D3 sensor = d3(start[0], start[1], start[2]);
+    const D3 sample = d3(end[0], end[1], end[2]);
+    const D3 mean = subVoxelToLocal(mcoord, mc.resolution) + centre;
+    const float initial_value = occ;
+    if (!is_sample)
+    {
+      bool is_miss = false;
+      const float adjusted = calculateMissNdt(mc, cov, initial_value, is_miss, sensor, sample, mean, mcount);
+      hm_miss += is_miss ? 1u : 0u;
+      occ = occupancyAdjustDown(mc, initial_value, adjusted);
+    }
+    else
+    {
+      float adjusted = initial_value;
+      if (hit_miss_layer)
+      {
+        calculateHitMissUpdateOnHit(mc, cov, adjusted, hm_hit, hm_miss, sensor, sample, mean, mcount);
+        calculateIntensityUpdateOnHit(mc, int_mean, int_cov, adjusted, intensities ? intensities[ray] : 0.0f, mcount);
+      }
+      const bool reset_mean = calculateHitWithCovariance(mc, cov, adjusted, sample, mean, mcount);
+      occ = occupancyAdjustUp(mc, initial_value, adjusted);
+      mcount = (!reset_mean) ? mcount : 0;
+      mcoord = subVoxelUpdateD3(mcoord, mcount, sample - centre, mc.resolution);
+      ++mcount;
+    }
+  }
+
+  occupancy[gi] = occ;
+  mean_layer[2 * gi] = mcoord;
+  mean_layer[2 * gi + 1] = mcount;
+  cov_layer[6 * gi + 0] = cov.c0;
+  cov_layer[6 * gi + 1] = cov.c1;
+  cov_layer[6 * gi + 2] = cov.c2;
+  cov_layer[6 * gi + 3] = cov.c3;
+  cov_layer[6 * gi + 4] = cov.c4;
+  cov_layer[6 * gi + 5] = cov.c5;
+  if (hit_miss_layer)
+  {
+    intensity_layer[2 * gi] = int_mean;
+    intensity_layer[2 * gi + 1] = int_cov;
+    hit_miss_layer[2 * gi] = hm_hit;
+    hit_miss_layer[2 * gi + 1] = hm_miss;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TSDF: RayMapperTsdf::integrateRays per-voxel semantics (ohm/RayMapperTsdf.cpp:105-160).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+  k_replay_tsdf(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
+                const double *__restrict__ rays, float *__restrict__ tsdf_layer)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_events)
+  {
+    return;
+  }
+  const unsigned long long key = sorted[i];
+  if (key == kHitInvalid)
+  {
+    return;
+  }
+  const unsigned long long group = key >> kHitRayBits;
+  if (i > 0 && (sorted[i - 1] >> kHitRayBits) == group)
+  {
+    return;
+  }
+  const uint32_t slot = uint32_t(key >> kHitSlotShift);
+  const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
+  const size_t gi = size_t(slot) * size_t(mc.region_voxels) + vi;
+  double centre_a[3];
+  voxelCentreOf(mc, rt, slot, vi, centre_a);
+  const D3 centre = d3(centre_a[0], centre_a[1], centre_a[2]);
+  float weight = tsdf_layer[2 * gi];
+  float distance = tsdf_layer[2 * gi + 1];
+  for (uint32_t j = i; j < n_events; ++j)
+  {
+    const unsigned long long kj = sorted[j];
+    if ((kj >> kHitRayBits) != group)
+    {
+      break;
+    }
+    const uint32_t ray = uint32_t((kj & kEvRayMask) >> kEvRayShift);
+    // calculateTsdf takes the ORIGINAL (unfiltered) sensor / sample (ohm/RayMapperTsdf.cpp:163-164).
+    const D3 sensor = d3(rays[size_t(ray) * 6 + 0], rays[size_t(ray) * 6 + 1], rays[size_t(ray) * 6 + 2]);
+    const D3 sample = d3(rays[size_t(ray) * 6 + 3], rays[size_t(ray) * 6 + 4], rays[size_t(ray) * 6 + 5]);
+    const float sdf = tsdfComputeDistance(sensor, sample, centre);
+    tsdfUpdate(mc, sdf, weight, distance);
+  }
+  tsdf_layer[2 * gi] = weight;
+  tsdf_layer[2 * gi + 1] = distance;
+}
+
+/// TSDF: one block per touched region: voxels which only saw free-space visits this batch (count n, none flagged):
+/// weight = min(weight + n, max_weight) (n unit increments, exact for integer-valued floats), distance = truncation
+/// distance -- the fixed point of calculateTsdf for sdf >= truncation distance.
+__global__ void __launch_bounds__(256)
+  k_apply_counts_tsdf(MapConst mc, RegionTable rt, BatchScratch bs, uint32_t *__restrict__ miss_counts,
+                      float *__restrict__ tsdf_layer)
+{
+  const uint32_t h = bs.touched[blockIdx.x];
+  const uint32_t slot = rt.vals[h];
+  const size_t base = size_t(slot) * size_t(mc.region_voxels);
+  for (uint32_t vi = threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
+  {
+    const uint32_t n = miss_counts[base + vi];
+    if (n)
+    {
+      const float w = tsdf_layer[2 * (base + vi)];
+      const float wn = w + float(n);
+      tsdf_layer[2 * (base + vi)] = (mc.tsdf_max_weight < wn) ? mc.tsdf_max_weight : wn;
+      tsdf_layer[2 * (base + vi) + 1] = mc.tsdf_trunc;
+      miss_counts[base + vi] = 0;
+    }
+  }
+  if (threadIdx.x == 0)
+  {
+    bs.seg_count[h] = 0;
+    bs.seg_cursor[h] = 0;
+    bs.touched_flag[h] = 0;
+  }
+}
+
+/// Safety margin on the truncation distance used to classify a visit as "free space" (count only).  A visit with
+/// sdf >= kTsdfFreeMargin * trunc leaves a (weight, trunc) voxel at (min(weight + 1, max), trunc) exactly, including
+/// float rounding of (sdf + trunc * w) / (w + 1) for w <= 1e4 (needs > 2e-3 relative margin; 1 % is used).
+constexpr float kTsdfFreeMargin = 1.01f;
+
+/// TSDF pre-pass, one lane per ray: flag every voxel near the ray's end whose sdf is below the free-space margin.
+/// Those voxels (and, persistently, every voxel ever flagged) take the ordered replay path.
+__global__ void __launch_bounds__(256)
+  k_tsdf_flag(MapConst mc, RegionTable rt, const RayWalk *__restrict__ walks, const double *__restrict__ rays,
+              uint32_t n_rays, uint32_t *__restrict__ hit_mask)
+{
+  const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n_rays)
+  {
+    return;
+  }
+  const RayWalk rw = walks[ray];
+  if (!(rw.flags & kRwValid))
+  {
+    return;
+  }
+  double start[3], end[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    start[a] = rays[size_t(ray) * 6 + a];
+    end[a] = rays[size_t(ray) * 6 + 3 + a];
+  }
+  const D3 sensor = d3(start[0], start[1], start[2]);
+  const D3 sample = d3(end[0], end[1], end[2]);
+  bool clipped = false;
+  filterRay(mc, start, end, clipped);
+  const double dx = end[0] - start[0], dy = end[1] - start[1], dz = end[2] - start[2];
+  const double length = sqrt((dx * dx + dy * dy) + dz * dz);
+  // Any voxel left before ray parameter t_star has its centre's projection at least margin * trunc short of the
+  // sample (centre projection is within one voxel edge... of the voxel's ray interval; 1 voxel of slack is used).
+  const double t_star = length - (double(kTsdfFreeMargin) * double(mc.tsdf_trunc) + 2.0 * mc.resolution);
+  int s0 = 0, s1 = 0, s2 = 0;
+  if (t_star > 0)
+  {
+    // Steps strictly before t_star form a valid prefix of the walk (axis == 3 disables the tie rule).
+    s0 = stepsBefore(rw.init[0], rw.delta[0], rw.total[0], 0, 3, t_star);
+    s1 = stepsBefore(rw.init[1], rw.delta[1], rw.total[1], 1, 3, t_star);
+    s2 = stepsBefore(rw.init[2], rw.delta[2], rw.total[2], 2, 3, t_star);
+  }
+  const int d0 = rwDir(rw, 0), d1 = rwDir(rw, 1), d2 = rwDir(rw, 2);
+  int g0 = rw.g0[0] + d0 * s0, g1 = rw.g0[1] + d1 * s1, g2 = rw.g0[2] + d2 * s2;
+  int rem0 = rw.total[0] - s0, rem1 = rw.total[1] - s1, rem2 = rw.total[2] - s2;
+  const double inf = dInf();
+  double k0 = double(s0), k1 = double(s1), k2 = double(s2);
+  double t0 = rem0 ? ((s0 == 0) ? rw.init[0] : rw.init[0] + rw.delta[0] * k0) : inf;
+  double t1 = rem1 ? ((s1 == 0) ? rw.init[1] : rw.init[1] + rw.delta[1] * k1) : inf;
+  double t2 = rem2 ? ((s2 == 0) ? rw.init[2] : rw.init[2] + rw.delta[2] * k2) : inf;
+  uint64_t cached_key = 0;
+  uint32_t cached_slot = kSlotUnassigned;
+  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
+  while (true)
+  {
+    int r0, r1, r2, l0, l1, l2;
+    splitGlobal(g0, mc.dim[0], r0, l0);
+    splitGlobal(g1, mc.dim[1], r1, l1);
+    splitGlobal(g2, mc.dim[2], r2, l2);
+    const D3 centre = d3(voxelCentreAxis(mc, 0, r0, l0), voxelCentreAxis(mc, 1, r1, l1), voxelCentreAxis(mc, 2, r2, l2));
+    const float sdf = tsdfComputeDistance(sensor, sample, centre);
+    if (sdf < kTsdfFreeMargin * mc.tsdf_trunc)
+    {
+      const uint64_t rkey = packRegionKey(r0, r1, r2);
+      if (rkey != cached_key)
+      {
+        const uint32_t h = regionFind(rt, rkey);
+        cached_slot = (h != 0xffffffffu) ? rt.vals[h] : kSlotUnassigned;
+        cached_key = rkey;
+      }
+      if (cached_slot < rt.slot_capacity)
+      {
+        const uint32_t vi = uint32_t(l0 + l1 * mc.dim[0] + l2 * mc.dim[0] * mc.dim[1]);
+        atomicOr(&hit_mask[size_t(cached_slot) * mask_words + (vi >> 5)], 1u << (vi & 31));
+      }
+    }
+    if ((rem0 | rem1 | rem2) == 0)
+    {
+      break;
+    }
+    const bool c01 = t0 < t1;
+    const double t01 = c01 ? t0 : t1;
+    const bool c2 = t01 < t2;
+    if (!c2)
+    {
+      g2 += d2;
+      --rem2;
+      k2 += 1.0;
+      t2 = rem2 ? rw.init[2] + rw.delta[2] * k2 : inf;
+    }
+    else if (c01)
+    {
+      g0 += d0;
+      --rem0;
+      k0 += 1.0;
+      t0 = rem0 ? rw.init[0] + rw.delta[0] * k0 : inf;
+    }
+    else
+    {
+      g1 += d1;
+      --rem1;
+      k1 += 1.0;
+      t1 = rem1 ? rw.init[1] + rw.delta[1] * k1 : inf;
+    }
+  }
+}
+
+/// Rebuild the persistent "ordered replay" voxel mask of one region from its stored layers (after a CPU upload):
+/// NDT: voxels holding samples (mean.count > 0); TSDF: observed voxels whose distance is not the free-space value.
+__global__ void __launch_bounds__(256)
+  k_rebuild_mask(MapConst mc, uint32_t slot, const uint32_t *__restrict__ mean_layer,
+                 const float *__restrict__ tsdf_layer, uint32_t *__restrict__ hit_mask)
+{
+  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
+  const size_t base = size_t(slot) * size_t(mc.region_voxels);
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < mask_words; w += gridDim.x * blockDim.x)
+  {
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < 32; ++b)
+    {
+      const uint32_t vi = w * 32 + b;
+      if (vi < uint32_t(mc.region_voxels))
+      {
+        bool flag = false;
+        if (mean_layer)
+        {
+          flag = mean_layer[2 * (base + vi) + 1] > 0;
+        }
+        if (tsdf_layer)
+        {
+          const float wgt = tsdf_layer[2 * (base + vi)];
+          const float dist = tsdf_layer[2 * (base + vi) + 1];
+          flag = flag || (wgt != 0.0f && dist != mc.tsdf_trunc) || (wgt == 0.0f && dist != 0.0f);
+        }
+        bits |= flag ? (1u << b) : 0u;
+      }
+    }
+    hit_mask[size_t(slot) * mask_words + w] = bits;
+  }
+}
+}  // namespace ohmhip
+
+#endif  // OHMHIP_REPLAY_KERNELS_H

@@ -152,6 +152,36 @@ __device__ inline int stepsBefore(double init, double delta, int total, int b, i
   return lo;
 }
 
+/// Ray filter: ohm/RayFilter.cpp:12-58 (goodRayFilter / clipRayFilter).  May move `end` (clip).  Returns false for
+/// a rejected ray.
+__device__ inline bool filterRay(const MapConst &mc, const double start[3], double end[3], bool &clipped_end)
+{
+  clipped_end = false;
+  if (mc.filter_mode == OHMHIP_FILTER_NONE)
+  {
+    return true;
+  }
+  bool good = isfinite(start[0]) && isfinite(start[1]) && isfinite(start[2]) && isfinite(end[0]) && isfinite(end[1]) &&
+              isfinite(end[2]);
+  const double rx = end[0] - start[0];
+  const double ry = end[1] - start[1];
+  const double rz = end[2] - start[2];
+  const double len2 = (rx * rx + ry * ry) + rz * rz;
+  if (mc.filter_mode == OHMHIP_FILTER_GOOD)
+  {
+    good = good && (mc.filter_range <= 0 || len2 <= mc.filter_range * mc.filter_range);
+  }
+  else if (good && mc.filter_range > 0 && len2 > mc.filter_range * mc.filter_range)
+  {
+    const double len = sqrt(len2);
+    end[0] = start[0] + (rx / len) * mc.filter_range;
+    end[1] = start[1] + (ry / len) * mc.filter_range;
+    end[2] = start[2] + (rz / len) * mc.filter_range;
+    clipped_end = true;
+  }
+  return good;
+}
+
 /// Ray filter + key + line-walk set-up for one ray.  Mirrors, in order:
 ///   ohm/RayFilter.cpp:12-58 (goodRayFilter / clipRayFilter), ohm/LineWalk.h:112-129 (walkSegmentKeys),
 ///   ohm/LineWalkCompute.h:188-248 (walkInitRay) and :260-280 (walkCalculateSteps).
@@ -168,30 +198,9 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
   }
 
   bool clipped_end = false;
-  if (mc.filter_mode != OHMHIP_FILTER_NONE)
+  if (!filterRay(mc, start, end, clipped_end))
   {
-    bool good = isfinite(start[0]) && isfinite(start[1]) && isfinite(start[2]) && isfinite(end[0]) &&
-                isfinite(end[1]) && isfinite(end[2]);
-    const double rx = end[0] - start[0];
-    const double ry = end[1] - start[1];
-    const double rz = end[2] - start[2];
-    const double len2 = (rx * rx + ry * ry) + rz * rz;
-    if (mc.filter_mode == OHMHIP_FILTER_GOOD)
-    {
-      good = good && (mc.filter_range <= 0 || len2 <= mc.filter_range * mc.filter_range);
-    }
-    else if (good && mc.filter_range > 0 && len2 > mc.filter_range * mc.filter_range)
-    {
-      const double len = sqrt(len2);
-      end[0] = start[0] + (rx / len) * mc.filter_range;
-      end[1] = start[1] + (ry / len) * mc.filter_range;
-      end[2] = start[2] + (rz / len) * mc.filter_range;
-      clipped_end = true;
-    }
-    if (!good)
-    {
-      return;
-    }
+    return;
   }
 
   int r0[3], l0[3], r1[3], l1[3];

@@ -1,0 +1,112 @@
+"""-m gpu: HIP GpuNdtMap / GpuTsdfMap vs the CPU oracle (RayMapperNdt / RayMapperTsdf restatements) on identical
+rays.  Integer fields (mean coord/count, hit/miss counts) must be bit exact; float fields within 1e-5 relative
+(north_star bar; NDT uses exp/log whose device and host libm may differ in the last bit)."""
+import numpy as np
+import pytest
+
+import ohm_amd
+from ohm_amd import GpuNdtMap, GpuTsdfMap, NdtMode, OccupancyMap, synth
+
+from parity import assert_parity, compare_maps, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ndt(rays, resolution=0.2, batch=None, mode=NdtMode.kOccupancy, intensities=None, flags=0):
+    map_ = OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+    gm = GpuNdtMap(map_, ndt_mode=mode)
+    om = make_oracle(map_)
+    om.set_ndt(sensor_noise=gm.sensor_noise, sample_threshold=gm.sample_threshold,
+               adaptation_rate=gm.adaptation_rate, reinit_threshold=gm.reinitialise_covariance_threshold,
+               reinit_count=gm.reinitialise_covariance_point_count, ndt_tm=(mode == NdtMode.kTraversability))
+    n_points = rays.shape[0]
+    step = n_points if batch is None else 2 * batch
+    for i in range(0, n_points, step):
+        chunk = rays[i:i + step]
+        ints = None if intensities is None else intensities[i // 2:(i + step) // 2]
+        assert gm.integrateRays(chunk, intensities=ints, ray_update_flags=flags) == chunk.shape[0]
+        om.integrate_ndt(chunk, intensities=ints, flags=int(flags))
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, list(map_.layers), rel=1e-5)
+    return stats, gm, om
+
+
+def test_ndt_room_single_batch(gpu):
+    rays = synth.rays_c2(n=40000)
+    stats, gm, om = run_ndt(rays)
+    assert_parity(stats)
+    assert gm.stats()["voxel_visits"] == om.visit_count()
+
+
+def test_ndt_room_batched_many_samples_per_voxel(gpu):
+    # several revolutions over the same walls in batches: covariances mature (count >> threshold), NDT misses active
+    rays = np.concatenate([synth.rays_c2(n=20000, seed=100 + k) for k in range(4)])
+    stats, gm, om = run_ndt(rays, batch=10000)
+    assert_parity(stats)
+
+
+def test_ndt_random_rays_small_voxels(gpu):
+    rays = synth.random_rays(6000, extent=4.0, seed=21, origin_spread=1.0)
+    stats, gm, om = run_ndt(rays, resolution=0.5, batch=2048)
+    assert_parity(stats)
+
+
+def test_ndt_tm(gpu):
+    rays = np.concatenate([synth.rays_c2(n=15000, seed=200 + k) for k in range(3)])
+    ints = (synth.uniform01(5, np.arange(rays.shape[0] // 2, dtype=np.uint64), 0) * 100).astype(np.float32)
+    stats, gm, om = run_ndt(rays, batch=15000, mode=NdtMode.kTraversability, intensities=ints)
+    assert_parity(stats)
+
+
+def run_tsdf(rays, resolution=0.1, batch=None, trunc=0.1, **opts):
+    map_ = OccupancyMap(resolution, (32, 32, 32), layers=("tsdf",))
+    gm = GpuTsdfMap(map_, default_truncation_distance=trunc, **opts)
+    om = make_oracle(map_)
+    om.set_tsdf(max_weight=gm.tsdf_options[0], trunc=gm.tsdf_options[1], dropoff=gm.tsdf_options[2],
+                sparsity=gm.tsdf_options[3])
+    n_points = rays.shape[0]
+    step = n_points if batch is None else 2 * batch
+    for i in range(0, n_points, step):
+        chunk = rays[i:i + step]
+        assert gm.integrateRays(chunk) == chunk.shape[0]
+        om.integrate_tsdf(chunk)
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True)
+    return stats, gm, om
+
+
+def test_tsdf_room(gpu):
+    rays = synth.rays_c2(n=30000)
+    stats, gm, om = run_tsdf(rays, resolution=0.1)
+    assert_parity(stats)
+    assert gm.stats()["voxel_visits"] == om.visit_count()
+
+
+def test_tsdf_batched_small_voxels(gpu):
+    rays = np.concatenate([synth.rays_c2(n=8000, seed=300 + k) for k in range(3)])
+    stats, gm, om = run_tsdf(rays, resolution=0.05, batch=8000)
+    assert_parity(stats)
+
+
+def test_tsdf_reference_test_rays(gpu):
+    # tests/ohmtest/TsdfTests.cpp:18-137 ray set, large and small truncation distance, integrated twice
+    dirs = [(1, 0, 0), (-1, 0, 0), (1, 1, 0), (-1, 1, 0), (1, 0, 0), (1, -1, 0), (-1, 0, 1), (1, 1, 1), (-1, 1, 1),
+            (1, 0, 1), (1, -1, 1), (-1, 0, 1), (1, 1, -1), (-1, 1, -1), (1, 0, -1), (1, -1, -1)]
+    rays = np.zeros((2 * len(dirs), 3))
+    rays[1::2] = dirs
+    for trunc in (10.0, 0.1):
+        stats, gm, om = run_tsdf(np.concatenate([rays, rays]), trunc=trunc, batch=len(dirs))
+        assert_parity(stats)
+
+
+def test_tsdf_sparsity_and_weight_cap(gpu):
+    rays = np.concatenate([synth.rays_c2(n=4000, seed=400)] * 6)
+    stats, gm, om = run_tsdf(rays, batch=4000, max_weight=4.0, sparsity_compensation_factor=2.5)
+    assert_parity(stats)
+
+
+def test_tsdf_dropoff_is_reported_unsupported(gpu):
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("tsdf",))
+    gm = GpuTsdfMap(map_, dropoff_epsilon=0.05)
+    with pytest.raises(ohm_amd.OhmHipError):
+        gm.integrateRays(synth.rays_c2(n=64))
