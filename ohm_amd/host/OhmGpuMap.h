@@ -1,0 +1,470 @@
+// OhmGpuMap.h -- C++14 host mirror of the reference's ray-integration interface over the ohmhip C ABI.
+//
+//   ohm::OccupancyMap (ohm/OccupancyMap.h:291)  parameters + MapChunk / VoxelBlock layout host storage
+//   ohm::RayMapper    (ohm/RayMapper.h:22-65)
+//   ohm::GpuMap       (ohmgpu/GpuMap.h:143-384)   ohm::GpuNdtMap (ohmgpu/GpuNdtMap.h:63-132)
+//   ohm::GpuTsdfMap   (ohmgpu/GpuTsdfMap.h:37-94)
+//
+// Same names, argument meaning and error behaviour as the reference for this path: integrateRays() takes
+// `element_count` POINTS (2 per ray) and returns the number integrated (0 on failure); construction throws
+// gputil::ApiException when device memory cannot be allocated; syncVoxels() is the fence that copies modified regions
+// back into MapChunk::voxel_blocks-equivalent host memory (index = x + y*dx + z*dx*dy, ohm/MapChunk.h:33-50).
+// Only what the path needs is mirrored: this is not a re-implementation of ohm::OccupancyMap.
+//
+// glm: callers which have glm pass glm::dvec3 arrays (3 packed doubles); this header does not need glm.
+#ifndef OHMHIP_OHMGPUMAP_H
+#define OHMHIP_OHMGPUMAP_H
+
+#include "gputil_hip.h"
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace ohm
+{
+/// ohm/RayFlag.h:16-60
+enum RayFlag : unsigned
+{
+  kRfDefault = 0,
+  kRfEndPointAsFree = (1u << 0u),
+  kRfStopOnFirstOccupied = (1u << 1u),
+  kRfExcludeOrigin = (1u << 2u),
+  kRfExcludeSample = (1u << 3u),
+  kRfExcludeRay = (1u << 4u),
+  kRfExcludeUnobserved = (1u << 5u),
+  kRfExcludeFree = (1u << 6u),
+  kRfExcludeOccupied = (1u << 7u),
+  kRfReverseWalk = (1u << 8u)
+};
+
+/// ohm/NdtMode.h
+enum class NdtMode
+{
+  kNone = 0,
+  kOccupancy,
+  kTraversability
+};
+
+/// Plain 3 x double point, layout compatible with glm::dvec3.
+struct dvec3
+{
+  double x, y, z;
+};
+
+/// ohm/MapProbability.h:20-36 (float)
+inline float probabilityToValue(float probability) { return std::log(probability / (1.0f - probability)); }
+inline float valueToProbability(float value)
+{
+  return (value == -INFINITY) ? 0.0f : 1.0f - (1.0f / (1.0f + std::exp(value)));
+}
+
+/// One region's voxel memory: one contiguous block per layer (ohm/MapChunk.h:155, ohm/VoxelBlock.h:48).
+struct MapChunk
+{
+  std::array<int16_t, 3> region{ { 0, 0, 0 } };
+  std::vector<std::vector<uint8_t>> voxel_blocks;  ///< indexed by layer id (ohmhip_layer_id); empty when absent
+};
+
+/// Host-side map description and chunk store.
+class OccupancyMap
+{
+public:
+  explicit OccupancyMap(double resolution = 1.0, int region_dim_x = 32, int region_dim_y = 32, int region_dim_z = 32)
+    : resolution_(resolution)
+  {
+    region_dim_[0] = region_dim_x > 0 ? region_dim_x : 32;  // ohm/OccupancyMap.h:24-26
+    region_dim_[1] = region_dim_y > 0 ? region_dim_y : 32;
+    region_dim_[2] = region_dim_z > 0 ? region_dim_z : 32;
+    // ohm/OccupancyMap.cpp:205-213
+    min_voxel_value_ = -2.0f;
+    max_voxel_value_ = 3.511f;
+    hit_value_ = probabilityToValue(0.9f);
+    miss_value_ = probabilityToValue(0.45f);
+    threshold_value_ = probabilityToValue(0.5f);
+    layers_ = OHMHIP_LAYER_BIT(OHMHIP_LID_OCCUPANCY);
+  }
+
+  double resolution() const { return resolution_; }
+  const int *regionVoxelDimensions() const { return region_dim_; }
+  size_t regionVoxelVolume() const { return size_t(region_dim_[0]) * region_dim_[1] * region_dim_[2]; }
+  void setOrigin(double x, double y, double z)
+  {
+    origin_[0] = x;
+    origin_[1] = y;
+    origin_[2] = z;
+  }
+  const double *origin() const { return origin_; }
+  void setHitProbability(float p) { hit_value_ = probabilityToValue(p); }
+  void setMissProbability(float p) { miss_value_ = probabilityToValue(p); }
+  void setOccupancyThresholdProbability(float p) { threshold_value_ = probabilityToValue(p); }
+  float hitValue() const { return hit_value_; }
+  float missValue() const { return miss_value_; }
+  float missProbability() const { return valueToProbability(miss_value_); }
+  float occupancyThresholdValue() const { return threshold_value_; }
+  float minVoxelValue() const { return min_voxel_value_; }
+  float maxVoxelValue() const { return max_voxel_value_; }
+  void setMinVoxelValue(float v) { min_voxel_value_ = v; }
+  void setMaxVoxelValue(float v) { max_voxel_value_ = v; }
+  bool saturateAtMinValue() const { return saturate_min_; }
+  bool saturateAtMaxValue() const { return saturate_max_; }
+  void setSaturateAtMinValue(bool s) { saturate_min_ = s; }
+  void setSaturateAtMaxValue(bool s) { saturate_max_ = s; }
+  /// Ray filter: 0 none, 1 goodRayFilter(range), 2 clipRayFilter(range) (ohm/RayFilter.cpp:12-58).
+  void setRayFilter(int mode, double range)
+  {
+    ray_filter_ = mode;
+    ray_filter_range_ = range;
+  }
+  int rayFilterMode() const { return ray_filter_; }
+  double rayFilterRange() const { return ray_filter_range_; }
+  unsigned layers() const { return layers_; }
+  void addLayer(int layer_id) { layers_ |= OHMHIP_LAYER_BIT(layer_id); }
+  bool hasLayer(int layer_id) const { return (layers_ & OHMHIP_LAYER_BIT(layer_id)) != 0; }
+
+  using ChunkMap = std::map<std::array<int16_t, 3>, MapChunk>;
+  ChunkMap &chunks() { return chunks_; }
+  const ChunkMap &chunks() const { return chunks_; }
+  size_t regionCount() const { return chunks_.size(); }
+
+  /// OccupancyMap::region(key, allow_create) restricted to what syncVoxels() needs.
+  MapChunk &region(const std::array<int16_t, 3> &key)
+  {
+    MapChunk &chunk = chunks_[key];
+    chunk.region = key;
+    if (chunk.voxel_blocks.size() < size_t(OHMHIP_LID_COUNT))
+    {
+      chunk.voxel_blocks.resize(OHMHIP_LID_COUNT);
+    }
+    return chunk;
+  }
+
+private:
+  double resolution_;
+  int region_dim_[3];
+  double origin_[3] = { 0, 0, 0 };
+  float hit_value_, miss_value_, threshold_value_, min_voxel_value_, max_voxel_value_;
+  bool saturate_min_ = false, saturate_max_ = false;
+  int ray_filter_ = OHMHIP_FILTER_GOOD;  // ohm/OccupancyMap.cpp:215-218
+  double ray_filter_range_ = 1e10;
+  unsigned layers_;
+  ChunkMap chunks_;
+};
+
+/// ohm/RayMapper.h:22-65
+class RayMapper
+{
+public:
+  virtual ~RayMapper() = default;
+  virtual bool valid() const = 0;
+  virtual size_t integrateRays(const dvec3 *rays, size_t element_count, const float *intensities,
+                               const double *timestamps, unsigned ray_update_flags) = 0;
+  size_t integrateRays(const dvec3 *rays, size_t element_count)
+  {
+    return integrateRays(rays, element_count, nullptr, nullptr, kRfDefault);
+  }
+};
+
+/// ohm::GpuMap (ohmgpu/GpuMap.h:143-384)
+class GpuMap : public RayMapper
+{
+public:
+  /// @param expected_element_count accepted for source compatibility; batch buffers grow on demand.
+  /// @param gpu_mem_size device memory budget for the resident map, 0 => default.
+  explicit GpuMap(OccupancyMap *map, bool borrowed_map = true, unsigned expected_element_count = 2048,
+                  size_t gpu_mem_size = 0)
+    : GpuMap(map, borrowed_map, expected_element_count, gpu_mem_size, OHMHIP_MODE_OCCUPANCY, nullptr)
+  {}
+
+  ~GpuMap() override
+  {
+    if (handle_)
+    {
+      ohmhip_map_destroy(handle_);
+    }
+    if (!borrowed_map_)
+    {
+      delete map_;
+    }
+  }
+  GpuMap(const GpuMap &) = delete;
+  GpuMap &operator=(const GpuMap &) = delete;
+
+  bool gpuOk() const { return handle_ != nullptr; }
+  bool valid() const override { return gpuOk(); }
+  OccupancyMap &map() { return *map_; }
+  const OccupancyMap &map() const { return *map_; }
+  bool borrowedMap() const { return borrowed_map_; }
+  float hitValue() const { return map_->hitValue(); }
+  float missValue() const { return map_->missValue(); }
+  /// ohmgpu/GpuMap.h:246-262.  Stored only: this backend bins rays per region, it does not need segmentation.
+  void setRaySegmentLength(double length) { ray_segment_length_ = length; }
+  double raySegmentLength() const { return ray_segment_length_; }
+
+  using RayMapper::integrateRays;
+  /// ohmgpu/GpuMap.cpp:416: returns points integrated, 0 on failure (gpuOk() false, device error).
+  size_t integrateRays(const dvec3 *rays, size_t element_count, const float *intensities, const double *timestamps,
+                       unsigned ray_update_flags) override
+  {
+    if (!gpuOk() || !rays || element_count < 2)
+    {
+      return 0;
+    }
+    size_t integrated = 0;
+    last_status_ = ohmhip_map_integrate_rays(handle_, reinterpret_cast<const double *>(rays), element_count,
+                                             intensities, timestamps, ray_update_flags, &integrated);
+    return (last_status_ == OHMHIP_OK) ? integrated : 0;
+  }
+  /// glm-compatible overload: any 3-double point type.
+  template <typename Vec3>
+  size_t integrateRays(const Vec3 *rays, size_t element_count, const float *intensities = nullptr,
+                       const double *timestamps = nullptr, unsigned ray_update_flags = kRfDefault)
+  {
+    static_assert(sizeof(Vec3) == 3 * sizeof(double), "rays must be packed double triples (glm::dvec3)");
+    return integrateRays(reinterpret_cast<const dvec3 *>(rays), element_count, intensities, timestamps,
+                         ray_update_flags);
+  }
+  int lastStatus() const { return last_status_; }
+
+  /// ohmgpu/GpuMap.cpp:308-324 -> GpuLayerCache::syncToMainMemory: fence, then copy regions modified on the device
+  /// into the host chunks (every enabled layer).
+  void syncVoxels()
+  {
+    if (!gpuOk())
+    {
+      return;
+    }
+    size_t count = 0;
+    OHMHIP_GPUAPICHECK(ohmhip_map_dirty_regions(handle_, nullptr, 0, &count));
+    std::vector<int16_t> keys(3 * count);
+    if (count)
+    {
+      OHMHIP_GPUAPICHECK(ohmhip_map_dirty_regions(handle_, keys.data(), count, &count));
+    }
+    const size_t voxels = map_->regionVoxelVolume();
+    for (int layer = 0; layer < OHMHIP_LID_COUNT; ++layer)
+    {
+      if (!map_->hasLayer(layer) || count == 0)
+      {
+        continue;
+      }
+      std::vector<void *> dsts(count);
+      for (size_t i = 0; i < count; ++i)
+      {
+        MapChunk &chunk = map_->region({ { keys[3 * i], keys[3 * i + 1], keys[3 * i + 2] } });
+        chunk.voxel_blocks[layer].resize(voxels * ohmhip_layer_voxel_bytes(layer));
+        dsts[i] = chunk.voxel_blocks[layer].data();
+      }
+      OHMHIP_GPUAPICHECK(ohmhip_map_read_regions(handle_, layer, keys.data(), count, dsts.data()));
+    }
+    OHMHIP_GPUAPICHECK(ohmhip_map_clear_dirty(handle_));
+    OHMHIP_GPUAPICHECK(ohmhip_map_sync(handle_));
+  }
+
+  ohmhip_batch_stats lastBatchStats() const
+  {
+    ohmhip_batch_stats st{};
+    ohmhip_map_last_stats(handle_, &st);
+    return st;
+  }
+  ohmhip_map_t handle() const { return handle_; }
+
+protected:
+  using ConfigHook = void (*)(ohmhip_map_config &, void *);
+  GpuMap(OccupancyMap *map, bool borrowed_map, unsigned /*expected_element_count*/, size_t gpu_mem_size, int mode,
+         void *hook_data, ConfigHook hook = nullptr)
+    : map_(map)
+    , borrowed_map_(borrowed_map)
+  {
+    ohmhip_map_config cfg;
+    ohmhip_map_config_default(&cfg);
+    cfg.resolution = map->resolution();
+    for (int a = 0; a < 3; ++a)
+    {
+      cfg.region_dim[a] = map->regionVoxelDimensions()[a];
+      cfg.origin[a] = map->origin()[a];
+    }
+    cfg.mode = mode;
+    cfg.hit_value = map->hitValue();
+    cfg.miss_value = map->missValue();
+    cfg.threshold_value = map->occupancyThresholdValue();
+    cfg.min_value = map->minVoxelValue();
+    cfg.max_value = map->maxVoxelValue();
+    cfg.saturate_at_min = map->saturateAtMinValue();
+    cfg.saturate_at_max = map->saturateAtMaxValue();
+    cfg.ray_filter = map->rayFilterMode();
+    cfg.ray_filter_range = map->rayFilterRange();
+    cfg.gpu_mem_size = gpu_mem_size;
+    if (hook)
+    {
+      hook(cfg, hook_data);
+    }
+    cfg.layers = map->layers();
+    // gputil::Exception on allocation failure from the ctor (ohmgpu/GpuMap.h:53-54,159-160).
+    OHMHIP_GPUAPICHECK(ohmhip_map_create(&handle_, &cfg));
+    uploadExisting();
+  }
+
+  /// gpumap::enableGpu + GpuLayerCache::upload for chunks the CPU map already holds.
+  void uploadExisting()
+  {
+    if (map_->chunks().empty())
+    {
+      return;
+    }
+    std::vector<int16_t> keys;
+    for (const auto &entry : map_->chunks())
+    {
+      keys.insert(keys.end(), entry.first.begin(), entry.first.end());
+    }
+    const size_t count = keys.size() / 3;
+    for (int layer = 0; layer < OHMHIP_LID_COUNT; ++layer)
+    {
+      if (!map_->hasLayer(layer))
+      {
+        continue;
+      }
+      std::vector<const void *> srcs;
+      std::vector<int16_t> layer_keys;
+      for (const auto &entry : map_->chunks())
+      {
+        if (entry.second.voxel_blocks.size() > size_t(layer) && !entry.second.voxel_blocks[layer].empty())
+        {
+          srcs.push_back(entry.second.voxel_blocks[layer].data());
+          layer_keys.insert(layer_keys.end(), entry.first.begin(), entry.first.end());
+        }
+      }
+      if (!srcs.empty())
+      {
+        OHMHIP_GPUAPICHECK(ohmhip_map_write_regions(handle_, layer, layer_keys.data(), srcs.size(), srcs.data()));
+      }
+    }
+    (void)count;
+  }
+
+  OccupancyMap *map_ = nullptr;
+  bool borrowed_map_ = true;
+  ohmhip_map_t handle_ = nullptr;
+  double ray_segment_length_ = 0;
+  int last_status_ = OHMHIP_OK;
+};
+
+/// ohm::GpuNdtMap (ohmgpu/GpuNdtMap.h:63-132).  NDT parameters default as in ohm/private/NdtMapDetail.h:20-45 and may
+/// be changed BEFORE construction through NdtParams.
+struct NdtParams
+{
+  float sensor_noise = 0.05f;
+  unsigned sample_threshold = 3;
+  float adaptation_rate = -1.0f;  ///< <= 0: derived from the map's miss probability (ohm/NdtMap.cpp:31-36)
+  float reinitialise_covariance_threshold = probabilityToValue(0.2f);
+  unsigned reinitialise_covariance_point_count = 100;
+  float initial_intensity_covariance = 1.0f;
+};
+
+class GpuNdtMap : public GpuMap
+{
+public:
+  GpuNdtMap(OccupancyMap *map, bool borrowed_map = true, unsigned expected_element_count = 2048,
+            size_t gpu_mem_size = 0, NdtMode ndt_mode = NdtMode::kOccupancy, const NdtParams &params = NdtParams())
+    : GpuMap(prepare(map, ndt_mode), borrowed_map, expected_element_count, gpu_mem_size,
+             ndt_mode == NdtMode::kTraversability ? OHMHIP_MODE_NDT_TM : OHMHIP_MODE_NDT_OM,
+             const_cast<NdtParams *>(&params), &GpuNdtMap::fill)
+    , params_(params)
+    , mode_(ndt_mode)
+  {}
+  NdtMode mode() const { return mode_; }
+  float sensorNoise() const { return params_.sensor_noise; }
+
+  /// ohm/NdtMap.h:146-149
+  static float ndtAdaptationRateFromMissProbability(float miss_probability, float scale = 2.0f)
+  {
+    return std::max(0.0f, std::min(scale * (1.0f - 2.0f * miss_probability), 1.0f));
+  }
+
+private:
+  static OccupancyMap *prepare(OccupancyMap *map, NdtMode mode)
+  {
+    // NdtMap::enableNdt (ohm/NdtMap.cpp:194-213): voxel mean + covariance (+ intensity, hit/miss for NDT-TM).
+    map->addLayer(OHMHIP_LID_OCCUPANCY);
+    map->addLayer(OHMHIP_LID_MEAN);
+    map->addLayer(OHMHIP_LID_COVARIANCE);
+    if (mode == NdtMode::kTraversability)
+    {
+      map->addLayer(OHMHIP_LID_INTENSITY);
+      map->addLayer(OHMHIP_LID_HIT_MISS);
+    }
+    return map;
+  }
+  static void fill(ohmhip_map_config &cfg, void *data)
+  {
+    const NdtParams &p = *static_cast<const NdtParams *>(data);
+    cfg.ndt_sensor_noise = p.sensor_noise;
+    cfg.ndt_sample_threshold = p.sample_threshold;
+    // cfg.miss_value is already the map's; derive the rate exactly as NdtMap's ctor does.
+    cfg.ndt_adaptation_rate = (p.adaptation_rate > 0) ?
+                                p.adaptation_rate :
+                                ndtAdaptationRateFromMissProbability(valueToProbability(cfg.miss_value));
+    cfg.ndt_reinit_threshold = p.reinitialise_covariance_threshold;
+    cfg.ndt_reinit_count = p.reinitialise_covariance_point_count;
+    cfg.ndt_initial_intensity_cov = p.initial_intensity_covariance;
+  }
+  NdtParams params_;
+  NdtMode mode_;
+};
+
+/// ohm/VoxelTsdf.h:27-37
+struct TsdfOptions
+{
+  float max_weight = 1e4f;
+  float default_truncation_distance = 0.1f;
+  float dropoff_epsilon = 0.0f;
+  float sparsity_compensation_factor = 1.0f;
+};
+
+/// ohm::GpuTsdfMap (ohmgpu/GpuTsdfMap.h:37-94)
+class GpuTsdfMap : public GpuMap
+{
+public:
+  GpuTsdfMap(OccupancyMap *map, bool borrowed_map = true, unsigned expected_element_count = 2048,
+             size_t gpu_mem_size = 0, const TsdfOptions &options = TsdfOptions())
+    : GpuMap(prepare(map), borrowed_map, expected_element_count, gpu_mem_size, OHMHIP_MODE_TSDF,
+             const_cast<TsdfOptions *>(&options), &GpuTsdfMap::fill)
+    , options_(options)
+  {}
+  const TsdfOptions &tsdfOptions() const { return options_; }
+  float maxWeight() const { return options_.max_weight; }
+  float defaultTruncationDistance() const { return options_.default_truncation_distance; }
+
+private:
+  static OccupancyMap *prepare(OccupancyMap *map)
+  {
+    map->addLayer(OHMHIP_LID_TSDF);
+    return map;
+  }
+  static void fill(ohmhip_map_config &cfg, void *data)
+  {
+    const TsdfOptions &o = *static_cast<const TsdfOptions *>(data);
+    cfg.tsdf_max_weight = o.max_weight;
+    cfg.tsdf_trunc = o.default_truncation_distance;
+    cfg.tsdf_dropoff = o.dropoff_epsilon;
+    cfg.tsdf_sparsity = o.sparsity_compensation_factor;
+  }
+  TsdfOptions options_;
+};
+
+/// ohm::configureGpu / gpuDevice (ohmgpu/OhmGpu.h:40-66): select the process-wide device.
+inline int configureGpu(int device_index = 0)
+{
+  int count = 0;
+  if (ohmhip_device_count(&count) != OHMHIP_OK || device_index >= count)
+  {
+    return 1;
+  }
+  return ohmhip_device_select(device_index) == OHMHIP_OK ? 0 : 1;
+}
+}  // namespace ohm
+
+#endif  // OHMHIP_OHMGPUMAP_H

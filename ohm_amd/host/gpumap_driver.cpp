@@ -1,0 +1,117 @@
+// gpumap_driver.cpp -- C++14 test driver for the host mirror (ohm::GpuMap / GpuNdtMap / GpuTsdfMap over the C ABI).
+// Reads a binary ray file, integrates it in batches exactly like the reference's gpuMapTest() harness
+// (tests/ohmtestgpu/GpuMapTest.cpp:68-205), syncs, and dumps every region layer for the Python parity test to check
+// against the CPU oracle.  Links libohmhip.so only; built with plain g++ (no hipcc, no glm).
+//
+//   gpumap_driver <mode: occ|occmean|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>
+//   rays.bin: u64 n_points, then n_points * 3 doubles.  out.bin: u64 regions, per region i16[3] key, then per enabled
+//   layer (ascending id): u32 layer id, u64 bytes, payload.
+#include "OhmGpuMap.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+int main(int argc, char **argv)
+{
+  if (argc < 6)
+  {
+    std::fprintf(stderr, "usage: %s <occ|occmean|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>\n", argv[0]);
+    return 2;
+  }
+  const std::string mode = argv[1];
+  const double resolution = std::atof(argv[2]);
+  const size_t batch_rays = size_t(std::atoll(argv[3]));
+  try
+  {
+    if (ohm::configureGpu(0) != 0)
+    {
+      std::fprintf(stderr, "no HIP device\n");
+      return 3;
+    }
+    FILE *in = std::fopen(argv[4], "rb");
+    if (!in)
+    {
+      return 4;
+    }
+    uint64_t n_points = 0;
+    if (std::fread(&n_points, sizeof(n_points), 1, in) != 1)
+    {
+      return 4;
+    }
+    std::vector<ohm::dvec3> rays(n_points);
+    if (std::fread(rays.data(), sizeof(ohm::dvec3), n_points, in) != n_points)
+    {
+      return 4;
+    }
+    std::fclose(in);
+
+    ohm::OccupancyMap map(resolution);
+    std::unique_ptr<ohm::GpuMap> gpu_map;
+    if (mode == "occ" || mode == "occmean")
+    {
+      if (mode == "occmean")
+      {
+        map.addLayer(OHMHIP_LID_MEAN);
+      }
+      gpu_map.reset(new ohm::GpuMap(&map, true, unsigned(batch_rays * 2)));
+    }
+    else if (mode == "ndt")
+    {
+      gpu_map.reset(new ohm::GpuNdtMap(&map, true, unsigned(batch_rays * 2)));
+    }
+    else if (mode == "tsdf")
+    {
+      gpu_map.reset(new ohm::GpuTsdfMap(&map, true, unsigned(batch_rays * 2)));
+    }
+    else
+    {
+      return 2;
+    }
+    if (!gpu_map->gpuOk())
+    {
+      return 5;
+    }
+    const size_t batch_points = batch_rays ? batch_rays * 2 : size_t(n_points);
+    size_t total = 0;
+    for (size_t i = 0; i < n_points; i += batch_points)
+    {
+      const size_t count = std::min<size_t>(batch_points, n_points - i);
+      total += gpu_map->integrateRays(rays.data() + i, count, nullptr, nullptr, ohm::kRfDefault);
+    }
+    gpu_map->syncVoxels();
+    std::printf("integrated %zu of %llu points, %zu regions\n", total, (unsigned long long)n_points, map.regionCount());
+
+    FILE *out = std::fopen(argv[5], "wb");
+    if (!out)
+    {
+      return 6;
+    }
+    const uint64_t regions = map.regionCount();
+    std::fwrite(&regions, sizeof(regions), 1, out);
+    for (const auto &entry : map.chunks())
+    {
+      std::fwrite(entry.first.data(), sizeof(int16_t), 3, out);
+      for (uint32_t layer = 0; layer < uint32_t(OHMHIP_LID_COUNT); ++layer)
+      {
+        if (!map.hasLayer(int(layer)))
+        {
+          continue;
+        }
+        const auto &block = entry.second.voxel_blocks[layer];
+        const uint64_t bytes = block.size();
+        std::fwrite(&layer, sizeof(layer), 1, out);
+        std::fwrite(&bytes, sizeof(bytes), 1, out);
+        std::fwrite(block.data(), 1, bytes, out);
+      }
+    }
+    std::fclose(out);
+    return (total == n_points) ? 0 : 7;
+  }
+  catch (const gputil::ApiException &e)
+  {
+    std::fprintf(stderr, "gputil::ApiException: %s\n", e.what());
+    return 10;
+  }
+}

@@ -1,0 +1,72 @@
+"""-m gpu: device plumbing of the C ABI (the gputil replacement), after tests/gputiltest/GpuBufferTest.cpp:22-590
+(ReadWriteCopy, Pinned, Allocation) and GpuDevice.Enumerate."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ohm_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_enumerate(gpu):
+    assert "gfx950" in gpu["arch"]
+    assert gpu["compute_units"] == 256
+    assert gpu["lds_bytes_per_block"] >= 160 * 1024
+
+
+def test_buffer_read_write_and_events(gpu):
+    n = 1 << 20
+    src = ((np.arange(n, dtype=np.uint64) * 2654435761) & 0xFFFFFFFF).astype(np.uint32)
+    buf = L._vp()
+    L.check(L.lib.ohmhip_buffer_create(C.byref(buf), src.nbytes, 3))
+    stream, ev0, ev1 = L._vp(), L._vp(), L._vp()
+    L.check(L.lib.ohmhip_stream_create(C.byref(stream)))
+    L.check(L.lib.ohmhip_event_create(C.byref(ev0)))
+    L.check(L.lib.ohmhip_event_create(C.byref(ev1)))
+    L.check(L.lib.ohmhip_event_record(ev0, stream))
+    # async write with completion event, then async read blocked on it
+    L.check(L.lib.ohmhip_buffer_write(buf, src.ctypes.data, src.nbytes, 0, stream, None, ev1))
+    dst = np.zeros_like(src)
+    L.check(L.lib.ohmhip_buffer_read(buf, dst.ctypes.data, dst.nbytes, 0, stream, ev1, None))
+    L.check(L.lib.ohmhip_stream_finish(stream))
+    assert np.array_equal(src, dst)
+    done = C.c_int(0)
+    L.check(L.lib.ohmhip_event_is_complete(ev1, C.byref(done)))
+    assert done.value == 1
+    ms = C.c_float(-1)
+    L.check(L.lib.ohmhip_event_elapsed_ms(ev0, ev1, C.byref(ms)))
+    assert ms.value >= 0
+    # partial write at an offset + fill
+    L.check(L.lib.ohmhip_buffer_fill(buf, 0, 4096, 0, None))
+    patch = np.full(16, 0xDEADBEEF, dtype=np.uint32)
+    L.check(L.lib.ohmhip_buffer_write(buf, patch.ctypes.data, patch.nbytes, 64, None, None, None))
+    L.check(L.lib.ohmhip_buffer_read(buf, dst.ctypes.data, 4096, 0, None, None, None))
+    assert np.all(dst[:16] == 0) and np.all(dst[16:32] == 0xDEADBEEF) and np.all(dst[32:1024] == 0)
+    # grow-only resize
+    actual = C.c_size_t(0)
+    L.check(L.lib.ohmhip_buffer_resize(buf, 1024, C.byref(actual)))
+    assert actual.value == src.nbytes
+    L.check(L.lib.ohmhip_buffer_resize(buf, 2 * src.nbytes, C.byref(actual)))
+    assert actual.value == 2 * src.nbytes
+    # out-of-range access is refused, not clamped
+    assert L.lib.ohmhip_buffer_read(buf, dst.ctypes.data, 16, 2 * src.nbytes, None, None, None) == L.ERR_INVALID_ARG
+    for h, fn in ((ev0, L.lib.ohmhip_event_destroy), (ev1, L.lib.ohmhip_event_destroy),
+                  (stream, L.lib.ohmhip_stream_destroy), (buf, L.lib.ohmhip_buffer_destroy)):
+        L.check(fn(h))
+
+
+def test_pinned_host_memory(gpu):
+    ptr = L._vp()
+    L.check(L.lib.ohmhip_host_alloc(C.byref(ptr), 1 << 16))
+    arr = np.ctypeslib.as_array((C.c_uint8 * (1 << 16)).from_address(ptr.value))
+    arr[:] = 7
+    buf = L._vp()
+    L.check(L.lib.ohmhip_buffer_create(C.byref(buf), 1 << 16, 3))
+    L.check(L.lib.ohmhip_buffer_write(buf, ptr, 1 << 16, 0, None, None, None))
+    out = np.zeros(1 << 16, dtype=np.uint8)
+    L.check(L.lib.ohmhip_buffer_read(buf, out.ctypes.data, 1 << 16, 0, None, None, None))
+    assert np.all(out == 7)
+    L.check(L.lib.ohmhip_buffer_destroy(buf))
+    L.check(L.lib.ohmhip_host_free(ptr))
