@@ -42,9 +42,10 @@ struct BatchScratch
   uint32_t *seg_offset;    ///< [hash_capacity]
   uint32_t *touched_flag;  ///< [hash_capacity]
   uint32_t *touched;       ///< [hash_capacity] list of touched hash indices
-  uint32_t *hit_begin;     ///< [slot_capacity]
+  uint32_t *hit_begin;     ///< [slot_capacity] first sample of the region in the sorted list
   uint32_t *hit_end;       ///< [slot_capacity]
   uint32_t *dirty;         ///< [slot_capacity]
+  uint32_t *voxel_first_hit;  ///< [slot_capacity * region_voxels] index of a voxel's first sample in the sorted list
   BatchInfo *info;
 };
 
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(1024)
           ch.slot = slot;
           ch.seg_begin = seg_excl + c * chunk_segments;
           ch.seg_end = seg_excl + min(cnt, (c + 1) * chunk_segments);
-          ch.hash_index = h;
+          ch.hash_index = h | ((nchk == 1) ? 0x80000000u : 0u);
           chunks[chk_excl + c] = ch;
         }
       }
@@ -519,12 +520,12 @@ __global__ void __launch_bounds__(256)
   {
     bool has = false;
     uint64_t key = 0;
-    uint32_t axis_step = 0;
+    uint32_t rs0 = 0, rs1 = 0, rs2 = 0;
     if (phase == 0)
     {
       has = manhattan > 0 || (rw.flags & kRwIncludeEnd);
       key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
-      axis_step = 3u << 30;
+      rs0 = kSegFirst;
       phase = 1;
     }
     else if (phase == 1)
@@ -535,7 +536,12 @@ __global__ void __launch_bounds__(256)
         const bool at_end = stepReachesEnd(rw, axis, j);
         has = !at_end || (rw.flags & kRwIncludeEnd);
         key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
-        axis_step = (uint32_t(axis) << 30) | uint32_t(j);
+        // Resume state: steps taken per axis at the moment the region is entered.
+        const double ta = stepTime(sel3(axis, rw.init[0], rw.init[1], rw.init[2]),
+                                   sel3(axis, rw.delta[0], rw.delta[1], rw.delta[2]), j);
+        rs0 = uint32_t((axis == 0) ? j : stepsBefore(rw.init[0], rw.delta[0], rw.total[0], 0, axis, ta));
+        rs1 = uint32_t((axis == 1) ? j : stepsBefore(rw.init[1], rw.delta[1], rw.total[1], 1, axis, ta));
+        rs2 = uint32_t((axis == 2) ? j : stepsBefore(rw.init[2], rw.delta[2], rw.total[2], 2, axis, ta));
       }
       else
       {
@@ -564,7 +570,9 @@ __global__ void __launch_bounds__(256)
         {
           Segment s;
           s.ray = ray;
-          s.axis_step = axis_step;
+          s.s0 = rs0;
+          s.s1 = rs1;
+          s.s2 = rs2;
           segments[pos] = s;
         }
       }
@@ -609,13 +617,22 @@ __global__ void __launch_bounds__(256)
 // k_hit_bounds: [begin, end) of each region slot in the sorted hit list.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-  k_hit_bounds(const unsigned long long *__restrict__ sorted, BatchScratch bs)
+  k_hit_bounds(const unsigned long long *__restrict__ sorted, BatchScratch bs, int region_voxels)
 {
   const uint32_t n_hits = bs.info->n_hits;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_hits)
   {
     return;
+  }
+  const unsigned long long group = sorted[i] >> kHitRayBits;
+  if (i == 0 || (sorted[i - 1] >> kHitRayBits) != group)
+  {
+    // First sample of its voxel: entry point for ordering misses against this voxel's samples.  Entries are only
+    // ever read for voxels whose mask bit is set in the same batch, so the table needs no clearing.
+    const uint32_t slot = uint32_t(group >> kHitVoxelBits);
+    const uint32_t vi = uint32_t(group) & ((1u << kHitVoxelBits) - 1u);
+    bs.voxel_first_hit[size_t(slot) * size_t(region_voxels) + vi] = i;
   }
   const uint32_t slot = uint32_t(sorted[i] >> kHitSlotShift);
   if (i == 0 || uint32_t(sorted[i - 1] >> kHitSlotShift) != slot)
@@ -625,325 +642,6 @@ __global__ void __launch_bounds__(256)
   if (i + 1 == n_hits || uint32_t(sorted[i + 1] >> kHitSlotShift) != slot)
   {
     bs.hit_end[slot] = i + 1;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// k_region_walk: the hot kernel.
-//
-// One workgroup (16 waves) per chunk of <= kChunkSegments ray-region segments of ONE region.  The region's miss-count
-// tile (u16 per voxel, 64 KiB for 32^3) and its hit bitmask live in LDS.  Every lane resumes one ray's fp64 walk at
-// the step that enters the region and walks until the ray leaves the region or ends.  Idle lanes are refilled in
-// batches from a workgroup-wide LDS cursor so waves stay mostly full although segments differ in length.
-//
-// A miss on a voxel which ALSO receives samples in this batch must be ordered against those samples.  Resolving that
-// needs a search in the region's sorted hit list (global memory latency), so such visits are not resolved here: they
-// are appended to a per-wave LDS queue (no atomics: the queue cursor is wave-uniform) which is flushed to a global
-// event list in coalesced bursts and resolved by k_flagged_events with full memory-level parallelism.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kWalkThreads = 1024;
-constexpr int kWalkWaves = kWalkThreads / 64;
-constexpr int kQueueCap = 256;     ///< deferred events per wave (8 B each)
-constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
-
-/// Resolve one deferred miss event: find the first sample of the same voxel with a larger ray index; the miss counts
-/// towards the interval before that sample, or towards the voxel's trailing count if there is none.
-__device__ inline void resolveFlaggedMiss(unsigned long long key, const BatchScratch &bs,
-                                          const unsigned long long *__restrict__ sorted_hits,
-                                          uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts,
-                                          int region_voxels)
-{
-  const uint32_t slot = uint32_t(key >> kHitSlotShift);
-  const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
-  const uint32_t he = bs.hit_end[slot];
-  uint32_t lo = bs.hit_begin[slot];
-  uint32_t hi = he;
-  while (lo < hi)
-  {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (sorted_hits[mid] > key)
-    {
-      hi = mid;
-    }
-    else
-    {
-      lo = mid + 1;
-    }
-  }
-  if (lo < he && (sorted_hits[lo] >> kHitRayBits) == (key >> kHitRayBits))
-  {
-    atomicAdd(&interval_counts[lo], 1u);
-  }
-  else
-  {
-    atomicAdd(&miss_counts[size_t(slot) * size_t(region_voxels) + vi], 1u);
-  }
-}
-
-__global__ void __launch_bounds__(kWalkThreads)
-  k_region_walk(MapConst mc, BatchScratch bs, const Chunk *__restrict__ chunks, const Segment *__restrict__ segments,
-                const RayWalk *__restrict__ walks, const unsigned long long *__restrict__ sorted_hits,
-                const uint32_t *__restrict__ hit_mask, uint32_t *__restrict__ miss_counts,
-                uint32_t *__restrict__ interval_counts, unsigned long long *__restrict__ events,
-                uint32_t event_capacity, uint32_t *__restrict__ event_count, int refill_min_idle, unsigned dbg, int ray_shift,
-                int defer_all)
-{
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  // Layout: [queues: kWalkWaves * kQueueCap u64][count words: ceil(region_voxels / 2)][mask words][cursor]
-  const uint32_t count_words = uint32_t(mc.region_voxels + 1) >> 1;
-  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
-  unsigned long long *l_queues = reinterpret_cast<unsigned long long *>(lds);
-  uint32_t *l_counts = lds + 2 * kWalkWaves * kQueueCap;
-  uint32_t *l_mask = l_counts + count_words;
-  uint32_t *l_cursor = l_mask + mask_words;
-
-  const Chunk chunk = chunks[blockIdx.x];
-  const uint32_t *g_mask = hit_mask + size_t(chunk.slot) * mask_words;
-  for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
-  {
-    l_counts[i] = 0;
-  }
-  for (uint32_t i = threadIdx.x; i < mask_words; i += kWalkThreads)
-  {
-    l_mask[i] = g_mask[i];
-  }
-  if (threadIdx.x == 0)
-  {
-    *l_cursor = 0;
-  }
-  __syncthreads();
-
-  const unsigned lane = laneId();
-  const unsigned wave = threadIdx.x >> 6;
-  unsigned long long *queue = l_queues + wave * kQueueCap;
-  const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
-  const int dimx = mc.dim[0];
-  const int dimxy = mc.dim[0] * mc.dim[1];
-  const double inf = dInf();
-  const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
-
-  // Per-lane walk state (all named scalars: no run-time indexed arrays).
-  bool active = false;
-  bool skip = false;
-  bool include_end = false;
-  double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
-  double t0 = 0, t1 = 0, t2 = 0, k0 = 0, k1 = 0, k2 = 0;  // time_next / steps taken per axis
-  int room0 = 0, room1 = 0, room2 = 0, rem0 = 0, rem1 = 0, rem2 = 0;
-  int sx = 0, sy = 0, sz = 0;
-  uint32_t vi = 0;
-  uint32_t ray = 0;
-  uint32_t qcount = 0;  // wave-uniform
-  bool exhausted = false;  // wave-uniform
-
-  while (true)
-  {
-    // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
-    const unsigned long long idle = __ballot(!active);
-    const int n_idle = __popcll(idle);
-    if (!exhausted && (n_idle >= refill_min_idle))
-    {
-      uint32_t base = 0;
-      if (lane == 0)
-      {
-        base = atomicAdd(l_cursor, uint32_t(n_idle));
-      }
-      base = __shfl(base, 0);
-      exhausted = base + uint32_t(n_idle) >= n_seg;
-      const uint32_t mine = base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
-      if (!active && mine < n_seg)
-      {
-        const Segment seg = segments[chunk.seg_begin + mine];
-        const RayWalk rw = walks[seg.ray];
-        const int eaxis = int(seg.axis_step >> 30);
-        const int ej = int(seg.axis_step & 0x3fffffffu);
-        i0 = rw.init[0];
-        i1 = rw.init[1];
-        i2 = rw.init[2];
-        e0 = rw.delta[0];
-        e1 = rw.delta[1];
-        e2 = rw.delta[2];
-        // Resume state: steps taken per axis when the region is entered.
-        int s0 = 0, s1 = 0, s2 = 0;
-        if (eaxis < 3)
-        {
-          const double ta = stepTime(sel3(eaxis, i0, i1, i2), sel3(eaxis, e0, e1, e2), ej);
-          s0 = (eaxis == 0) ? ej : stepsBefore(i0, e0, rw.total[0], 0, eaxis, ta);
-          s1 = (eaxis == 1) ? ej : stepsBefore(i1, e1, rw.total[1], 1, eaxis, ta);
-          s2 = (eaxis == 2) ? ej : stepsBefore(i2, e2, rw.total[2], 2, eaxis, ta);
-        }
-        const int d0 = rwDir(rw, 0);
-        const int d1 = rwDir(rw, 1);
-        const int d2 = rwDir(rw, 2);
-        int rtmp, l0, l1, l2;
-        splitGlobal(rw.g0[0] + d0 * s0, mc.dim[0], rtmp, l0);
-        splitGlobal(rw.g0[1] + d1 * s1, mc.dim[1], rtmp, l1);
-        splitGlobal(rw.g0[2] + d2 * s2, mc.dim[2], rtmp, l2);
-        room0 = (d0 > 0) ? (mc.dim[0] - 1 - l0) : l0;
-        room1 = (d1 > 0) ? (mc.dim[1] - 1 - l1) : l1;
-        room2 = (d2 > 0) ? (mc.dim[2] - 1 - l2) : l2;
-        rem0 = rw.total[0] - s0;
-        rem1 = rw.total[1] - s1;
-        rem2 = rw.total[2] - s2;
-        k0 = double(s0);
-        k1 = double(s1);
-        k2 = double(s2);
-        // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
-        t0 = rem0 ? ((s0 == 0) ? i0 : i0 + e0 * k0) : inf;
-        t1 = rem1 ? ((s1 == 0) ? i1 : i1 + e1 * k1) : inf;
-        t2 = rem2 ? ((s2 == 0) ? i2 : i2 + e2 * k2) : inf;
-        sx = d0;
-        sy = d1 * dimx;
-        sz = d2 * dimxy;
-        vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
-        skip = (eaxis == 3) && (rw.flags & kRwExcludeStart);
-        include_end = (rw.flags & kRwIncludeEnd) != 0;
-        ray = seg.ray;
-        active = !(dbg & 16u);
-      }
-    }
-    if (!__any(active))
-    {
-      break;
-    }
-
-    // ---- one walk step for every active lane (predicated, wave-uniform control flow) -------------------------------
-    const bool at_end = (rem0 | rem1 | rem2) == 0;
-    const bool visit = active && (at_end ? include_end : !skip);
-    bool flagged = false;
-    if (visit)
-    {
-      flagged = (dbg & 2u) ? false : bool((l_mask[vi >> 5] >> (vi & 31)) & 1u);
-      if (!flagged && !(dbg & 1u))
-      {
-        atomicAdd(&l_counts[vi >> 1], 1u << ((vi & 1u) * 16u));
-      }
-      flagged = flagged && !(dbg & 8u);
-    }
-    const unsigned long long fm = __ballot(flagged);
-    if (fm)
-    {
-      if (flagged)
-      {
-        queue[qcount + uint32_t(__popcll(fm & ((1ull << lane) - 1ull)))] =
-          slot_bits | ((unsigned long long)vi << kHitRayBits) | ((unsigned long long)ray << ray_shift);
-      }
-      qcount += uint32_t(__popcll(fm));
-      if (qcount > uint32_t(kQueueCap - 64))
-      {
-        // Flush this wave's queue: one global atomic for the burst, coalesced 8-byte stores.
-        uint32_t gbase = 0;
-        if (lane == 0)
-        {
-          gbase = atomicAdd(event_count, qcount);
-        }
-        gbase = __shfl(gbase, 0);
-        for (uint32_t q = lane; q < qcount; q += 64)
-        {
-          const unsigned long long ev = queue[q];
-          if (gbase + q < event_capacity)
-          {
-            events[gbase + q] = ev;
-          }
-          else if (!defer_all)
-          {
-            resolveFlaggedMiss(ev, bs, sorted_hits, miss_counts, interval_counts, mc.region_voxels);
-          }
-        }
-        qcount = 0;
-      }
-    }
-    skip = false;
-    {
-      // One branch-free walk step for every lane that still has steps to take.  All three axes' candidate updates are
-      // computed (independent fp64 chains, no exec-mask juggling) and the selected axis' values are committed with
-      // selects.  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
-      const bool stepping = active && !at_end;
-      const bool c01 = t0 < t1;
-      const double t01 = c01 ? t0 : t1;
-      const bool c2 = t01 < t2;
-      const bool is2 = stepping && !c2;
-      const bool is0 = stepping && c2 && c01;
-      const bool is1 = stepping && c2 && !c01;
-      const double k0n = k0 + 1.0;
-      const double k1n = k1 + 1.0;
-      const double k2n = k2 + 1.0;
-      const double t0n = i0 + e0 * k0n;  // ohm/LineWalkCompute.h:299-301
-      const double t1n = i1 + e1 * k1n;
-      const double t2n = i2 + e2 * k2n;
-      rem0 -= int(is0);
-      rem1 -= int(is1);
-      rem2 -= int(is2);
-      room0 -= int(is0);
-      room1 -= int(is1);
-      room2 -= int(is2);
-      k0 = is0 ? k0n : k0;
-      k1 = is1 ? k1n : k1;
-      k2 = is2 ? k2n : k2;
-      t0 = is0 ? (rem0 ? t0n : inf) : t0;
-      t1 = is1 ? (rem1 ? t1n : inf) : t1;
-      t2 = is2 ? (rem2 ? t2n : inf) : t2;
-      vi += uint32_t(is0 ? sx : (is1 ? sy : (is2 ? sz : 0)));
-      // room* counts the steps that can still be taken along an axis before the ray leaves the region.
-      active = stepping && ((room0 | room1 | room2) >= 0);
-    }
-  }
-
-  // Final queue flush.
-  if (qcount)
-  {
-    uint32_t gbase = 0;
-    if (lane == 0)
-    {
-      gbase = atomicAdd(event_count, qcount);
-    }
-    gbase = __shfl(gbase, 0);
-    for (uint32_t q = lane; q < qcount; q += 64)
-    {
-      const unsigned long long ev = queue[q];
-      if (gbase + q < event_capacity)
-      {
-        events[gbase + q] = ev;
-      }
-      else if (!defer_all)
-      {
-        resolveFlaggedMiss(ev, bs, sorted_hits, miss_counts, interval_counts, mc.region_voxels);
-      }
-    }
-  }
-  __syncthreads();
-
-  // Flush the tile: integer adds, so the merge across chunks of one region is order independent.
-  uint32_t *g_counts = miss_counts + size_t(chunk.slot) * size_t(mc.region_voxels);
-  for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
-  {
-    const uint32_t w = (dbg & 4u) ? 0u : l_counts[i];
-    if (w)
-    {
-      const uint32_t lo = w & 0xffffu;
-      const uint32_t hi = w >> 16;
-      if (lo)
-      {
-        atomicAdd(&g_counts[2 * i], lo);
-      }
-      if (hi)
-      {
-        atomicAdd(&g_counts[2 * i + 1], hi);
-      }
-    }
-  }
-}
-
-/// Resolve the deferred miss events (grid-stride; the event count lives in device memory).
-__global__ void __launch_bounds__(256)
-  k_flagged_events(BatchScratch bs, const unsigned long long *__restrict__ events, uint32_t event_capacity,
-                   const uint32_t *__restrict__ event_count, const unsigned long long *__restrict__ sorted_hits,
-                   uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts, int region_voxels)
-{
-  const uint32_t n = min(*event_count, event_capacity);
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-  {
-    resolveFlaggedMiss(events[i], bs, sorted_hits, miss_counts, interval_counts, region_voxels);
   }
 }
 
@@ -1027,6 +725,472 @@ __device__ inline uint32_t subVoxelUpdate(uint32_t coord, uint32_t point_count, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_region_walk: the hot kernel.
+//
+// One workgroup (16 waves) per chunk of <= kChunkSegments ray-region segments of ONE region.  The region's miss-count
+// tile (u16 per voxel, 64 KiB for 32^3) and its hit bitmask live in LDS.  Every lane resumes one ray's fp64 walk at
+// the step that enters the region and walks until the ray leaves the region or ends.  Idle lanes are refilled in
+// batches from a workgroup-wide LDS cursor so waves stay mostly full although segments differ in length.
+//
+// A miss on a voxel which ALSO receives samples in this batch must be ordered against those samples.  Resolving that
+// needs a search in the region's sorted hit list (global memory latency), so such visits are not resolved here: they
+// are appended to a per-wave LDS queue (no atomics: the queue cursor is wave-uniform) which is flushed to a global
+// event list in coalesced bursts and resolved by k_flagged_events with full memory-level parallelism.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kWalkThreads = 1024;
+constexpr int kWalkWaves = kWalkThreads / 64;
+constexpr int kQueueCap = 256;     ///< deferred events per wave (8 B each)
+constexpr int kLdsHits = 4096;     ///< a region's sample list is staged in LDS when it has at most this many samples
+constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
+
+/// Resolve one deferred miss event: find the first sample of the same voxel with a larger ray index; the miss counts
+/// towards the interval before that sample, or towards the voxel's trailing count if there is none.
+__device__ inline void resolveFlaggedMiss(unsigned long long key, const BatchScratch &bs,
+                                          const unsigned long long *__restrict__ sorted_hits,
+                                          uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts,
+                                          int region_voxels)
+{
+  const uint32_t slot = uint32_t(key >> kHitSlotShift);
+  const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
+  const uint32_t he = bs.info->n_hits;
+  // Start at the voxel's first sample and step over the (few) samples with a smaller ray index.
+  uint32_t lo = bs.voxel_first_hit[size_t(slot) * size_t(region_voxels) + vi];
+  while (lo < he && (sorted_hits[lo] >> kHitRayBits) == (key >> kHitRayBits) && sorted_hits[lo] < key)
+  {
+    ++lo;
+  }
+  if (lo < he && (sorted_hits[lo] >> kHitRayBits) == (key >> kHitRayBits))
+  {
+    // The visit was counted in the voxel's miss count by the walk; move it to the interval before that sample.
+    // (Integer add / sub commute, so the transient order against the tile flush does not matter.)
+    atomicAdd(&interval_counts[lo], 1u);
+    atomicSub(&miss_counts[size_t(slot) * size_t(region_voxels) + vi], 1u);
+  }
+}
+
+/// Drain one wave's deferred-miss queue.  Preferred: order each miss against the region's samples in LDS (binary search
+/// over the staged sorted keys, LDS atomics on the interval / trailing counters).  Otherwise append the events to the
+/// global list in one coalesced burst (resolved by k_flagged_events, or sorted and replayed for NDT / TSDF).
+__device__ inline void flushQueue(const unsigned long long *queue, uint32_t qcount, unsigned lane, bool lds_resolve,
+                                  const unsigned long long *l_hits, uint32_t n_region_hits, uint32_t hb,
+                                  uint32_t *l_intervals, uint32_t *l_counts, unsigned long long *__restrict__ events,
+                                  uint32_t event_capacity, uint32_t *__restrict__ event_count, int defer_all,
+                                  const BatchScratch &bs, const unsigned long long *__restrict__ sorted_hits,
+                                  uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts,
+                                  int region_voxels)
+{
+  if (lds_resolve)
+  {
+    for (uint32_t q = lane; q < qcount; q += 64)
+    {
+      const unsigned long long ev = queue[q];
+      // First staged sample with key > ev.
+      uint32_t lo = 0, hi = n_region_hits;
+      while (lo < hi)
+      {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (l_hits[mid] > ev)
+        {
+          hi = mid;
+        }
+        else
+        {
+          lo = mid + 1;
+        }
+      }
+      if (lo < n_region_hits && (l_hits[lo] >> kHitRayBits) == (ev >> kHitRayBits))
+      {
+        // Belongs before a later sample of the voxel: move it from the voxel's count to that sample's interval.
+        const uint32_t vi = uint32_t(ev >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
+        atomicAdd(&l_intervals[lo], 1u);
+        atomicSub(&l_counts[vi >> 1], 1u << ((vi & 1u) * 16u));
+      }
+    }
+    return;
+  }
+  uint32_t gbase = 0;
+  if (lane == 0)
+  {
+    gbase = atomicAdd(event_count, qcount);
+  }
+  gbase = __shfl(gbase, 0);
+  for (uint32_t q = lane; q < qcount; q += 64)
+  {
+    const unsigned long long ev = queue[q];
+    if (gbase + q < event_capacity)
+    {
+      events[gbase + q] = ev;
+    }
+    else if (!defer_all)
+    {
+      resolveFlaggedMiss(ev, bs, sorted_hits, miss_counts, interval_counts, region_voxels);
+    }
+  }
+}
+
+/// Kernel parameters of k_region_walk (one struct keeps the template instantiations readable).
+struct WalkArgs
+{
+  MapConst mc;
+  BatchScratch bs;
+  const Chunk *chunks;
+  const Segment *segments;
+  const RayWalk *walks;
+  const unsigned long long *sorted_hits;
+  const uint32_t *hit_mask;
+  uint32_t *miss_counts;
+  uint32_t *interval_counts;
+  unsigned long long *events;
+  uint32_t event_capacity;
+  uint32_t *event_count;
+  int refill_min_idle;
+  unsigned dbg;
+  int ray_shift;
+  int defer_all;     ///< NDT / TSDF: every visit to a masked voxel becomes an event; masked voxels are not counted
+  float *occupancy;  ///< non-null: single-chunk regions are applied straight from LDS
+  unsigned ray_flags;
+  unsigned long long *dbg_counters;
+};
+
+/// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
+/// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every active
+/// lane sits on a voxel that takes a miss, and a lane retires the moment it steps onto its ray's end voxel.
+template <bool kSpecial>
+__global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const MapConst &mc = args.mc;
+  // Layout: [queues][staged sample keys][interval counters][count words: ceil(region_voxels / 2)][mask words][cursor]
+  const uint32_t count_words = uint32_t(mc.region_voxels + 1) >> 1;
+  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
+  unsigned long long *l_queues = reinterpret_cast<unsigned long long *>(lds);
+  unsigned long long *l_hits = l_queues + kWalkWaves * kQueueCap;           // [kLdsHits] region's sorted sample keys
+  uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] interval counters
+  uint32_t *l_counts = l_intervals + kLdsHits;
+  uint32_t *l_mask = l_counts + count_words;
+  uint32_t *l_cursor = l_mask + mask_words;
+
+  const Chunk chunk = args.chunks[blockIdx.x];
+  const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
+  for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
+  {
+    l_counts[i] = 0;
+  }
+  for (uint32_t i = threadIdx.x; i < mask_words; i += kWalkThreads)
+  {
+    l_mask[i] = g_mask[i];
+  }
+  if (threadIdx.x == 0)
+  {
+    *l_cursor = 0;
+  }
+  // Stage the region's sorted sample keys so deferred misses can be ordered against them at LDS latency.
+  const int defer_all = args.defer_all;
+  const uint32_t hb = defer_all ? 0u : args.bs.hit_begin[chunk.slot];
+  const uint32_t he = defer_all ? 0u : args.bs.hit_end[chunk.slot];
+  const uint32_t n_region_hits = he - hb;
+  const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(kLdsHits);
+  if (lds_resolve)
+  {
+    for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
+    {
+      l_hits[i] = args.sorted_hits[hb + i];
+      l_intervals[i] = 0;
+    }
+  }
+  __syncthreads();
+
+  const unsigned lane = laneId();
+  const unsigned wave = threadIdx.x >> 6;
+  unsigned long long *queue = l_queues + wave * kQueueCap;
+  const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
+  const int dimx = mc.dim[0];
+  const int dimxy = mc.dim[0] * mc.dim[1];
+  const double inf = dInf();
+  const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
+  const int ray_shift = args.ray_shift;
+  const int refill_min_idle = args.refill_min_idle;
+  const unsigned dbg = args.dbg;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+  // Per-lane walk state (all named scalars: no run-time indexed arrays).
+  bool active = false;
+  bool skip = false;         // kSpecial only
+  bool include_end = false;  // kSpecial only
+  double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
+  double t0 = 0, t1 = 0, t2 = 0, k0 = 0, k1 = 0, k2 = 0;  // time_next / steps taken per axis
+  int room0 = 0, room1 = 0, room2 = 0, rem0 = 0, rem1 = 0, rem2 = 0;
+  int sx = 0, sy = 0, sz = 0;
+  uint32_t vi = 0;
+  uint32_t ray = 0;
+  uint32_t qcount = 0;     // wave-uniform
+  bool exhausted = false;  // wave-uniform
+  uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;
+
+  while (true)
+  {
+    // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
+    unsigned long long am = __ballot(active);
+    const int n_idle = 64 - __popcll(am);
+    if (!exhausted && (n_idle >= refill_min_idle))
+    {
+      ++dbg_refills;
+      const unsigned long long idle = ~am;
+      uint32_t base = 0;
+      if (lane == 0)
+      {
+        base = atomicAdd(l_cursor, uint32_t(n_idle));
+      }
+      base = __shfl(base, 0);
+      exhausted = base + uint32_t(n_idle) >= n_seg;
+      const uint32_t mine = base + uint32_t(__popcll(idle & lane_lt));
+      if (!active && mine < n_seg)
+      {
+        const Segment seg = args.segments[chunk.seg_begin + mine];
+        const RayWalk rw = args.walks[seg.ray];
+        const bool first_segment = (seg.s0 & kSegFirst) != 0;
+        const int s0 = int(seg.s0 & ~kSegFirst);
+        const int s1 = int(seg.s1);
+        const int s2 = int(seg.s2);
+        i0 = rw.init[0];
+        i1 = rw.init[1];
+        i2 = rw.init[2];
+        e0 = rw.delta[0];
+        e1 = rw.delta[1];
+        e2 = rw.delta[2];
+        const int d0 = rwDir(rw, 0);
+        const int d1 = rwDir(rw, 1);
+        const int d2 = rwDir(rw, 2);
+        const int l0 = localCoord(rw.g0[0] + d0 * s0, mc.dim[0]);
+        const int l1 = localCoord(rw.g0[1] + d1 * s1, mc.dim[1]);
+        const int l2 = localCoord(rw.g0[2] + d2 * s2, mc.dim[2]);
+        // room*: steps that can still be taken along an axis before the ray leaves the region.
+        room0 = (d0 > 0) ? (mc.dim[0] - 1 - l0) : l0;
+        room1 = (d1 > 0) ? (mc.dim[1] - 1 - l1) : l1;
+        room2 = (d2 > 0) ? (mc.dim[2] - 1 - l2) : l2;
+        rem0 = rw.total[0] - s0;
+        rem1 = rw.total[1] - s1;
+        rem2 = rw.total[2] - s2;
+        k0 = double(s0);
+        k1 = double(s1);
+        k2 = double(s2);
+        // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
+        t0 = rem0 ? ((s0 == 0) ? i0 : i0 + e0 * k0) : inf;
+        t1 = rem1 ? ((s1 == 0) ? i1 : i1 + e1 * k1) : inf;
+        t2 = rem2 ? ((s2 == 0) ? i2 : i2 + e2 * k2) : inf;
+        sx = d0;
+        sy = d1 * dimx;
+        sz = d2 * dimxy;
+        vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
+        ray = seg.ray;
+        if (kSpecial)
+        {
+          skip = first_segment && (rw.flags & kRwExcludeStart);
+          include_end = (rw.flags & kRwIncludeEnd) != 0;
+          active = true;
+        }
+        else
+        {
+          // A segment whose entry voxel is the ray's end voxel never exists here (k_ray_bin drops it).
+          active = (rem0 | rem1 | rem2) != 0;
+        }
+        active = active && !(dbg & 16u);
+      }
+      am = __ballot(active);
+    }
+    if (am == 0)
+    {
+      break;
+    }
+
+    // ---- visit: count the miss.  Masked voxels (which also receive samples) are counted too; the ordering pass
+    // ---- moves such a miss to an interval counter when a later sample of the voxel exists.
+    const bool at_end = kSpecial ? ((rem0 | rem1 | rem2) == 0) : false;
+    const bool visit = kSpecial ? (active && (at_end ? include_end : !skip)) : active;
+    const uint32_t vi_visit = vi;
+    uint32_t mword = 0;
+    if (visit)
+    {
+      mword = l_mask[vi_visit >> 5];
+      if (!(dbg & 1u))
+      {
+        atomicAdd(&l_counts[vi_visit >> 1], 1u << ((vi_visit & 1u) * 16u));
+      }
+    }
+    if (kSpecial)
+    {
+      skip = false;
+    }
+    ++dbg_iters;
+
+    // ---- one branch-free walk step.  All three axes' candidate updates are computed (independent fp64 chains, no
+    // ---- exec-mask juggling); the selected axis' values are committed with selects.
+    // ---- walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
+    {
+      const bool stepping = kSpecial ? (active && !at_end) : active;
+      const bool c01 = t0 < t1;
+      const double t01 = c01 ? t0 : t1;
+      const bool c2 = t01 < t2;
+      const bool is2 = stepping && !c2;
+      const bool is0 = stepping && c2 && c01;
+      const bool is1 = stepping && c2 && !c01;
+      const double k0n = k0 + 1.0;
+      const double k1n = k1 + 1.0;
+      const double k2n = k2 + 1.0;
+      const double t0n = i0 + e0 * k0n;  // ohm/LineWalkCompute.h:299-301
+      const double t1n = i1 + e1 * k1n;
+      const double t2n = i2 + e2 * k2n;
+      rem0 -= int(is0);
+      rem1 -= int(is1);
+      rem2 -= int(is2);
+      room0 -= int(is0);
+      room1 -= int(is1);
+      room2 -= int(is2);
+      k0 = is0 ? k0n : k0;
+      k1 = is1 ? k1n : k1;
+      k2 = is2 ? k2n : k2;
+      t0 = is0 ? (rem0 ? t0n : inf) : t0;
+      t1 = is1 ? (rem1 ? t1n : inf) : t1;
+      t2 = is2 ? (rem2 ? t2n : inf) : t2;
+      vi += uint32_t(is0 ? sx : (is1 ? sy : (is2 ? sz : 0)));
+      const bool inside = (room0 | room1 | room2) >= 0;
+      if (kSpecial)
+      {
+        active = stepping && inside;
+      }
+      else
+      {
+        // Retire on leaving the region or on reaching the end voxel (which takes no miss).
+        active = stepping && inside && ((rem0 | rem1 | rem2) != 0);
+      }
+    }
+
+    // ---- deferred ordering of misses on masked voxels (the mask word was fetched before the step: its LDS latency
+    // ---- overlaps the step arithmetic).
+    const bool flagged = visit && ((mword >> (vi_visit & 31)) & 1u) && !(dbg & 10u);
+    const unsigned long long fm = __ballot(flagged);
+    if (args.dbg_counters)
+    {
+      dbg_active += uint32_t(__popcll(__ballot(visit)));
+      dbg_fm += fm ? 1u : 0u;
+    }
+    if (fm)
+    {
+      if (flagged)
+      {
+        queue[qcount + uint32_t(__popcll(fm & lane_lt))] =
+          slot_bits | ((unsigned long long)vi_visit << kHitRayBits) | ((unsigned long long)ray << ray_shift);
+      }
+      qcount += uint32_t(__popcll(fm));
+      if (qcount > uint32_t(kQueueCap - 64))
+      {
+        flushQueue(queue, qcount, lane, lds_resolve, l_hits, n_region_hits, hb, l_intervals, l_counts, args.events,
+                   args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits, args.miss_counts,
+                   args.interval_counts, mc.region_voxels);
+        qcount = 0;
+      }
+    }
+  }
+
+  if (args.dbg_counters && lane == 0)
+  {
+    atomicAdd(&args.dbg_counters[0], (unsigned long long)dbg_iters);
+    atomicAdd(&args.dbg_counters[1], (unsigned long long)dbg_active);
+    atomicAdd(&args.dbg_counters[2], (unsigned long long)dbg_refills);
+    atomicAdd(&args.dbg_counters[3], (unsigned long long)dbg_fm);
+  }
+  // Final queue flush.
+  if (qcount)
+  {
+    flushQueue(queue, qcount, lane, lds_resolve, l_hits, n_region_hits, hb, l_intervals, l_counts, args.events,
+               args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits, args.miss_counts,
+               args.interval_counts, mc.region_voxels);
+  }
+  __syncthreads();
+
+  if (lds_resolve)
+  {
+    for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
+    {
+      const uint32_t c = l_intervals[i];
+      if (c)
+      {
+        atomicAdd(&args.interval_counts[hb + i], c);
+      }
+    }
+  }
+  uint32_t *g_counts = args.miss_counts + size_t(chunk.slot) * size_t(mc.region_voxels);
+  if (args.occupancy && (chunk.hash_index & 0x80000000u))
+  {
+    // This chunk holds ALL of the region's segments for the batch: apply the miss counts to the log-odds layer
+    // straight from LDS (no count round trip through HBM).  Voxels which also receive samples keep their count for
+    // the ordered replay (occupancy: k_apply_hits; NDT: their visits are events, the tile entry is not used).
+    float *g_occ = args.occupancy + size_t(chunk.slot) * size_t(mc.region_voxels);
+    for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
+    {
+      const uint32_t w = l_counts[i];
+      if (w)
+      {
+#pragma unroll
+        for (uint32_t half = 0; half < 2; ++half)
+        {
+          const uint32_t n = (w >> (16u * half)) & 0xffffu;
+          if (n)
+          {
+            const uint32_t v = 2 * i + half;
+            if ((l_mask[v >> 5] >> (v & 31)) & 1u)
+            {
+              if (!defer_all)
+              {
+                atomicAdd(&g_counts[v], n);
+              }
+            }
+            else
+            {
+              g_occ[v] = occMissN(mc, args.ray_flags, g_occ[v], n);
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  // Flush the tile: integer adds, so the merge across chunks of one region is order independent.  (NDT / TSDF:
+  // entries of masked voxels are skipped -- their visits travel as events.)
+  for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
+  {
+    const uint32_t w = (dbg & 4u) ? 0u : l_counts[i];
+    if (w)
+    {
+#pragma unroll
+      for (uint32_t half = 0; half < 2; ++half)
+      {
+        const uint32_t n = (w >> (16u * half)) & 0xffffu;
+        const uint32_t v = 2 * i + half;
+        if (n && !(defer_all && ((l_mask[v >> 5] >> (v & 31)) & 1u)))
+        {
+          atomicAdd(&g_counts[v], n);
+        }
+      }
+    }
+  }
+}
+
+/// Resolve the deferred miss events (grid-stride; the event count lives in device memory).
+__global__ void __launch_bounds__(256)
+  k_flagged_events(BatchScratch bs, const unsigned long long *__restrict__ events, uint32_t event_capacity,
+                   const uint32_t *__restrict__ event_count, const unsigned long long *__restrict__ sorted_hits,
+                   uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts, int region_voxels)
+{
+  const uint32_t n = min(*event_count, event_capacity);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  {
+    resolveFlaggedMiss(events[i], bs, sorted_hits, miss_counts, interval_counts, region_voxels);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_apply_hits: one lane per sorted hit; the first hit of each voxel group replays the whole group in ray order.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -1097,25 +1261,71 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------------------------------------
 // k_apply_counts: one block per touched region: apply plain miss counts, clear scratch.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
   k_apply_counts(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags, uint32_t *__restrict__ miss_counts,
                  uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy, int clear_mask,
-                 uint32_t *__restrict__ hit_miss_counts)
+                 uint32_t *__restrict__ hit_miss_counts, uint32_t direct_chunk_segments, int skip_masked)
 {
   const uint32_t h = bs.touched[blockIdx.x];
   const uint32_t slot = rt.vals[h];
   const size_t base = size_t(slot) * size_t(mc.region_voxels);
-  for (uint32_t vi = threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
+  // Regions with a single chunk were applied by the walk kernel itself (direct_chunk_segments != 0).
+  const bool applied_by_walk = direct_chunk_segments && bs.seg_count[h] > 0 && bs.seg_count[h] <= direct_chunk_segments;
+  if (!applied_by_walk)
   {
-    const uint32_t n = miss_counts[base + vi];
-    if (n)
+    // 4 voxels per lane per step: 16-byte loads of the count and log-odds layers (region blocks are 16-byte aligned
+    // whenever region_voxels is a multiple of 4; otherwise fall back to scalar accesses).
+    const uint32_t n4 = (mc.region_voxels % 4 == 0) ? uint32_t(mc.region_voxels) / 4u : 0u;
+    uint4 *counts4 = reinterpret_cast<uint4 *>(miss_counts + base);
+    float4 *occ4 = reinterpret_cast<float4 *>(occupancy + base);
+    const uint32_t *mask = hit_mask + size_t(slot) * (uint32_t(mc.region_voxels + 31) >> 5);
+    for (uint32_t q = threadIdx.x; q < n4; q += blockDim.x)
     {
-      occupancy[base + vi] = occMissN(mc, ray_flags, occupancy[base + vi], n);
-      miss_counts[base + vi] = 0;
-      if (hit_miss_counts)
+      uint4 n = counts4[q];
+      if (n.x | n.y | n.z | n.w)
       {
-        // NDT-TM: every plain miss increments HitMissCount::miss_count (ohm/RayMapperNdt.cpp:171-178).
-        hit_miss_counts[2 * (base + vi) + 1] += n;
+        if (skip_masked)
+        {
+          // NDT: voxels holding samples are updated by the ordered replay only; their tile entry is not used.
+          const uint32_t bits = mask[(4 * q) >> 5] >> ((4 * q) & 31);
+          n.x = (bits & 1u) ? 0u : n.x;
+          n.y = (bits & 2u) ? 0u : n.y;
+          n.z = (bits & 4u) ? 0u : n.z;
+          n.w = (bits & 8u) ? 0u : n.w;
+        }
+        float4 o = occ4[q];
+        o.x = n.x ? occMissN(mc, ray_flags, o.x, n.x) : o.x;
+        o.y = n.y ? occMissN(mc, ray_flags, o.y, n.y) : o.y;
+        o.z = n.z ? occMissN(mc, ray_flags, o.z, n.z) : o.z;
+        o.w = n.w ? occMissN(mc, ray_flags, o.w, n.w) : o.w;
+        occ4[q] = o;
+        counts4[q] = make_uint4(0, 0, 0, 0);
+        if (hit_miss_counts)
+        {
+          // NDT-TM: every plain miss increments HitMissCount::miss_count (ohm/RayMapperNdt.cpp:171-178).
+          hit_miss_counts[2 * (base + 4 * q + 0) + 1] += n.x;
+          hit_miss_counts[2 * (base + 4 * q + 1) + 1] += n.y;
+          hit_miss_counts[2 * (base + 4 * q + 2) + 1] += n.z;
+          hit_miss_counts[2 * (base + 4 * q + 3) + 1] += n.w;
+        }
+      }
+    }
+    for (uint32_t vi = 4 * n4 + threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
+    {
+      uint32_t n = miss_counts[base + vi];
+      if (n && skip_masked && ((mask[vi >> 5] >> (vi & 31)) & 1u))
+      {
+        miss_counts[base + vi] = 0;
+        n = 0;
+      }
+      if (n)
+      {
+        occupancy[base + vi] = occMissN(mc, ray_flags, occupancy[base + vi], n);
+        miss_counts[base + vi] = 0;
+        if (hit_miss_counts)
+        {
+          hit_miss_counts[2 * (base + vi) + 1] += n;
+        }
       }
     }
   }

@@ -91,13 +91,15 @@ enum : unsigned
   kRwWalk = 1u << 7           ///< ray part is walked (not kRfExcludeRay)
 };
 
-/// One (ray, region) unit of line-walk work: "resume ray `ray` at the step that enters this region".
-/// axis == 3 => the ray's first segment (starts at the origin voxel, step 0).
+/// One (ray, region) unit of line-walk work: "resume ray `ray` with these per-axis step counts", i.e. the walk state
+/// at the step that enters the region (all zero for the ray's first segment).  Computed densely by k_ray_bin so the
+/// walk kernel's lane refill is a couple of loads.  Bit 31 of s0 marks the ray's first segment.
 struct Segment
 {
   uint32_t ray;
-  uint32_t axis_step;  ///< (axis << 30) | j : the j-th step along `axis` is the one that enters the region.
+  uint32_t s0, s1, s2;
 };
+constexpr uint32_t kSegFirst = 0x80000000u;
 
 struct Chunk
 {

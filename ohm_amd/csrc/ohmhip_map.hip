@@ -87,7 +87,7 @@ struct ohmhip_map_s
   // scratch
   uint32_t *d_seg_count = nullptr, *d_seg_cursor = nullptr, *d_seg_offset = nullptr, *d_touched_flag = nullptr,
            *d_touched = nullptr;
-  uint32_t *d_hit_begin = nullptr, *d_hit_end = nullptr, *d_dirty = nullptr;
+  uint32_t *d_voxel_first_hit = nullptr, *d_hit_begin = nullptr, *d_hit_end = nullptr, *d_dirty = nullptr;
   BatchInfo *d_info = nullptr;
   BatchInfo *h_info = nullptr;  ///< pinned
   uint32_t *d_miss_counts = nullptr;
@@ -97,6 +97,7 @@ struct ohmhip_map_s
 
   DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev, events;
   uint32_t *d_event_count = nullptr;
+  unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   uint32_t event_demand = 0;
   uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= 65535 (u16 LDS counters)
   unsigned debug_flags = 0;  ///< OHMHIP_DEBUG_FLAGS: timing experiments only (breaks results)
@@ -134,6 +135,7 @@ BatchScratch batchScratch(ohmhip_map_t m)
   bs.seg_offset = m->d_seg_offset;
   bs.touched_flag = m->d_touched_flag;
   bs.touched = m->d_touched;
+  bs.voxel_first_hit = m->d_voxel_first_hit;
   bs.hit_begin = m->d_hit_begin;
   bs.hit_end = m->d_hit_end;
   bs.dirty = m->d_dirty;
@@ -198,7 +200,7 @@ void freePool(ohmhip_map_t m)
     }
   }
   void *ptrs[] = { m->d_keys,       m->d_vals,        m->d_slot_keys, m->d_seg_count, m->d_seg_cursor,
-                   m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_hit_begin, m->d_hit_end,
+                   m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_voxel_first_hit, m->d_hit_begin, m->d_hit_end,
                    m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks };
   for (void *p : ptrs)
   {
@@ -211,7 +213,7 @@ void freePool(ohmhip_map_t m)
   m->d_vals = nullptr;
   m->d_slot_keys = nullptr;
   m->d_seg_count = m->d_seg_cursor = m->d_seg_offset = m->d_touched_flag = m->d_touched = nullptr;
-  m->d_hit_begin = m->d_hit_end = m->d_dirty = nullptr;
+  m->d_voxel_first_hit = m->d_hit_begin = m->d_hit_end = m->d_dirty = nullptr;
   m->d_miss_counts = m->d_hit_mask = nullptr;
   m->d_chunks = nullptr;
 }
@@ -280,7 +282,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
     m->layers[l] = new_layers[l];
   }
   void *old[] = { m->d_keys,       m->d_vals,         m->d_slot_keys, m->d_seg_count, m->d_seg_cursor,
-                  m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_hit_begin, m->d_hit_end,
+                  m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_voxel_first_hit, m->d_hit_begin, m->d_hit_end,
                   m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks };
   for (void *p : old)
   {
@@ -307,6 +309,10 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_offset), sizeof(uint32_t) * hash_cap);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_touched_flag), sizeof(uint32_t) * hash_cap);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_touched), sizeof(uint32_t) * hash_cap);
+  if (m->config.mode == OHMHIP_MODE_OCCUPANCY)
+  {
+    err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_voxel_first_hit), sizeof(uint32_t) * rv * capacity);
+  }
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_begin), sizeof(uint32_t) * capacity);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_end), sizeof(uint32_t) * capacity);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_miss_counts), sizeof(uint32_t) * rv * capacity);
@@ -384,9 +390,21 @@ int ensureStage(ohmhip_map_t m, size_t bytes)
   return OHMHIP_OK;
 }
 
+/// Highest key bit the sorts need: the slot field only uses log2(capacity) + 1 bits (invalid keys are all ones).
+unsigned sortEndBit(ohmhip_map_t m)
+{
+  unsigned bits = 1;
+  while ((1u << bits) <= m->slot_capacity)
+  {
+    ++bits;
+  }
+  return std::min<unsigned>(64u, unsigned(kHitSlotShift) + bits + 1u);
+}
+
 size_t walkLdsBytes(const MapConst &mc)
 {
-  return (size_t(2 * kWalkWaves * kQueueCap) + size_t((mc.region_voxels + 1) / 2) + size_t((mc.region_voxels + 31) / 32) + 4) *
+  return (size_t(2 * kWalkWaves * kQueueCap) + size_t(3 * kLdsHits) + size_t((mc.region_voxels + 1) / 2) +
+          size_t((mc.region_voxels + 31) / 32) + 4) *
          sizeof(uint32_t);
 }
 
@@ -430,8 +448,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     OHMHIP_CHECK(m->interval_counts.ensure(sizeof(uint32_t) * size_t(n_rays), true, s));
     size_t sort_bytes = 0;
     OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, static_cast<unsigned long long *>(m->hit_keys_a.ptr),
-                                          static_cast<unsigned long long *>(m->hit_keys_b.ptr), size_t(n_rays), 0, 64,
-                                          s));
+                                          static_cast<unsigned long long *>(m->hit_keys_b.ptr), size_t(n_rays),
+                                          kHitRayBits, sortEndBit(m), s));
     OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
   }
 
@@ -506,22 +524,56 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     if (occupancy_mode)
     {
       size_t temp_bytes = m->sort_temp.bytes;
-      OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays), 0, 64, s));
-      hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m));
+      // Sample keys are emitted in ray order and the radix sort is stable: sorting on the (slot, voxel) bits alone
+      // leaves each voxel's samples in ray order.
+      OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays), kHitRayBits,
+                                            sortEndBit(m), s));
+      hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m), m->mc.region_voxels);
     }
     OHMHIP_CHECK(hipEventRecord(m->ev[2], s));
 
+    // Single-chunk regions are applied by the walk kernel straight from LDS (plain log-odds misses only).
+    float *direct_occ = (occupancy_mode || mode == OHMHIP_MODE_NDT_OM) ?
+                          static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]) :
+                          nullptr;
+    const uint32_t direct_segments = direct_occ ? m->chunk_segments : 0u;
     uint32_t n_events = 0;
     if (info.n_chunks)
     {
       for (int walk_attempt = 0; walk_attempt < 4; ++walk_attempt)
       {
         OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_region_walk, dim3(info.n_chunks), dim3(kWalkThreads), walkLdsBytes(m->mc), s, m->mc,
-                           batchScratch(m), m->d_chunks, static_cast<const Segment *>(m->segments.ptr),
-                           static_cast<const RayWalk *>(m->walks.ptr), sorted, m->d_hit_mask, m->d_miss_counts,
-                           static_cast<uint32_t *>(m->interval_counts.ptr), events, event_capacity, m->d_event_count,
-                           m->refill_min_idle, m->debug_flags, ray_shift, occupancy_mode ? 0 : 1);
+        WalkArgs wa;
+        wa.mc = m->mc;
+        wa.bs = batchScratch(m);
+        wa.chunks = m->d_chunks;
+        wa.segments = static_cast<const Segment *>(m->segments.ptr);
+        wa.walks = static_cast<const RayWalk *>(m->walks.ptr);
+        wa.sorted_hits = sorted;
+        wa.hit_mask = m->d_hit_mask;
+        wa.miss_counts = m->d_miss_counts;
+        wa.interval_counts = static_cast<uint32_t *>(m->interval_counts.ptr);
+        wa.events = events;
+        wa.event_capacity = event_capacity;
+        wa.event_count = m->d_event_count;
+        wa.refill_min_idle = m->refill_min_idle;
+        wa.dbg = m->debug_flags;
+        wa.ray_shift = ray_shift;
+        wa.defer_all = occupancy_mode ? 0 : 1;
+        wa.occupancy = direct_occ;
+        wa.ray_flags = ray_flags;
+        wa.dbg_counters = (m->debug_flags & 64u) ? m->d_dbg : nullptr;
+        // The lean instantiation applies unless some ray's end voxel is part of its walk or origins are excluded.
+        const bool special = (ray_flags & (OHMHIP_RF_END_POINT_AS_FREE | OHMHIP_RF_EXCLUDE_ORIGIN)) ||
+                             m->mc.filter_mode == OHMHIP_FILTER_CLIP;
+        if (special)
+        {
+          hipLaunchKernelGGL(k_region_walk<true>, dim3(info.n_chunks), dim3(kWalkThreads), walkLdsBytes(m->mc), s, wa);
+        }
+        else
+        {
+          hipLaunchKernelGGL(k_region_walk<false>, dim3(info.n_chunks), dim3(kWalkThreads), walkLdsBytes(m->mc), s, wa);
+        }
         OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
         if (occupancy_mode)
         {
@@ -575,20 +627,20 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                          static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]));
       if (info.n_touched)
       {
-        hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
+        hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
                            batchScratch(m), ray_flags, m->d_miss_counts, m->d_hit_mask,
                            static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]), 1,
-                           static_cast<uint32_t *>(nullptr));
+                           static_cast<uint32_t *>(nullptr), direct_segments, 0);
       }
     }
     else
     {
       const size_t total = size_t(n_rays) + size_t(n_events);
       size_t sort_bytes = 0;
-      OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, keys_a, keys_b, total, 0, 64, s));
+      OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
       OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
       size_t temp_bytes = m->sort_temp.bytes;
-      OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, total, 0, 64, s));
+      OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
       const uint32_t replay_blocks = uint32_t((total + 127) / 128);
       if (ndt_mode)
       {
@@ -602,10 +654,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                            tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr);
         if (info.n_touched)
         {
-          hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
+          hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
                              batchScratch(m), 0u, m->d_miss_counts, m->d_hit_mask,
                              static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]), 0,
-                             tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr);
+                             tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr, direct_segments, 1);
         }
       }
       else
@@ -615,7 +667,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         if (info.n_touched)
         {
           hipLaunchKernelGGL(k_apply_counts_tsdf, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
-                             batchScratch(m), m->d_miss_counts, static_cast<float *>(m->layers[OHMHIP_LID_TSDF]));
+                             batchScratch(m), m->d_miss_counts, m->d_hit_mask,
+                             static_cast<float *>(m->layers[OHMHIP_LID_TSDF]));
         }
       }
     }
@@ -784,6 +837,11 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   {
     return fail(err);
   }
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_dbg), 8 * sizeof(unsigned long long))) != 0)
+  {
+    return fail(err);
+  }
+  (void)hipMemset(m->d_dbg, 0, 8 * sizeof(unsigned long long));
   if ((err = hipHostMalloc(reinterpret_cast<void **>(&m->h_info), 2 * sizeof(BatchInfo), hipHostMallocDefault)) != 0)
   {
     return fail(err);
@@ -802,7 +860,12 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   }
   // The walk kernel stages a region's count tile + hit mask in LDS (68 KiB for 32^3).
   const size_t lds_bytes = walkLdsBytes(mc);
-  if ((err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_walk),
+  if ((err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_walk<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
+  {
+    return fail(err);
+  }
+  if ((err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_walk<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
   {
     return fail(err);
@@ -1009,6 +1072,14 @@ int ohmhip_map_sync(ohmhip_map_t m)
     return OHMHIP_ERR_INVALID_ARG;
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  if (m->debug_flags & 64u)
+  {
+    unsigned long long c[8];
+    OHMHIP_CHECK(hipMemcpy(c, m->d_dbg, sizeof(c), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[ohmhip dbg] wave-iterations %llu visits %llu refills %llu flagged-iterations %llu\n", c[0], c[1], c[2],
+                 c[3]);
+    OHMHIP_CHECK(hipMemset(m->d_dbg, 0, sizeof(c)));
+  }
   OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
   return OHMHIP_OK;
 }

@@ -198,14 +198,21 @@ __global__ void __launch_bounds__(128)
 /// distance -- the fixed point of calculateTsdf for sdf >= truncation distance.
 __global__ void __launch_bounds__(256)
   k_apply_counts_tsdf(MapConst mc, RegionTable rt, BatchScratch bs, uint32_t *__restrict__ miss_counts,
-                      float *__restrict__ tsdf_layer)
+                      const uint32_t *__restrict__ hit_mask, float *__restrict__ tsdf_layer)
 {
   const uint32_t h = bs.touched[blockIdx.x];
   const uint32_t slot = rt.vals[h];
   const size_t base = size_t(slot) * size_t(mc.region_voxels);
+  const uint32_t *mask = hit_mask + size_t(slot) * (uint32_t(mc.region_voxels + 31) >> 5);
   for (uint32_t vi = threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
   {
-    const uint32_t n = miss_counts[base + vi];
+    uint32_t n = miss_counts[base + vi];
+    if (n && ((mask[vi >> 5] >> (vi & 31)) & 1u))
+    {
+      // near-surface voxel: updated by the ordered replay only
+      miss_counts[base + vi] = 0;
+      n = 0;
+    }
     if (n)
     {
       const float w = tsdf_layer[2 * (base + vi)];

@@ -86,6 +86,17 @@ __device__ inline void splitGlobal(int g, int dim, int &region, int &local)
   local = r;
 }
 
+/// Local voxel coordinate of a global voxel coordinate (floor modulo); a mask when the region edge is a power of two.
+__device__ inline int localCoord(int g, int dim)
+{
+  if ((dim & (dim - 1)) == 0)
+  {
+    return g & (dim - 1);
+  }
+  int r = g % dim;
+  return (r < 0) ? r + dim : r;
+}
+
 /// Time at which the j-th step (j >= 1) along an axis is taken: the value `time_next[axis]` holds after j-1 steps on
 /// that axis (ohm/LineWalkCompute.h:299-301 and :375-378).
 __device__ inline double stepTime(double init, double delta, int j)
