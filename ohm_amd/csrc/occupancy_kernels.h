@@ -218,20 +218,175 @@ __device__ inline uint64_t shfl64(uint64_t v, int src)
   return (uint64_t(hi) << 32) | lo;
 }
 
+/// Wave-level match: for every lane with `has`, find the lowest lane holding the same 32-bit value and the mask of all
+/// lanes holding it.  Compute only (no memory traffic), one loop trip per distinct value in the wave.
+__device__ inline void waveMatch(bool has, uint32_t value, unsigned lane, int &leader, unsigned long long &group)
+{
+  leader = -1;
+  group = 0;
+  unsigned long long todo = __ballot(has);
+  while (todo)
+  {
+    const int l = __ffsll((long long)todo) - 1;
+    const uint32_t lv = __shfl(value, l);
+    const bool mine = has && value == lv;
+    const unsigned long long same = __ballot(mine);
+    if (mine)
+    {
+      leader = l;
+      group = same;
+    }
+    todo &= ~same;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// k_ray_setup
+// Block-level region table in LDS.
+//
+// Rays of one workgroup cross the same few dozen regions.  Counting (k_ray_setup) and bucket reservation (k_ray_bin)
+// therefore aggregate per workgroup in an LDS hash table and touch each global per-region counter ONCE per workgroup:
+// the per-region counters of the regions around a sensor are otherwise hit by every wave of the launch, and atomics on
+// one address serialise at the memory side (that, not arithmetic, dominated the first version of these kernels).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+constexpr int kBinThreads = 512;
+constexpr int kBinRaysPerBlock = 2048;
+constexpr uint32_t kLtabSize = 2048;  ///< entries (power of two)
+
+struct LdsRegionTable
+{
+  unsigned long long keys[kLtabSize];
+  uint32_t count[kLtabSize];   ///< segments of this workgroup in the region
+  uint32_t cursor[kLtabSize];  ///< k_ray_bin: next free position (global index) of the workgroup's reserved range
+};
+
+/// Find or insert `key`; returns the entry index or kLtabSize when the table is full (caller falls back to global).
+__device__ inline uint32_t ltabFindOrInsert(LdsRegionTable &tab, uint64_t key)
+{
+  uint32_t idx = hashRegionKey(key, kLtabSize - 1);
+  for (uint32_t probe = 0; probe < 64; ++probe)
+  {
+    unsigned long long prev = tab.keys[idx];
+    if (prev == 0)
+    {
+      prev = atomicCAS(&tab.keys[idx], 0ull, (unsigned long long)key);
+    }
+    if (prev == 0 || prev == key)
+    {
+      return idx;
+    }
+    idx = (idx + 1) & (kLtabSize - 1);
+  }
+  return kLtabSize;
+}
+
+__device__ inline uint32_t ltabFind(const LdsRegionTable &tab, uint64_t key)
+{
+  uint32_t idx = hashRegionKey(key, kLtabSize - 1);
+  for (uint32_t probe = 0; probe < 64; ++probe)
+  {
+    const unsigned long long k = tab.keys[idx];
+    if (k == key)
+    {
+      return idx;
+    }
+    if (k == 0)
+    {
+      break;
+    }
+    idx = (idx + 1) & (kLtabSize - 1);
+  }
+  return kLtabSize;
+}
+
+/// Walk the regions a ray crosses and call f(region key, s0, s1, s2, first) for every ray-region segment which
+/// produces at least one miss visit.  (s0, s1, s2) are the per-axis step counts at the moment the region is entered.
+template <typename F>
+__device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, bool with_resume_state, F f)
+{
+  if (!(rw.flags & kRwValid) || !(rw.flags & kRwWalk))
+  {
+    return;
+  }
+  const int manhattan = rw.total[0] + rw.total[1] + rw.total[2];
+  const bool include_end = (rw.flags & kRwIncludeEnd) != 0;
+  RegionCursor rc;
+  regionCursorInit(mc, rw, rc);
+  if (manhattan > 0 || include_end)
+  {
+    f(packRegionKey(rc.region[0], rc.region[1], rc.region[2]), kSegFirst, 0u, 0u);
+  }
+  int axis, j;
+  while (regionCursorNext(mc, rw, rc, axis, j))
+  {
+    // Entering a region at the ray's end voxel only produces work when the end voxel is part of the ray.
+    if (stepReachesEnd(rw, axis, j) && !include_end)
+    {
+      continue;
+    }
+    uint32_t rs0 = 0, rs1 = 0, rs2 = 0;
+    if (with_resume_state)
+    {
+      const double ta = stepTime(sel3(axis, rw.init[0], rw.init[1], rw.init[2]),
+                                 sel3(axis, rw.delta[0], rw.delta[1], rw.delta[2]), j);
+      rs0 = uint32_t((axis == 0) ? j : stepsBefore(rw.init[0], rw.delta[0], rw.total[0], 0, axis, ta));
+      rs1 = uint32_t((axis == 1) ? j : stepsBefore(rw.init[1], rw.delta[1], rw.total[1], 1, axis, ta));
+      rs2 = uint32_t((axis == 2) ? j : stepsBefore(rw.init[2], rw.delta[2], rw.total[2], 2, axis, ta));
+    }
+    f(packRegionKey(rc.region[0], rc.region[1], rc.region[2]), rs0, rs1, rs2);
+  }
+}
+
+/// Region / voxel of the ray's sample (end) voxel.
+__device__ inline void sampleVoxel(const MapConst &mc, const RayWalk &rw, uint64_t &region_key, uint32_t &vi)
+{
+  int r1[3], l1[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    splitGlobal(rw.g0[a] + rwDir(rw, a) * rw.total[a], mc.dim[a], r1[a], l1[a]);
+  }
+  region_key = packRegionKey(r1[0], r1[1], r1[2]);
+  vi = uint32_t(l1[0] + l1[1] * mc.dim[0] + l1[2] * mc.dim[0] * mc.dim[1]);
+}
+
+__device__ inline void markTouched(const BatchScratch &bs, uint32_t h)
+{
+  if (bs.touched_flag[h] == 0 && atomicExch(&bs.touched_flag[h], 1u) == 0)
+  {
+    const uint32_t t = atomicAdd(&bs.info->n_touched, 1u);
+    bs.touched[t] = h;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ray_setup: per-ray line-walk set-up + per-region segment counts.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBinThreads)
   k_ray_setup(MapConst mc, RegionTable rt, BatchScratch bs, const double *__restrict__ rays, uint32_t n_rays,
               unsigned ray_flags, RayWalk *__restrict__ walks)
 {
-  const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned lane = laneId();
-  RayWalk rw;
-  rw.flags = 0;
-  bool valid = false;
-  if (ray < n_rays)
+  __shared__ LdsRegionTable tab;
+  __shared__ unsigned long long s_visits;
+  __shared__ uint32_t s_rays_ok;
+  for (uint32_t i = threadIdx.x; i < kLtabSize; i += kBinThreads)
   {
+    tab.keys[i] = 0;
+    tab.count[i] = 0;
+  }
+  if (threadIdx.x == 0)
+  {
+    s_visits = 0;
+    s_rays_ok = 0;
+  }
+  __syncthreads();
+
+  const uint32_t first = blockIdx.x * kBinRaysPerBlock;
+  const uint32_t last = min(first + kBinRaysPerBlock, n_rays);
+  unsigned long long my_visits = 0;
+  uint32_t my_ok = 0;
+  for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
+  {
+    RayWalk rw;
     double start[3], end[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -241,128 +396,68 @@ __global__ void __launch_bounds__(256)
     }
     setupRay(mc, start, end, ray_flags, rw);
     walks[ray] = rw;
-    valid = (rw.flags & kRwValid) != 0;
-  }
+    if (!(rw.flags & kRwValid))
+    {
+      continue;
+    }
+    ++my_ok;
+    // Visit accounting: Manhattan extent == number of voxels the walk reports before the end voxel.
+    const int manhattan = rw.total[0] + rw.total[1] + rw.total[2];
+    if (rw.flags & kRwWalk)
+    {
+      my_visits += (unsigned long long)manhattan;
+      my_visits -= ((rw.flags & kRwExcludeStart) && manhattan > 0) ? 1u : 0u;
+      my_visits += (rw.flags & kRwIncludeEnd) ? 1u : 0u;
+    }
+    my_visits += (rw.flags & kRwApplySample) ? 1u : 0u;
 
-  // Visit accounting: Manhattan extent == number of voxels the walk reports before the end voxel.
-  unsigned long long my_visits = 0;
-  const bool walk = valid && (rw.flags & kRwWalk);
-  const int manhattan = rw.total[0] + rw.total[1] + rw.total[2];
-  if (walk)
-  {
-    my_visits += (unsigned long long)manhattan;
-    if ((rw.flags & kRwExcludeStart) && manhattan > 0)
-    {
-      --my_visits;
-    }
-    if (rw.flags & kRwIncludeEnd)
-    {
-      ++my_visits;
-    }
-  }
-  if (valid && (rw.flags & kRwApplySample))
-  {
-    ++my_visits;
-  }
-  // Wave reduce then one atomic per wave.
-  unsigned long long v = my_visits;
-  unsigned long long ok = valid ? 1ull : 0ull;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-  {
-    v += shfl64(v, lane ^ off);
-    ok += shfl64(ok, lane ^ off);
-  }
-  if (lane == 0)
-  {
-    atomicAdd(&bs.info->visits, v);
-    atomicAdd(&bs.info->rays_ok, ok);
-  }
-
-  // Region enumeration.  Every iteration handles at most one (ray, region) segment per lane; lanes holding the same
-  // region are aggregated so the hash probe and the counter atomic happen once per group.
-  RegionCursor rc;
-  if (valid)
-  {
-    regionCursorInit(mc, rw, rc);
-  }
-  // phase 0: first segment (start region); phase 1: crossings; phase 2: sample region registration; 3: done
-  int phase = valid ? 0 : 3;
-  if (valid && !walk)
-  {
-    phase = 2;
-  }
-  while (__any(phase < 3))
-  {
-    bool has = false;
-    bool is_segment = false;
-    uint64_t key = 0;
-    if (phase == 0)
-    {
-      // The first segment exists if the start voxel (or, for a zero-extent ray, the end voxel) gets a miss visit.
-      const bool any_visit = manhattan > 0 || (rw.flags & kRwIncludeEnd);
-      has = any_visit;
-      is_segment = any_visit;
-      key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
-      phase = 1;
-    }
-    else if (phase == 1)
-    {
-      int axis, j;
-      if (regionCursorNext(mc, rw, rc, axis, j))
+    forEachSegment(mc, rw, false, [&](uint64_t key, uint32_t, uint32_t, uint32_t) {
+      const uint32_t e = ltabFindOrInsert(tab, key);
+      if (e < kLtabSize)
       {
-        // Entering a region at the ray's end voxel only produces work when the end voxel is part of the ray.
-        const bool at_end = stepReachesEnd(rw, axis, j);
-        has = !at_end || (rw.flags & kRwIncludeEnd);
-        is_segment = has;
-        key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
+        atomicAdd(&tab.count[e], 1u);
       }
       else
       {
-        phase = 2;
+        // LDS table full (very long rays): count straight in the global table.
+        const uint32_t h = regionInsert(rt, key, &bs.info->error);
+        atomicAdd(&bs.seg_count[h], 1u);
+        markTouched(bs, h);
+      }
+    });
+    if (rw.flags & kRwApplySample)
+    {
+      // The sample's region must exist (and be listed as touched) even when no segment enters it.
+      uint64_t key;
+      uint32_t vi;
+      sampleVoxel(mc, rw, key, vi);
+      if (ltabFindOrInsert(tab, key) >= kLtabSize)
+      {
+        markTouched(bs, regionInsert(rt, key, &bs.info->error));
       }
     }
-    if (phase == 2 && !has)
+  }
+  atomicAdd(&s_visits, my_visits);
+  atomicAdd(&s_rays_ok, my_ok);
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    atomicAdd(&bs.info->visits, s_visits);
+    atomicAdd(&bs.info->rays_ok, (unsigned long long)s_rays_ok);
+  }
+  // One global insert + one counter atomic per (workgroup, region).
+  for (uint32_t e = threadIdx.x; e < kLtabSize; e += kBinThreads)
+  {
+    const unsigned long long key = tab.keys[e];
+    if (key)
     {
-      if (rw.flags & kRwApplySample)
+      const uint32_t h = regionInsert(rt, key, &bs.info->error);
+      const uint32_t c = tab.count[e];
+      if (c)
       {
-        int r1[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-        {
-          int local;
-          splitGlobal(rw.g0[a] + rwDir(rw, a) * rw.total[a], mc.dim[a], r1[a], local);
-        }
-        has = true;
-        is_segment = false;
-        key = packRegionKey(r1[0], r1[1], r1[2]);
+        atomicAdd(&bs.seg_count[h], c);
       }
-      phase = 3;
-    }
-
-    unsigned long long todo = __ballot(has);
-    while (todo)
-    {
-      const int leader = __ffsll((long long)todo) - 1;
-      const uint64_t lkey = shfl64(key, leader);
-      const bool mine = has && key == lkey;
-      const unsigned long long same = __ballot(mine);
-      const unsigned long long seg_same = __ballot(mine && is_segment);
-      if (lane == unsigned(leader))
-      {
-        const uint32_t h = regionInsert(rt, lkey, &bs.info->error);
-        const uint32_t nseg = __popcll(seg_same);
-        if (nseg)
-        {
-          atomicAdd(&bs.seg_count[h], nseg);
-        }
-        if (bs.touched_flag[h] == 0 && atomicExch(&bs.touched_flag[h], 1u) == 0)
-        {
-          const uint32_t t = atomicAdd(&bs.info->n_touched, 1u);
-          bs.touched[t] = h;
-        }
-      }
-      todo &= ~same;
+      markTouched(bs, h);
     }
   }
 }
@@ -456,128 +551,108 @@ __global__ void __launch_bounds__(1024)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_ray_bin: scatter segments to region buckets, emit hit sort keys, set per-region hit bitmask.
+// k_ray_bin: scatter segments to region buckets, emit sample sort keys, set the per-region sample bitmask.
+// Three steps per workgroup: count its segments per region in LDS, reserve one contiguous range per region with a
+// single returning atomic, then re-enumerate and scatter through LDS cursors.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kBinThreads)
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
             uint32_t *__restrict__ hit_mask, int ray_shift)
 {
-  const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned lane = laneId();
-  RayWalk rw;
-  rw.flags = 0;
-  if (ray < n_rays)
+  __shared__ LdsRegionTable tab;
+  __shared__ uint32_t s_hits;
+  for (uint32_t i = threadIdx.x; i < kLtabSize; i += kBinThreads)
   {
-    rw = walks[ray];
+    tab.keys[i] = 0;
+    tab.count[i] = 0;
+    tab.cursor[i] = 0;
   }
-  const bool valid = (rw.flags & kRwValid) != 0;
-  const bool walk = valid && (rw.flags & kRwWalk);
-  const int manhattan = rw.total[0] + rw.total[1] + rw.total[2];
-
-  // Hit key.
-  bool is_hit = false;
-  if (ray < n_rays)
+  if (threadIdx.x == 0)
   {
+    s_hits = 0;
+  }
+  __syncthreads();
+
+  const uint32_t first = blockIdx.x * kBinRaysPerBlock;
+  const uint32_t last = min(first + kBinRaysPerBlock, n_rays);
+  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
+
+  // Step 1: per-region segment counts of this workgroup; sample keys and mask bits on the way.
+  uint32_t my_hits = 0;
+  for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
+  {
+    const RayWalk rw = walks[ray];
     unsigned long long hk = kHitInvalid;
-    if (valid && (rw.flags & kRwApplySample))
+    if ((rw.flags & kRwValid) && (rw.flags & kRwApplySample))
     {
-      int r1[3], l1[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-      {
-        splitGlobal(rw.g0[a] + rwDir(rw, a) * rw.total[a], mc.dim[a], r1[a], l1[a]);
-      }
-      const uint32_t h = regionFind(rt, packRegionKey(r1[0], r1[1], r1[2]));
+      uint64_t key;
+      uint32_t vi;
+      sampleVoxel(mc, rw, key, vi);
+      const uint32_t h = regionFind(rt, key);
       const uint32_t slot = (h != 0xffffffffu) ? rt.vals[h] : kSlotUnassigned;
       if (slot < rt.slot_capacity)
       {
-        const uint32_t vi = uint32_t(l1[0] + l1[1] * mc.dim[0] + l1[2] * mc.dim[0] * mc.dim[1]);
         // ray_shift == 1 (NDT / TSDF event streams): the low bit tags the key as a sample (hit) event.
         hk = ((unsigned long long)slot << kHitSlotShift) | ((unsigned long long)vi << kHitRayBits) |
              ((unsigned long long)ray << ray_shift) | (unsigned long long)(ray_shift ? 1u : 0u);
-        atomicOr(&hit_mask[size_t(slot) * (size_t(mc.region_voxels + 31) / 32) + (vi >> 5)], 1u << (vi & 31));
-        is_hit = true;
+        atomicOr(&hit_mask[size_t(slot) * mask_words + (vi >> 5)], 1u << (vi & 31));
+        ++my_hits;
       }
     }
     hit_keys[ray] = hk;
-  }
-  {
-    const unsigned long long hit_lanes = __ballot(is_hit);
-    if (lane == 0 && hit_lanes)
-    {
-      atomicAdd(&bs.info->n_hits, uint32_t(__popcll(hit_lanes)));
-    }
-  }
-
-  RegionCursor rc;
-  if (walk)
-  {
-    regionCursorInit(mc, rw, rc);
-  }
-  int phase = walk ? 0 : 2;
-  while (__any(phase < 2))
-  {
-    bool has = false;
-    uint64_t key = 0;
-    uint32_t rs0 = 0, rs1 = 0, rs2 = 0;
-    if (phase == 0)
-    {
-      has = manhattan > 0 || (rw.flags & kRwIncludeEnd);
-      key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
-      rs0 = kSegFirst;
-      phase = 1;
-    }
-    else if (phase == 1)
-    {
-      int axis, j;
-      if (regionCursorNext(mc, rw, rc, axis, j))
+    forEachSegment(mc, rw, false, [&](uint64_t key, uint32_t, uint32_t, uint32_t) {
+      const uint32_t e = ltabFindOrInsert(tab, key);
+      if (e < kLtabSize)
       {
-        const bool at_end = stepReachesEnd(rw, axis, j);
-        has = !at_end || (rw.flags & kRwIncludeEnd);
-        key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
-        // Resume state: steps taken per axis at the moment the region is entered.
-        const double ta = stepTime(sel3(axis, rw.init[0], rw.init[1], rw.init[2]),
-                                   sel3(axis, rw.delta[0], rw.delta[1], rw.delta[2]), j);
-        rs0 = uint32_t((axis == 0) ? j : stepsBefore(rw.init[0], rw.delta[0], rw.total[0], 0, axis, ta));
-        rs1 = uint32_t((axis == 1) ? j : stepsBefore(rw.init[1], rw.delta[1], rw.total[1], 1, axis, ta));
-        rs2 = uint32_t((axis == 2) ? j : stepsBefore(rw.init[2], rw.delta[2], rw.total[2], 2, axis, ta));
+        atomicAdd(&tab.count[e], 1u);
+      }
+    });
+  }
+  atomicAdd(&s_hits, my_hits);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_hits)
+  {
+    atomicAdd(&bs.info->n_hits, s_hits);
+  }
+  // Step 2: reserve this workgroup's range in every region bucket it feeds.
+  for (uint32_t e = threadIdx.x; e < kLtabSize; e += kBinThreads)
+  {
+    const unsigned long long key = tab.keys[e];
+    const uint32_t c = tab.count[e];
+    if (key && c)
+    {
+      const uint32_t h = regionFind(rt, key);
+      tab.cursor[e] = bs.seg_offset[h] + atomicAdd(&bs.seg_cursor[h], c);
+    }
+  }
+  __syncthreads();
+  // Step 3: scatter.
+  for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
+  {
+    const RayWalk rw = walks[ray];
+    forEachSegment(mc, rw, true, [&](uint64_t key, uint32_t rs0, uint32_t rs1, uint32_t rs2) {
+      const uint32_t e = ltabFind(tab, key);
+      uint32_t pos;
+      if (e < kLtabSize)
+      {
+        pos = atomicAdd(&tab.cursor[e], 1u);
       }
       else
       {
-        phase = 2;
+        const uint32_t h = regionFind(rt, key);  // table overflow: straight to the global cursor
+        pos = bs.seg_offset[h] + atomicAdd(&bs.seg_cursor[h], 1u);
       }
-    }
-
-    unsigned long long todo = __ballot(has);
-    while (todo)
-    {
-      const int leader = __ffsll((long long)todo) - 1;
-      const uint64_t lkey = shfl64(key, leader);
-      const bool mine = has && key == lkey;
-      const unsigned long long same = __ballot(mine);
-      uint32_t base = 0;
-      if (lane == unsigned(leader))
+      if (pos < segment_capacity)
       {
-        const uint32_t h = regionFind(rt, lkey);
-        base = bs.seg_offset[h] + atomicAdd(&bs.seg_cursor[h], uint32_t(__popcll(same)));
+        Segment sg;
+        sg.ray = ray;
+        sg.s0 = rs0;
+        sg.s1 = rs1;
+        sg.s2 = rs2;
+        segments[pos] = sg;
       }
-      base = __shfl(base, leader);
-      if (mine)
-      {
-        const uint32_t pos = base + __popcll(same & ((1ull << lane) - 1ull));
-        if (pos < segment_capacity)
-        {
-          Segment s;
-          s.ray = ray;
-          s.s0 = rs0;
-          s.s1 = rs1;
-          s.s2 = rs2;
-          segments[pos] = s;
-        }
-      }
-      todo &= ~same;
-    }
+    });
   }
 }
 
@@ -739,8 +814,8 @@ __device__ inline uint32_t subVoxelUpdate(uint32_t coord, uint32_t point_count, 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kWalkThreads = 1024;
 constexpr int kWalkWaves = kWalkThreads / 64;
-constexpr int kQueueCap = 256;     ///< deferred events per wave (8 B each)
-constexpr int kLdsHits = 4096;     ///< a region's sample list is staged in LDS when it has at most this many samples
+constexpr int kQueueCap = 128;     ///< deferred events per wave (8 B each)
+constexpr int kLdsHits = 7168;     ///< a region's sample list is staged in LDS when it has at most this many samples
 constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
 
 /// Resolve one deferred miss event: find the first sample of the same voxel with a larger ray index; the miss counts
@@ -802,7 +877,7 @@ __device__ inline void flushQueue(const unsigned long long *queue, uint32_t qcou
       {
         // Belongs before a later sample of the voxel: move it from the voxel's count to that sample's interval.
         const uint32_t vi = uint32_t(ev >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
-        atomicAdd(&l_intervals[lo], 1u);
+        atomicAdd(&l_intervals[lo >> 1], 1u << ((lo & 1u) * 16u));
         atomicSub(&l_counts[vi >> 1], 1u << ((vi & 1u) * 16u));
       }
     }
@@ -865,8 +940,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
   unsigned long long *l_queues = reinterpret_cast<unsigned long long *>(lds);
   unsigned long long *l_hits = l_queues + kWalkWaves * kQueueCap;           // [kLdsHits] region's sorted sample keys
-  uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] interval counters
-  uint32_t *l_counts = l_intervals + kLdsHits;
+  uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] u16 interval counters
+  uint32_t *l_counts = l_intervals + kLdsHits / 2;
   uint32_t *l_mask = l_counts + count_words;
   uint32_t *l_cursor = l_mask + mask_words;
 
@@ -895,7 +970,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
     {
       l_hits[i] = args.sorted_hits[hb + i];
-      l_intervals[i] = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < (n_region_hits + 1) / 2; i += kWalkThreads)
+    {
+      l_intervals[i] = 0;  // two u16 counters per word (a chunk adds at most kChunkSegments to one counter)
     }
   }
   __syncthreads();
@@ -913,10 +991,13 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   const unsigned dbg = args.dbg;
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
-  // Per-lane walk state (all named scalars: no run-time indexed arrays).
-  bool active = false;
-  bool skip = false;         // kSpecial only
-  bool include_end = false;  // kSpecial only
+  // Per-lane walk state (all named scalars: no run-time indexed arrays).  Predicates that feed back into the walk
+  // state are kept as 0/1 integers in VGPRs and combined arithmetically: lane-mask logic would bounce every
+  // dependency through the scalar ALU (VALU -> SALU -> VALU costs tens of cycles per hop and this loop is a chain of
+  // such hops).
+  uint32_t act = 0;          // 1 while the lane has a voxel to visit / steps to take
+  uint32_t skip = 0;         // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
+  uint32_t include_end = 0;  // kSpecial only: the end voxel takes a miss too
   double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
   double t0 = 0, t1 = 0, t2 = 0, k0 = 0, k1 = 0, k2 = 0;  // time_next / steps taken per axis
   int room0 = 0, room1 = 0, room2 = 0, rem0 = 0, rem1 = 0, rem2 = 0;
@@ -930,7 +1011,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   while (true)
   {
     // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
-    unsigned long long am = __ballot(active);
+    unsigned long long am = __ballot(act != 0);
     const int n_idle = 64 - __popcll(am);
     if (!exhausted && (n_idle >= refill_min_idle))
     {
@@ -944,7 +1025,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       base = __shfl(base, 0);
       exhausted = base + uint32_t(n_idle) >= n_seg;
       const uint32_t mine = base + uint32_t(__popcll(idle & lane_lt));
-      if (!active && mine < n_seg)
+      if (act == 0 && mine < n_seg)
       {
         const Segment seg = args.segments[chunk.seg_begin + mine];
         const RayWalk rw = args.walks[seg.ray];
@@ -985,18 +1066,18 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         ray = seg.ray;
         if (kSpecial)
         {
-          skip = first_segment && (rw.flags & kRwExcludeStart);
-          include_end = (rw.flags & kRwIncludeEnd) != 0;
-          active = true;
+          skip = (first_segment && (rw.flags & kRwExcludeStart)) ? 1u : 0u;
+          include_end = (rw.flags & kRwIncludeEnd) ? 1u : 0u;
+          act = 1u;
         }
         else
         {
           // A segment whose entry voxel is the ray's end voxel never exists here (k_ray_bin drops it).
-          active = (rem0 | rem1 | rem2) != 0;
+          act = ((rem0 | rem1 | rem2) != 0) ? 1u : 0u;
         }
-        active = active && !(dbg & 16u);
+        act = (dbg & 16u) ? 0u : act;
       }
-      am = __ballot(active);
+      am = __ballot(act != 0);
     }
     if (am == 0)
     {
@@ -1005,8 +1086,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 
     // ---- visit: count the miss.  Masked voxels (which also receive samples) are counted too; the ordering pass
     // ---- moves such a miss to an interval counter when a later sample of the voxel exists.
-    const bool at_end = kSpecial ? ((rem0 | rem1 | rem2) == 0) : false;
-    const bool visit = kSpecial ? (active && (at_end ? include_end : !skip)) : active;
+    const uint32_t not_end = kSpecial ? uint32_t(min(uint32_t(rem0 | rem1 | rem2), 1u)) : 1u;
+    // kSpecial: at the end voxel visit iff include_end, elsewhere iff !skip.
+    const uint32_t visit = kSpecial ? (act & (not_end ? (skip ^ 1u) : include_end)) : act;
     const uint32_t vi_visit = vi;
     uint32_t mword = 0;
     if (visit)
@@ -1019,64 +1101,63 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     }
     if (kSpecial)
     {
-      skip = false;
+      skip = 0;
     }
     ++dbg_iters;
 
-    // ---- one branch-free walk step.  All three axes' candidate updates are computed (independent fp64 chains, no
-    // ---- exec-mask juggling); the selected axis' values are committed with selects.
+    // ---- one branch-free walk step.  The axis is an integer in a VGPR (3 == no step); all three axes' candidate
+    // ---- updates are computed (independent fp64 chains) and committed with selects on (axis == a).
     // ---- walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
     {
-      const bool stepping = kSpecial ? (active && !at_end) : active;
-      const bool c01 = t0 < t1;
-      const double t01 = c01 ? t0 : t1;
-      const bool c2 = t01 < t2;
-      const bool is2 = stepping && !c2;
-      const bool is0 = stepping && c2 && c01;
-      const bool is1 = stepping && c2 && !c01;
+      const uint32_t stepping = kSpecial ? (act & not_end) : act;
+      int axis = (t0 < t1) ? 0 : 1;
+      const double t01 = (t0 < t1) ? t0 : t1;
+      axis = (t01 < t2) ? axis : 2;
+      axis = stepping ? axis : 3;
       const double k0n = k0 + 1.0;
       const double k1n = k1 + 1.0;
       const double k2n = k2 + 1.0;
       const double t0n = i0 + e0 * k0n;  // ohm/LineWalkCompute.h:299-301
       const double t1n = i1 + e1 * k1n;
       const double t2n = i2 + e2 * k2n;
-      rem0 -= int(is0);
-      rem1 -= int(is1);
-      rem2 -= int(is2);
-      room0 -= int(is0);
-      room1 -= int(is1);
-      room2 -= int(is2);
-      k0 = is0 ? k0n : k0;
-      k1 = is1 ? k1n : k1;
-      k2 = is2 ? k2n : k2;
-      t0 = is0 ? (rem0 ? t0n : inf) : t0;
-      t1 = is1 ? (rem1 ? t1n : inf) : t1;
-      t2 = is2 ? (rem2 ? t2n : inf) : t2;
-      vi += uint32_t(is0 ? sx : (is1 ? sy : (is2 ? sz : 0)));
-      const bool inside = (room0 | room1 | room2) >= 0;
-      if (kSpecial)
-      {
-        active = stepping && inside;
-      }
-      else
-      {
-        // Retire on leaving the region or on reaching the end voxel (which takes no miss).
-        active = stepping && inside && ((rem0 | rem1 | rem2) != 0);
-      }
+      rem0 -= (axis == 0);
+      rem1 -= (axis == 1);
+      rem2 -= (axis == 2);
+      room0 -= (axis == 0);
+      room1 -= (axis == 1);
+      room2 -= (axis == 2);
+      k0 = (axis == 0) ? k0n : k0;
+      k1 = (axis == 1) ? k1n : k1;
+      k2 = (axis == 2) ? k2n : k2;
+      const double t0m = rem0 ? t0n : inf;
+      const double t1m = rem1 ? t1n : inf;
+      const double t2m = rem2 ? t2n : inf;
+      t0 = (axis == 0) ? t0m : t0;
+      t1 = (axis == 1) ? t1m : t1;
+      t2 = (axis == 2) ? t2m : t2;
+      int stride = (axis == 0) ? sx : 0;
+      stride = (axis == 1) ? sy : stride;
+      stride = (axis == 2) ? sz : stride;
+      vi += uint32_t(stride);
+      // inside: no room counter went negative (sign bit of the OR); more: steps remain (non-negative values).
+      const uint32_t inside = (uint32_t(room0 | room1 | room2) >> 31) ^ 1u;
+      const uint32_t more = min(uint32_t(rem0 | rem1 | rem2), 1u);
+      // Retire on leaving the region; the lean instantiation also retires on reaching the end voxel (no miss there).
+      act = kSpecial ? (stepping & inside) : (stepping & inside & more);
     }
 
     // ---- deferred ordering of misses on masked voxels (the mask word was fetched before the step: its LDS latency
     // ---- overlaps the step arithmetic).
-    const bool flagged = visit && ((mword >> (vi_visit & 31)) & 1u) && !(dbg & 10u);
-    const unsigned long long fm = __ballot(flagged);
+    const uint32_t flagged = (dbg & 10u) ? 0u : (visit & (mword >> (vi_visit & 31)));
+    const unsigned long long fm = __ballot((flagged & 1u) != 0);
     if (args.dbg_counters)
     {
-      dbg_active += uint32_t(__popcll(__ballot(visit)));
+      dbg_active += uint32_t(__popcll(__ballot(visit != 0)));
       dbg_fm += fm ? 1u : 0u;
     }
     if (fm)
     {
-      if (flagged)
+      if (flagged & 1u)
       {
         queue[qcount + uint32_t(__popcll(fm & lane_lt))] =
           slot_bits | ((unsigned long long)vi_visit << kHitRayBits) | ((unsigned long long)ray << ray_shift);
@@ -1112,7 +1193,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   {
     for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
     {
-      const uint32_t c = l_intervals[i];
+      const uint32_t c = (l_intervals[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
       if (c)
       {
         atomicAdd(&args.interval_counts[hb + i], c);

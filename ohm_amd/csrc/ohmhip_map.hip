@@ -403,7 +403,7 @@ unsigned sortEndBit(ohmhip_map_t m)
 
 size_t walkLdsBytes(const MapConst &mc)
 {
-  return (size_t(2 * kWalkWaves * kQueueCap) + size_t(3 * kLdsHits) + size_t((mc.region_voxels + 1) / 2) +
+  return (size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) + size_t((mc.region_voxels + 1) / 2) +
           size_t((mc.region_voxels + 31) / 32) + 4) *
          sizeof(uint32_t);
 }
@@ -424,6 +424,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
 {
   hipStream_t s = m->stream;
   const uint32_t ray_blocks = (n_rays + 255) / 256;
+  const uint32_t bin_blocks = (n_rays + kBinRaysPerBlock - 1) / kBinRaysPerBlock;
   const int mode = m->config.mode;
   const bool occupancy_mode = mode == OHMHIP_MODE_OCCUPANCY;
   const bool ndt_mode = mode == OHMHIP_MODE_NDT_OM || mode == OHMHIP_MODE_NDT_TM;
@@ -457,7 +458,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   {
     OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, sizeof(BatchInfo), s));
     OHMHIP_CHECK(hipEventRecord(m->ev[0], s));
-    hipLaunchKernelGGL(k_ray_setup, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
+    hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(kBinThreads), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
                        n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr));
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
                        m->chunk_capacity, m->chunk_segments);
@@ -511,7 +512,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       event_capacity = uint32_t(std::min<size_t>(std::min(cap_a, cap_b), 0xfffffff0u - n_rays));
     }
 
-    hipLaunchKernelGGL(k_ray_bin, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
+    hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(kBinThreads), 0, s, m->mc, regionTable(m), batchScratch(m),
                        static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
                        seg_cap, keys_a, m->d_hit_mask, ray_shift);
     if (tsdf_mode)
