@@ -221,10 +221,14 @@ int ohmhip_map_write_regions(ohmhip_map_t map, int layer_id, const int16_t *keys
 /* GpuCache::clear / MapRegionCache::remove (ohmgpu/GpuCache.cpp, ohm/MapRegionCache.h): drop all regions. */
 int ohmhip_map_clear(ohmhip_map_t map);
 
-/* Multi-GPU occupancy merge support: export / import additive per-region miss/hit count deltas. See
- * DESIGN.md.  (Declared for round 2; returns OHMHIP_ERR_UNSUPPORTED until implemented.) */
+/* Multi-GPU merge support (no reference equivalent -- ohm is single device).  The resident layer of a
+ * map is one allocation of region_stride_bytes per slot: ohm_amd/distributed.py wraps it as a device tensor and runs
+ * the RCCL all-reduce of touched-region occupancy deltas on it.  ensure_regions makes regions resident (cleared)
+ * without touching their data and returns their slots; mark_dirty flags slots for the next syncVoxels(). */
 int ohmhip_map_device_layer_ptr(ohmhip_map_t map, int layer_id, void **device_ptr, size_t *region_stride_bytes);
 int ohmhip_map_region_slot(ohmhip_map_t map, const int16_t key_xyz[3], uint32_t *slot);
+int ohmhip_map_ensure_regions(ohmhip_map_t map, const int16_t *keys_xyz, size_t count, uint32_t *slots);
+int ohmhip_map_mark_dirty(ohmhip_map_t map, const uint32_t *slots, size_t count);
 
 #ifdef __cplusplus
 }

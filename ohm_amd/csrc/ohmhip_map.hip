@@ -1411,6 +1411,79 @@ int ohmhip_map_write_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_x
   return OHMHIP_OK;
 }
 
+int ohmhip_map_ensure_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, uint32_t *slots)
+{
+  if (!m || (count && !keys_xyz))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  int err = refreshHostRegionTable(m);
+  if (err)
+  {
+    return err;
+  }
+  const uint32_t old = m->slots_committed;
+  for (size_t i = 0; i < count; ++i)
+  {
+    const uint64_t key = packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]);
+    auto it = m->region_slots.find(key);
+    if (it == m->region_slots.end())
+    {
+      it = m->region_slots.emplace(key, uint32_t(m->slot_keys_host.size())).first;
+      m->slot_keys_host.push_back(key);
+    }
+    if (slots)
+    {
+      slots[i] = it->second;
+    }
+  }
+  const uint32_t total = uint32_t(m->slot_keys_host.size());
+  if (total > old)
+  {
+    if (total > m->slot_capacity)
+    {
+      uint32_t cap = m->slot_capacity;
+      while (cap < total)
+      {
+        cap *= 2;
+      }
+      err = allocPool(m, cap, old);
+      if (err)
+      {
+        return err;
+      }
+    }
+    OHMHIP_CHECK(hipMemcpy(m->d_slot_keys + old, m->slot_keys_host.data() + old, sizeof(uint64_t) * (total - old),
+                           hipMemcpyHostToDevice));
+    OHMHIP_CHECK(hipMemsetAsync(m->d_keys, 0, sizeof(unsigned long long) * m->hash_capacity, m->stream));
+    OHMHIP_CHECK(hipMemcpyAsync(m->d_n_slots, &total, sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_rehash, dim3((total + 255) / 256), dim3(256), 0, m->stream, regionTable(m), total);
+    OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+    m->slots_committed = total;
+  }
+  return OHMHIP_OK;
+}
+
+int ohmhip_map_mark_dirty(ohmhip_map_t m, const uint32_t *slots, size_t count)
+{
+  if (!m || (count && !slots))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  const uint32_t one = 1;
+  for (size_t i = 0; i < count; ++i)
+  {
+    if (slots[i] >= m->slot_capacity)
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+    OHMHIP_CHECK(hipMemcpyAsync(m->d_dirty + slots[i], &one, sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  return OHMHIP_OK;
+}
+
 int ohmhip_map_clear(ohmhip_map_t m)
 {
   if (!m)

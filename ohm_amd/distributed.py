@@ -1,0 +1,152 @@
+"""Multi-GPU support for the ray-integration path -- no reference equivalent: ohm is single device.
+
+Sharding: rays are partitioned by SENSOR ORIGIN (one origin / contiguous block of origins per rank).  Every rank
+integrates its shard into its own resident map with no data-path collective; that is what `bench.py --gpus N` times
+(weak scaling).
+
+Merging replicas (explicit, on demand): `merge_occupancy_deltas` reconciles per-rank occupancy layers with the additive
+log-odds rule  merged = clamp(base + sum_r (x_r - base), min, max)  over the UNION of regions the ranks touched since
+the common base state, using ONE all-reduce(sum) of the packed delta tiles (RCCL over xGMI when the tensors live on
+GPUs, gloo in the CPU tests).  An unobserved voxel (+inf) contributes base 0 and stays unobserved only if no rank
+observed it.
+
+Caveat, stated where the results are used: the additive rule equals the sequential CPU integration of the concatenated
+shards exactly when no min/max clamp engages between the shards' updates of a voxel (log-odds updates commute until
+they saturate).  Where clamps interact the merged value is the order-free sum, which is the standard map-merge
+semantic, not the sequential one.  NDT / TSDF layers are not additive: replicas only.
+
+The functions below are backend agnostic (any torch device / process group) so the protocol itself is covered by
+world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py).
+"""
+import numpy as np
+
+
+def shard_rays_by_origin(rays, world_size, rank):
+    """Partition a (2N, 3) origin/sample array by sensor-origin region: rays are grouped by their origin's 3.2 m cell
+    (32 voxels of 0.1 m) and cells are dealt to ranks round-robin in sorted order, so all rays of one sensor origin
+    land on one rank.  Deterministic and identical on every rank."""
+    rays = np.asarray(rays, dtype=np.float64).reshape(-1, 3)
+    origins = rays[0::2]
+    cells = np.floor(origins / 3.2 + 0.5).astype(np.int64)
+    uniq, inverse = np.unique(cells, axis=0, return_inverse=True)
+    owner = np.arange(len(uniq)) % world_size
+    keep = owner[inverse.reshape(-1)] == rank
+    out = np.empty((2 * int(keep.sum()), 3), dtype=np.float64)
+    out[0::2] = origins[keep]
+    out[1::2] = rays[1::2][keep]
+    return out
+
+
+def _pack_keys(keys):
+    """int16 (n, 3) region keys -> sortable int64."""
+    k = np.asarray(keys, dtype=np.int64).reshape(-1, 3)
+    return ((k[:, 0] + 32768) << 32) | ((k[:, 1] + 32768) << 16) | (k[:, 2] + 32768)
+
+
+def _unpack_keys(packed):
+    p = np.asarray(packed, dtype=np.int64)
+    return np.stack([(p >> 32) - 32768, ((p >> 16) & 0xFFFF) - 32768, (p & 0xFFFF) - 32768], axis=1).astype(np.int16)
+
+
+def union_region_keys(local_keys, group=None):
+    """All-gather the ranks' touched-region key lists and return the sorted union (identical on every rank)."""
+    import torch
+    import torch.distributed as dist
+    packed = torch.from_numpy(np.ascontiguousarray(_pack_keys(local_keys)))
+    world = dist.get_world_size(group)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, packed.numpy().tolist(), group=group)
+    union = sorted(set(k for lst in gathered for k in lst))
+    return _unpack_keys(np.array(union, dtype=np.int64)).reshape(-1, 3)
+
+
+def merge_occupancy_deltas(base_tiles, local_tiles, min_value, max_value, group=None):
+    """Additive log-odds merge of one region set.
+
+    base_tiles, local_tiles: float32 tensors (n_union_regions, region_voxels) on any device, rows in the SAME (union)
+    order on every rank; rows a rank did not touch must equal its base rows.  Returns the merged tensor (same on every
+    rank).  One all-reduce(sum) of 2 * n * V floats (delta + observed count)."""
+    import torch
+    import torch.distributed as dist
+    inf = float("inf")
+    base_obs = base_tiles != inf
+    local_obs = local_tiles != inf
+    base0 = torch.where(base_obs, base_tiles, torch.zeros_like(base_tiles))
+    local0 = torch.where(local_obs, local_tiles, torch.zeros_like(local_tiles))
+    # delta of this rank; a voxel the rank did not observe contributes nothing
+    delta = torch.where(local_obs, local0 - base0, torch.zeros_like(base0))
+    payload = torch.stack([delta, local_obs.to(delta.dtype)])
+    dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group)
+    merged = torch.clamp(base0 + payload[0], min=min_value, max=max_value)
+    observed = payload[1] > 0
+    return torch.where(observed, merged, torch.full_like(merged, inf))
+
+
+class _DeviceArray:
+    """Expose a raw HIP device pointer through __cuda_array_interface__ so torch can alias it (no copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def occupancy_tensor(gpu_map):
+    """The map's resident occupancy layer as a (region_capacity_in_use, region_voxels) float32 torch tensor aliasing
+    device memory (valid until the pool is re-allocated by growth)."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    gpu_map.wait()
+    ptr = L._vp()
+    stride = C.c_size_t(0)
+    L.check(L.lib.ohmhip_map_device_layer_ptr(gpu_map._handle, L.LID_OCCUPANCY, C.byref(ptr), C.byref(stride)))
+    n = C.c_size_t(0)
+    L.check(L.lib.ohmhip_map_region_count(gpu_map._handle, C.byref(n)))
+    voxels = stride.value // 4
+    return torch.as_tensor(_DeviceArray(ptr.value, (max(n.value, 1), voxels), "<f4"), device="cuda")
+
+
+class ReplicaMerger:
+    """Keeps the common base state of a GpuMap replica and merges replicas across ranks.
+
+    usage:  merger = ReplicaMerger(gpu_map); ... integrateRays on every rank ...; merger.merge()
+    After merge() every rank holds the same occupancy values for the union of touched regions and the merged state
+    becomes the new base."""
+
+    def __init__(self, gpu_map, group=None):
+        self.gpu_map = gpu_map
+        self.group = group
+        self._base = {}  # packed region key -> base tile (device tensor); absent == all unobserved
+
+    def _slots(self, keys):
+        import ctypes as C
+        from . import _lib as L
+        keys = np.ascontiguousarray(keys, dtype=np.int16).reshape(-1, 3)
+        slots = np.zeros(len(keys), dtype=np.uint32)
+        L.check(L.lib.ohmhip_map_ensure_regions(self.gpu_map._handle, keys.ctypes.data, len(keys), slots.ctypes.data),
+                "ensure_regions")
+        return slots
+
+    def merge(self):
+        import ctypes as C
+        import torch
+        from . import _lib as L
+        gm = self.gpu_map
+        local_keys = gm.regionKeys(dirty_only=True)
+        union = union_region_keys(local_keys, self.group)
+        if len(union) == 0:
+            return 0
+        slots = self._slots(union)  # may grow the pool: take the tensor afterwards
+        occ = occupancy_tensor(gm)
+        idx = torch.as_tensor(slots.astype(np.int64), device=occ.device)
+        local = occ[idx]
+        packed = _pack_keys(union)
+        base = torch.stack([self._base.get(int(k), torch.full_like(local[0], float("inf"))) for k in packed])
+        merged = merge_occupancy_deltas(base, local, float(gm._map.min_voxel_value), float(gm._map.max_voxel_value),
+                                        self.group)
+        occ[idx] = merged
+        torch.cuda.synchronize()
+        for i, k in enumerate(packed):
+            self._base[int(k)] = merged[i].clone()
+        L.check(L.lib.ohmhip_map_mark_dirty(gm._handle, slots.ctypes.data, len(slots)), "mark_dirty")
+        return len(union)

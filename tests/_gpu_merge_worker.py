@@ -1,0 +1,57 @@
+"""Worker for tests/test_gpu_distributed.py: runs in its own process because torch must be imported BEFORE ohm_amd when
+both are used (torch bundles its own HIP runtime; loading /opt/rocm's first makes torch lose the GPU)."""
+import os
+import socket
+import sys
+
+import torch  # noqa: E402  (first, on purpose)
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from ohm_amd import GpuMap, OccupancyMap, synth  # noqa: E402
+from ohm_amd import distributed as D  # noqa: E402
+from oracle.oracle import OracleMap  # noqa: E402
+
+
+def main():
+    assert torch.cuda.is_available()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        map_ = OccupancyMap(0.1)
+        gm = GpuMap(map_)
+        merger = D.ReplicaMerger(gm)
+        rays = synth.rays_c0(n=5000, length=4.0)
+        gm.integrateRays(rays)
+        view = D.occupancy_tensor(gm)
+        assert view.is_cuda and view.shape[1] == 32 ** 3
+        n = merger.merge()
+        assert n == len(gm.regionKeys())
+        # with one rank the merge must be the identity (base + (x - base)); do a second round on a non-trivial base
+        gm.integrateRays(rays[:2000])
+        merger.merge()
+        gm.syncVoxels()
+        om = OracleMap(0.1)
+        om.integrate_occupancy(rays)
+        om.integrate_occupancy(rays[:2000])
+        checked = 0
+        for key, layers in om.chunks().items():
+            got = map_.chunks[key]["occupancy"]
+            exp = layers["occupancy"]
+            assert np.array_equal(np.isinf(got), np.isinf(exp))
+            fin = np.isfinite(exp)
+            assert np.allclose(got[fin], exp[fin], rtol=1e-6, atol=1e-6)
+            checked += int(fin.sum())
+        print("MERGE_OK", n, checked)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
