@@ -30,14 +30,14 @@ def cpu_baseline(rays, resolution, sample_rays):
     from oracle.oracle import OracleMap
     sample = rays[: 2 * sample_rays]
     best = None
-    for _ in range(2):
+    for _ in range(3):
         om = OracleMap(resolution, (32, 32, 32), layers=("occupancy",))
         t0 = time.perf_counter()
         om.integrate_occupancy(sample)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return {"value": sample_rays / best, "unit": "rays/s", "cores": 1, "kind": "port",
-            "sample": f"first {sample_rays} rays of the same C1 batch, fresh map, best of 2, {best:.2f} s",
+            "sample": f"first {sample_rays} rays of the same C1 batch, fresh map, best of 3, {best:.2f} s",
             "visits_per_s": om.visit_count() / best}
 
 
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -120,6 +120,14 @@ def main():
     rays_ok = int(st["rays_integrated"])
     # Algorithmic bytes: 44 B per ray + 8 B per voxel visit (4 B read + 4 B write of the log-odds).
     b_alg = 44.0 * rays_ok + 8.0 * visits
+    # Measured HBM traffic of the dominant kernel: from the committed PMC profile of this same command (separate
+    # rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); bench.py itself cannot run the profiler.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            traffic = json.load(fh)["traffic_bytes_per_launch"] if world == 1 and n_rays == 1_000_000 else None
+    except Exception:
+        traffic = None
     t_walk = float(np.mean(walk_ms)) * 1e-3
     t_dev = float(np.mean(total_ms)) * 1e-3
     achieved = b_alg / t_walk / 1e9
@@ -139,7 +147,7 @@ def main():
         "config": {"workload": workload, "rays_per_step_per_gpu": n_rays, "voxel_visits_per_step": visits,
                    "regions": int(st["regions_resident"]), "ray_region_segments": int(st["ray_region_segments"])},
         "roofline": {"bound": "hbm", "kernel": "k_region_walk", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": b_alg, "kernel_ms": t_walk * 1e3,
                      "pipeline_ms": t_dev * 1e3, "pipeline_frac": b_alg / t_dev / 1e9 / HBM_PEAK_GBPS},
         "device_ms": {"setup_bin": float(st["ms_setup"]), "walk": float(st["ms_walk"]),

@@ -20,6 +20,7 @@
 #ifndef OHMHIP_OCCUPANCY_KERNELS_H
 #define OHMHIP_OCCUPANCY_KERNELS_H
 
+#include "secondary_device.h"
 #include "walk_device.h"
 
 namespace ohmhip
@@ -925,12 +926,15 @@ struct WalkArgs
   float *occupancy;  ///< non-null: single-chunk regions are applied straight from LDS
   unsigned ray_flags;
   unsigned long long *dbg_counters;
+  float *traversal;  ///< kTraversal instantiations: per-visit ray length accumulation (global float atomics)
 };
 
 /// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
 /// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every active
 /// lane sits on a voxel that takes a miss, and a lane retires the moment it steps onto its ray's end voxel.
-template <bool kSpecial>
+/// kTraversal: also accumulate the ray length inside every visited voxel (traversal layer, ohm/RayMapperOccupancy.cpp:
+/// 166-173).  Float adds in arbitrary order: that layer matches the CPU to summation-order rounding, not bit for bit.
+template <bool kSpecial, bool kTraversal>
 __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1004,6 +1008,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   int sx = 0, sy = 0, sz = 0;
   uint32_t vi = 0;
   uint32_t ray = 0;
+  double t_enter = 0;  // kTraversal: range at which the current voxel was entered
+  double ray_len = 0;  // kTraversal && kSpecial: exit range of the end voxel
   uint32_t qcount = 0;     // wave-uniform
   bool exhausted = false;  // wave-uniform
   uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;
@@ -1064,6 +1070,18 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         sz = d2 * dimxy;
         vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
         ray = seg.ray;
+        if (kTraversal)
+        {
+          // The step which entered this region is the latest step taken so far.
+          double te = 0;
+          te = (s0 > 0) ? stepTime(i0, e0, s0) : te;
+          const double te1 = (s1 > 0) ? stepTime(i1, e1, s1) : 0.0;
+          const double te2 = (s2 > 0) ? stepTime(i2, e2, s2) : 0.0;
+          te = (te1 > te) ? te1 : te;
+          te = (te2 > te) ? te2 : te;
+          t_enter = te;
+          ray_len = rw.length;
+        }
         if (kSpecial)
         {
           skip = (first_segment && (rw.flags & kRwExcludeStart)) ? 1u : 0u;
@@ -1097,6 +1115,21 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       if (!(dbg & 1u))
       {
         atomicAdd(&l_counts[vi_visit >> 1], 1u << ((vi_visit & 1u) * 16u));
+      }
+    }
+    double t_exit = 0;
+    if (kTraversal)
+    {
+      // exit range of this voxel == time of the next step (the ray's length at its end voxel)
+      const double tm01 = (t0 < t1) ? t0 : t1;
+      t_exit = (tm01 < t2) ? tm01 : t2;
+      if (kSpecial)
+      {
+        t_exit = not_end ? t_exit : ray_len;
+      }
+      if (visit)
+      {
+        atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + vi_visit], float(t_exit - t_enter));
       }
     }
     if (kSpecial)
@@ -1144,6 +1177,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       const uint32_t more = min(uint32_t(rem0 | rem1 | rem2), 1u);
       // Retire on leaving the region; the lean instantiation also retires on reaching the end voxel (no miss there).
       act = kSpecial ? (stepping & inside) : (stepping & inside & more);
+      if (kTraversal)
+      {
+        t_enter = stepping ? t_exit : t_enter;
+      }
     }
 
     // ---- deferred ordering of misses on masked voxels (the mask word was fetched before the step: its LDS latency
@@ -1278,7 +1315,7 @@ __global__ void __launch_bounds__(256)
   k_apply_hits(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags,
                const unsigned long long *__restrict__ sorted, uint32_t *__restrict__ interval_counts,
                uint32_t *__restrict__ miss_counts, const double *__restrict__ rays, float *__restrict__ occupancy,
-               uint32_t *__restrict__ mean)
+               uint32_t *__restrict__ mean, SecondaryLayers sec, const RayWalk *__restrict__ walks)
 {
   const uint32_t n_hits = bs.info->n_hits;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1313,14 +1350,36 @@ __global__ void __launch_bounds__(256)
     centre[2] = voxelCentreAxis(mc, 2, rk[2], lz);
   }
 
+  uint32_t packed_normal = sec.incident ? sec.incident[gi] : 0u;
+  float traversal_add = 0.0f;
+  float traversal = sec.traversal ? sec.traversal[gi] : 0.0f;
+  uint32_t last_ray = 0;
   for (uint32_t j = i; j < n_hits && (sorted[j] >> kHitRayBits) == group; ++j)
   {
     x = occMissN(mc, ray_flags, x, interval_counts[j]);
     interval_counts[j] = 0;
     x = occHit(mc, ray_flags, x);
+    const uint32_t ray = uint32_t(sorted[j] & ((1ull << kHitRayBits) - 1ull));
+    last_ray = ray;
+    if (sec.incident)
+    {
+      // ohm/RayMapperOccupancy.cpp:319-325: incident ray = start - end (converted to float), weight = sample count
+      // before this sample (0 without a mean layer).
+      const float dir[3] = { float(rays[size_t(ray) * 6 + 0] - rays[size_t(ray) * 6 + 3]),
+                             float(rays[size_t(ray) * 6 + 1] - rays[size_t(ray) * 6 + 4]),
+                             float(rays[size_t(ray) * 6 + 2] - rays[size_t(ray) * 6 + 5]) };
+      packed_normal = updateIncidentNormal(packed_normal, dir, mean ? mcount : 0u);
+    }
+    if (sec.traversal)
+    {
+      // ohm/RayMapperOccupancy.cpp:299-305: remaining ray length inside the sample voxel.
+      const double dx = rays[size_t(ray) * 6 + 3] - rays[size_t(ray) * 6 + 0];
+      const double dy = rays[size_t(ray) * 6 + 4] - rays[size_t(ray) * 6 + 1];
+      const double dz = rays[size_t(ray) * 6 + 5] - rays[size_t(ray) * 6 + 2];
+      traversal += float(sqrt((dx * dx + dy * dy) + dz * dz) - lastExitRange(walks, ray));
+    }
     if (mean)
     {
-      const uint32_t ray = uint32_t(sorted[j] & ((1ull << kHitRayBits) - 1ull));
       // NOTE: uses the ray's sample as submitted; the clip filter never applies a hit to a moved end point.
       const double local[3] = { rays[size_t(ray) * 6 + 3] - centre[0], rays[size_t(ray) * 6 + 4] - centre[1],
                                 rays[size_t(ray) * 6 + 5] - centre[2] };
@@ -1336,6 +1395,21 @@ __global__ void __launch_bounds__(256)
   {
     mean[2 * gi] = mcoord;
     mean[2 * gi + 1] = mcount;
+  }
+  (void)traversal_add;
+  if (sec.incident)
+  {
+    sec.incident[gi] = packed_normal;
+  }
+  if (sec.traversal)
+  {
+    sec.traversal[gi] = traversal;
+  }
+  if (sec.touch_time && sec.timestamps)
+  {
+    // The CPU mapper overwrites the touch time at every sample: the last sample in ray order wins
+    // (ohm/RayMapperOccupancy.cpp:313-317).
+    sec.touch_time[gi] = encodeVoxelTouchTime(sec.time_base, sec.timestamps[last_ray]);
   }
 }
 

@@ -75,6 +75,7 @@ struct RayWalk
 {
   double init[3];   ///< initial_delta[]: exit time of the start voxel per axis.
   double delta[3];  ///< step_delta[]
+  double length;    ///< WalkSteps::length (0 for rays shorter than the 1e-3 epsilon)
   int g0[3];        ///< start voxel in global voxel coordinates (region * dim + local)
   int total[3];     ///< |steps_remaining| at the start = Manhattan extent per axis
   unsigned flags;   ///< kRw* bits

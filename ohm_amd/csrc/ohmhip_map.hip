@@ -98,6 +98,7 @@ struct ohmhip_map_s
   DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev, events;
   uint32_t *d_event_count = nullptr;
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
+  double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
   uint32_t event_demand = 0;
   uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= 65535 (u16 LDS counters)
   unsigned debug_flags = 0;  ///< OHMHIP_DEBUG_FLAGS: timing experiments only (breaks results)
@@ -419,8 +420,8 @@ __global__ void k_clear_counts(MapConst mc, RegionTable rt, BatchScratch bs, uin
 }
 
 /// One ray batch through the pipeline (all map modes).  d_rays: device pointer to 6 doubles per ray.
-int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensities, uint32_t n_rays,
-                   unsigned ray_flags)
+int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensities, const double *d_timestamps,
+                   uint32_t n_rays, unsigned ray_flags)
 {
   hipStream_t s = m->stream;
   const uint32_t ray_blocks = (n_rays + 255) / 256;
@@ -440,6 +441,12 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     ray_flags = OHMHIP_RF_END_POINT_AS_FREE;
   }
   const int ray_shift = occupancy_mode ? 0 : kEvRayShift;
+  SecondaryLayers sec;
+  sec.traversal = tsdf_mode ? nullptr : static_cast<float *>(m->layers[OHMHIP_LID_TRAVERSAL]);
+  sec.touch_time = tsdf_mode ? nullptr : static_cast<uint32_t *>(m->layers[OHMHIP_LID_TOUCH_TIME]);
+  sec.incident = tsdf_mode ? nullptr : static_cast<uint32_t *>(m->layers[OHMHIP_LID_INCIDENT]);
+  sec.timestamps = d_timestamps;
+  sec.time_base = m->first_ray_time;
 
   OHMHIP_CHECK(m->walks.ensure(sizeof(RayWalk) * size_t(n_rays), false, s));
   if (occupancy_mode)
@@ -564,16 +571,27 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.occupancy = direct_occ;
         wa.ray_flags = ray_flags;
         wa.dbg_counters = (m->debug_flags & 64u) ? m->d_dbg : nullptr;
+        wa.traversal = sec.traversal;
         // The lean instantiation applies unless some ray's end voxel is part of its walk or origins are excluded.
         const bool special = (ray_flags & (OHMHIP_RF_END_POINT_AS_FREE | OHMHIP_RF_EXCLUDE_ORIGIN)) ||
                              m->mc.filter_mode == OHMHIP_FILTER_CLIP;
-        if (special)
+        const dim3 wgrid(info.n_chunks), wblock(kWalkThreads);
+        const size_t wlds = walkLdsBytes(m->mc);
+        if (special && sec.traversal)
         {
-          hipLaunchKernelGGL(k_region_walk<true>, dim3(info.n_chunks), dim3(kWalkThreads), walkLdsBytes(m->mc), s, wa);
+          hipLaunchKernelGGL((k_region_walk<true, true>), wgrid, wblock, wlds, s, wa);
+        }
+        else if (special)
+        {
+          hipLaunchKernelGGL((k_region_walk<true, false>), wgrid, wblock, wlds, s, wa);
+        }
+        else if (sec.traversal)
+        {
+          hipLaunchKernelGGL((k_region_walk<false, true>), wgrid, wblock, wlds, s, wa);
         }
         else
         {
-          hipLaunchKernelGGL(k_region_walk<false>, dim3(info.n_chunks), dim3(kWalkThreads), walkLdsBytes(m->mc), s, wa);
+          hipLaunchKernelGGL((k_region_walk<false, false>), wgrid, wblock, wlds, s, wa);
         }
         OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
         if (occupancy_mode)
@@ -625,7 +643,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       hipLaunchKernelGGL(k_apply_hits, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
                          ray_flags, sorted, static_cast<uint32_t *>(m->interval_counts.ptr), m->d_miss_counts, d_rays,
                          static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
-                         static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]));
+                         static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]), sec,
+                         static_cast<const RayWalk *>(m->walks.ptr));
       if (info.n_touched)
       {
         hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
@@ -652,7 +671,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                            static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]),
                            static_cast<float *>(m->layers[OHMHIP_LID_COVARIANCE]),
                            tm ? static_cast<float *>(m->layers[OHMHIP_LID_INTENSITY]) : nullptr,
-                           tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr);
+                           tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr, sec,
+                           static_cast<const RayWalk *>(m->walks.ptr));
         if (info.n_touched)
         {
           hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
@@ -861,15 +881,16 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   }
   // The walk kernel stages a region's count tile + hit mask in LDS (68 KiB for 32^3).
   const size_t lds_bytes = walkLdsBytes(mc);
-  if ((err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_walk<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
+  const void *walk_kernels[4] = { reinterpret_cast<const void *>(k_region_walk<false, false>),
+                                  reinterpret_cast<const void *>(k_region_walk<false, true>),
+                                  reinterpret_cast<const void *>(k_region_walk<true, false>),
+                                  reinterpret_cast<const void *>(k_region_walk<true, true>) };
+  for (const void *kernel : walk_kernels)
   {
-    return fail(err);
-  }
-  if ((err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_walk<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
-  {
-    return fail(err);
+    if ((err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
+    {
+      return fail(err);
+    }
   }
   if (const char *env = std::getenv("OHMHIP_CHUNK_SEGMENTS"))
   {
@@ -955,7 +976,6 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
                                      size_t *integrated)
 {
-  (void)d_timestamps;
   if (integrated)
   {
     *integrated = 0;
@@ -977,6 +997,14 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
   {
     return OHMHIP_ERR_INVALID_ARG;  // split larger batches at the caller (29-bit ray index in the hit key)
   }
+  if (d_timestamps && m->first_ray_time < 0)
+  {
+    // OccupancyMap::updateFirstRayTime(*timestamps) (ohm/OccupancyMap.cpp:343-347)
+    double first = 0;
+    OHMHIP_CHECK(hipMemcpyAsync(&first, d_timestamps, sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+    m->first_ray_time = first;
+  }
   int err = OHMHIP_ERR_UNSUPPORTED;
   switch (m->config.mode)
   {
@@ -985,7 +1013,7 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
     {
       return OHMHIP_ERR_INVALID_ARG;
     }
-    err = integrateBatch(m, d_rays, d_intensities, uint32_t(n_rays), ray_flags);
+    err = integrateBatch(m, d_rays, d_intensities, d_timestamps, uint32_t(n_rays), ray_flags);
     break;
   case OHMHIP_MODE_NDT_OM:
   case OHMHIP_MODE_NDT_TM:
@@ -997,7 +1025,7 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
     {
       return OHMHIP_ERR_INVALID_ARG;
     }
-    err = integrateBatch(m, d_rays, d_intensities, uint32_t(n_rays), ray_flags);
+    err = integrateBatch(m, d_rays, d_intensities, d_timestamps, uint32_t(n_rays), ray_flags);
     break;
   case OHMHIP_MODE_TSDF:
     if (!m->layers[OHMHIP_LID_TSDF])
@@ -1008,7 +1036,7 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
     {
       return OHMHIP_ERR_UNSUPPORTED;  // weight drop-off makes free-space updates value dependent
     }
-    err = integrateBatch(m, d_rays, d_intensities, uint32_t(n_rays), ray_flags);
+    err = integrateBatch(m, d_rays, d_intensities, d_timestamps, uint32_t(n_rays), ray_flags);
     break;
   default:
     break;

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(128)
   k_replay_ndt(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
                const double *__restrict__ rays, const float *__restrict__ intensities, float *__restrict__ occupancy,
                uint32_t *__restrict__ mean_layer, float *__restrict__ cov_layer, float *__restrict__ intensity_layer,
-               uint32_t *__restrict__ hit_miss_layer)
+               uint32_t *__restrict__ hit_miss_layer, SecondaryLayers sec, const RayWalk *__restrict__ walks)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_events)
@@ -82,6 +82,9 @@ __global__ void __launch_bounds__(128)
     hm_miss = hit_miss_layer[2 * gi + 1];
   }
 
+  uint32_t packed_normal = sec.incident ? sec.incident[gi] : 0u;
+  float traversal = sec.traversal ? sec.traversal[gi] : 0.0f;
+  uint32_t last_sample_ray = 0xffffffffu;
   for (uint32_t j = i; j < n_events; ++j)
   {
     const unsigned long long kj = sorted[j];
@@ -124,7 +127,31 @@ __global__ void __launch_bounds__(128)
       mcount = (!reset_mean) ? mcount : 0;
       mcoord = subVoxelUpdateD3(mcoord, mcount, sample - centre, mc.resolution);
       ++mcount;
+      last_sample_ray = ray;
+      if (sec.traversal)
+      {
+        // ohm/RayMapperNdt.cpp:367-373
+        traversal += float(sqrt(dot(sample - sensor, sample - sensor)) - lastExitRange(walks, ray));
+      }
+      if (sec.incident)
+      {
+        // ohm/RayMapperNdt.cpp:381-388: weight = point count before this sample (count already incremented)
+        const float dir[3] = { float(sensor.x - sample.x), float(sensor.y - sample.y), float(sensor.z - sample.z) };
+        packed_normal = updateIncidentNormal(packed_normal, dir, mcount - 1);
+      }
     }
+  }
+  if (sec.incident)
+  {
+    sec.incident[gi] = packed_normal;
+  }
+  if (sec.traversal)
+  {
+    sec.traversal[gi] = traversal;
+  }
+  if (sec.touch_time && sec.timestamps && last_sample_ray != 0xffffffffu)
+  {
+    sec.touch_time[gi] = encodeVoxelTouchTime(sec.time_base, sec.timestamps[last_sample_ray]);
   }
 
   occupancy[gi] = occ;

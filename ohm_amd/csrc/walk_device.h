@@ -201,6 +201,7 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
 {
   rw.flags = 0;
   rw.pad = 0;
+  rw.length = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
   {
@@ -261,6 +262,7 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
     // from the key difference.  They agree whenever there is at least one step to take.
   }
 
+  rw.length = length;
   const bool include_end = clipped_end || (ray_flags & OHMHIP_RF_END_POINT_AS_FREE);
   flags |= include_end ? kRwIncludeEnd : 0u;
   flags |= (!include_end && !(ray_flags & OHMHIP_RF_EXCLUDE_SAMPLE)) ? kRwApplySample : 0u;
