@@ -1,0 +1,84 @@
+"""-m gpu: the BASELINE.json configurations at FULL size.
+
+C1 (1 M lidar rays, 0.1 m) and C2 (NDT, 1 M rays, 0.2 m) are compared voxel-for-voxel with the CPU oracle (a few
+seconds of CPU each).  C3 (TSDF, 0.05 m, 4 M rays) is checked against the oracle on its first revolution (1 M rays) and
+at full size through size-independent properties: the exact voxel-visit count (closed form from the voxel keys), and
+batch-split invariance (integrating in one call or in four must give bit-identical maps because the device applies
+every voxel's events in ray order)."""
+import numpy as np
+import pytest
+
+from ohm_amd import GpuMap, GpuNdtMap, GpuTsdfMap, OccupancyMap, synth
+
+from parity import assert_parity, compare_maps, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def expected_visits(rays, resolution, include_end):
+    """Sum over rays of (Manhattan voxel distance + 1): what the CPU walk reports (ohm/LineWalkCompute.h:345-413)."""
+    g = np.floor(rays / resolution).astype(np.int64)  # map origin 0: global voxel coordinate (ohm/MapCoord.h)
+    manhattan = np.abs(g[1::2] - g[0::2]).sum(axis=1)
+    return int(manhattan.sum() + (len(manhattan) if include_end else len(manhattan)))
+
+
+def test_c1_occupancy_full_vs_oracle(gpu):
+    rays = synth.rays_c1()
+    map_ = OccupancyMap(0.1)
+    gm = GpuMap(map_, gpu_mem_size=2 << 30)
+    assert gm.integrateRays(rays) == rays.shape[0]
+    gm.syncVoxels()
+    st = gm.stats()
+    assert st["voxel_visits"] == expected_visits(rays, 0.1, False)
+    om = make_oracle(map_)
+    om.integrate_occupancy(rays)
+    assert om.visit_count() == st["voxel_visits"]
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+
+
+def test_c2_ndt_full_vs_oracle(gpu):
+    rays = synth.rays_c2()
+    map_ = OccupancyMap(0.2)
+    gm = GpuNdtMap(map_, gpu_mem_size=4 << 30)
+    assert gm.integrateRays(rays) == rays.shape[0]
+    gm.syncVoxels()
+    om = make_oracle(map_)
+    om.set_ndt(adaptation_rate=gm.adaptation_rate)
+    om.integrate_ndt(rays)
+    assert om.visit_count() == gm.stats()["voxel_visits"]
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean", "covariance"], rel=1e-5))
+
+
+def test_c3_tsdf_first_revolution_vs_oracle_and_full_properties(gpu):
+    rays = synth.rays_c3()
+    assert rays.shape[0] == 8_000_000
+    first = rays[:2_000_000]
+    map_ = OccupancyMap(0.05, layers=("tsdf",))
+    gm = GpuTsdfMap(map_, gpu_mem_size=16 << 30)
+    assert gm.integrateRays(first) == first.shape[0]
+    gm.syncVoxels()
+    om = make_oracle(map_)
+    om.integrate_tsdf(first)
+    assert om.visit_count() == gm.stats()["voxel_visits"]
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True))
+    del om
+
+    # full size: one call vs four calls must agree bit for bit, and the visit count must match the closed form
+    map_a = OccupancyMap(0.05, layers=("tsdf",))
+    gm_a = GpuTsdfMap(map_a, gpu_mem_size=16 << 30)
+    assert gm_a.integrateRays(rays) == rays.shape[0]
+    assert gm_a.stats()["voxel_visits"] == expected_visits(rays, 0.05, True)
+    gm_a.syncVoxels()
+    gm_a.close()
+    map_b = OccupancyMap(0.05, layers=("tsdf",))
+    gm_b = GpuTsdfMap(map_b, gpu_mem_size=16 << 30)
+    for i in range(0, rays.shape[0], 2_000_000):
+        assert gm_b.integrateRays(rays[i:i + 2_000_000]) == 2_000_000
+    gm_b.syncVoxels()
+    gm_b.close()
+    assert set(map_a.chunks) == set(map_b.chunks)
+    for key, layers in map_a.chunks.items():
+        assert np.array_equal(layers["tsdf"].view(np.uint32), map_b.chunks[key]["tsdf"].view(np.uint32))
+    w = np.concatenate([c["tsdf"].reshape(-1, 2)[:, 0] for c in map_a.chunks.values()])
+    d = np.concatenate([c["tsdf"].reshape(-1, 2)[:, 1] for c in map_a.chunks.values()])
+    assert w.max() <= 1e4 and np.all(np.abs(d) <= np.float32(0.1))
