@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--rays", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,6 +154,32 @@ def main():
         "device_ms": {"setup_bin": float(st["ms_setup"]), "walk": float(st["ms_walk"]),
                       "sort_apply": float(st["ms_apply"]), "total": float(st["ms_total"])},
     }
+    if world == 1 and not args.no_extra:
+        # Secondary figures (not the headline `value`): C2 GpuNdtMap and C3 GpuTsdfMap (first revolution), same harness.
+        extra = {}
+        for name, cls, res, gen, layers in (("C2_ndt_1M_rays_0.2m", ohm_amd.GpuNdtMap, 0.2, synth.rays_c2, ("occupancy",)),
+                                            ("C3_tsdf_1M_rays_0.05m", ohm_amd.GpuTsdfMap, 0.05, synth.rays_c2, ("tsdf",))):
+            r2 = gen(n=n_rays)
+            m2 = ohm_amd.OccupancyMap(res, (32, 32, 32), layers=layers)
+            g2 = cls(m2, gpu_mem_size=16 << 30)
+            b2 = L._vp()
+            L.check(L.lib.ohmhip_buffer_create(C.byref(b2), r2.nbytes, 3), "buffer_create")
+            L.check(L.lib.ohmhip_buffer_write(b2, r2.ctypes.data, r2.nbytes, 0, None, None, None), "buffer_write")
+            p2 = L._vp()
+            L.check(L.lib.ohmhip_buffer_ptr(b2, C.byref(p2)), "buffer_ptr")
+            g2.integrateRaysDevice(p2, r2.shape[0])
+            g2.wait()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                g2.integrateRaysDevice(p2, r2.shape[0])
+            g2.wait()
+            dt = (time.perf_counter() - t1) / 3
+            st2 = g2.stats()
+            extra[name] = {"rays_per_s": n_rays / dt, "ms_per_step": dt * 1e3, "voxel_visits": int(st2["voxel_visits"]),
+                           "walk_ms": float(st2["ms_walk"])}
+            L.lib.ohmhip_buffer_destroy(b2)
+            g2.close()
+        out["other_configs"] = extra
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(rays, resolution, min(args.cpu_sample, n_rays))
     elif rank == 0:
