@@ -56,17 +56,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    backend = None
     if world > 1:
+        # torch must be imported before ohm_amd (it bundles its own HIP runtime; see tests/_gpu_merge_worker.py).
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        n_dev = torch.cuda.device_count()
+        device_index = local_rank % max(n_dev, 1)
+        torch.cuda.set_device(device_index)
+        # One rank per GPU over RCCL; if ranks outnumber GPUs (single-GPU smoke runs) fall back to gloo for the
+        # control-plane collectives -- the data path has no collective.
+        backend = "nccl" if n_dev >= world else "gloo"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
+    else:
+        device_index = 0
 
     import ohm_amd
     from ohm_amd import _lib as L
     from ohm_amd import synth
 
-    L.check(L.lib.ohmhip_device_select(local_rank), "device_select")
+    L.check(L.lib.ohmhip_device_select(device_index), "device_select")
     resolution = 0.1
     n_rays = args.rays
     if world == 1:
@@ -91,6 +103,7 @@ def main():
         gm.wait()
         if dist is not None:
             import torch
+            torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -112,7 +125,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

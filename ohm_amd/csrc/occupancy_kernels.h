@@ -1012,6 +1012,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   double ray_len = 0;  // kTraversal && kSpecial: exit range of the end voxel
   uint32_t qcount = 0;     // wave-uniform
   bool exhausted = false;  // wave-uniform
+  uint32_t pend_word = 0, pend_vi = 0, pend_visit = 0, pend_ray = 0;  // previous iteration's mask test
   uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;
 
   while (true)
@@ -1108,6 +1109,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // kSpecial: at the end voxel visit iff include_end, elsewhere iff !skip.
     const uint32_t visit = kSpecial ? (act & (not_end ? (skip ^ 1u) : include_end)) : act;
     const uint32_t vi_visit = vi;
+    const uint32_t ray_visit = ray;
     uint32_t mword = 0;
     if (visit)
     {
@@ -1183,30 +1185,51 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       }
     }
 
-    // ---- deferred ordering of misses on masked voxels (the mask word was fetched before the step: its LDS latency
-    // ---- overlaps the step arithmetic).
-    const uint32_t flagged = (dbg & 10u) ? 0u : (visit & (mword >> (vi_visit & 31)));
-    const unsigned long long fm = __ballot((flagged & 1u) != 0);
-    if (args.dbg_counters)
+    // ---- deferred ordering of misses on masked voxels, software pipelined by one iteration: the mask word fetched
+    // ---- for THIS iteration's voxel is consumed at the end of the NEXT iteration, so its LDS latency never stalls
+    // ---- the wave (a use in the same iteration gets hoisted right behind the ds_read by the compiler).
     {
-      dbg_active += uint32_t(__popcll(__ballot(visit != 0)));
-      dbg_fm += fm ? 1u : 0u;
+      const uint32_t flagged = (dbg & 10u) ? 0u : (pend_visit & (pend_word >> (pend_vi & 31)));
+      const unsigned long long fm = __ballot((flagged & 1u) != 0);
+      if (args.dbg_counters)
+      {
+        dbg_active += uint32_t(__popcll(__ballot(visit != 0)));
+        dbg_fm += fm ? 1u : 0u;
+      }
+      if (fm)
+      {
+        if (flagged & 1u)
+        {
+          queue[qcount + uint32_t(__popcll(fm & lane_lt))] =
+            slot_bits | ((unsigned long long)pend_vi << kHitRayBits) | ((unsigned long long)pend_ray << ray_shift);
+        }
+        qcount += uint32_t(__popcll(fm));
+        if (qcount > uint32_t(kQueueCap - 64))
+        {
+          flushQueue(queue, qcount, lane, lds_resolve, l_hits, n_region_hits, hb, l_intervals, l_counts, args.events,
+                     args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits, args.miss_counts,
+                     args.interval_counts, mc.region_voxels);
+          qcount = 0;
+        }
+      }
+      pend_word = mword;
+      pend_vi = vi_visit;
+      pend_visit = visit;
+      pend_ray = ray_visit;
     }
+  }
+  // Drain the last iteration's pending mask test.
+  {
+    const uint32_t flagged = (dbg & 10u) ? 0u : (pend_visit & (pend_word >> (pend_vi & 31)));
+    const unsigned long long fm = __ballot((flagged & 1u) != 0);
     if (fm)
     {
       if (flagged & 1u)
       {
         queue[qcount + uint32_t(__popcll(fm & lane_lt))] =
-          slot_bits | ((unsigned long long)vi_visit << kHitRayBits) | ((unsigned long long)ray << ray_shift);
+          slot_bits | ((unsigned long long)pend_vi << kHitRayBits) | ((unsigned long long)pend_ray << ray_shift);
       }
       qcount += uint32_t(__popcll(fm));
-      if (qcount > uint32_t(kQueueCap - 64))
-      {
-        flushQueue(queue, qcount, lane, lds_resolve, l_hits, n_region_hits, hb, l_intervals, l_counts, args.events,
-                   args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits, args.miss_counts,
-                   args.interval_counts, mc.region_voxels);
-        qcount = 0;
-      }
     }
   }
 
