@@ -221,6 +221,13 @@ int ohmhip_map_write_regions(ohmhip_map_t map, int layer_id, const int16_t *keys
 /* GpuCache::clear / MapRegionCache::remove (ohmgpu/GpuCache.cpp, ohm/MapRegionCache.h): drop all regions. */
 int ohmhip_map_clear(ohmhip_map_t map);
 
+/* LineKeysQueryGpu / `calculateLines` (ohmgpu/LineKeysQueryGpu.cpp, ohmgpu/gpu/LineKeys.cl:66-100): the voxel keys on
+ * `line_count` query lines (6 doubles each: start, end), in walk order, with the CPU walk's fp64 semantics.  keys_out is
+ * line_count * max_keys_per_line records in the reference's GpuKey layout (short region[3]; uchar voxel[4], 10 bytes,
+ * ohmgpu/GpuKey.h:37-46); counts_out[i] is the line's total voxel count.  Host pointers; synchronous. */
+int ohmhip_map_line_keys(ohmhip_map_t map, const double *lines, size_t line_count, uint32_t max_keys_per_line,
+                         void *keys_out, uint32_t *counts_out);
+
 /* Multi-GPU merge support (no reference equivalent -- ohm is single device).  The resident layer of a
  * map is one allocation of region_stride_bytes per slot: ohm_amd/distributed.py wraps it as a device tensor and runs
  * the RCCL all-reduce of touched-region occupancy deltas on it.  ensure_regions makes regions resident (cleared)

@@ -1512,6 +1512,54 @@ int ohmhip_map_mark_dirty(ohmhip_map_t m, const uint32_t *slots, size_t count)
   return OHMHIP_OK;
 }
 
+int ohmhip_map_line_keys(ohmhip_map_t m, const double *lines, size_t line_count, uint32_t max_keys_per_line,
+                         void *keys_out, uint32_t *counts_out)
+{
+  if (!m || (line_count && (!lines || !keys_out || !counts_out)) || max_keys_per_line == 0)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (line_count == 0)
+  {
+    return OHMHIP_OK;
+  }
+  hipStream_t s = m->stream;
+  const size_t key_bytes = sizeof(GpuKeyOut) * line_count * size_t(max_keys_per_line);
+  double *d_lines = nullptr;
+  GpuKeyOut *d_keys = nullptr;
+  uint32_t *d_counts = nullptr;
+  int status = OHMHIP_OK;
+  auto cleanup = [&]() {
+    (void)hipFree(d_lines);
+    (void)hipFree(d_keys);
+    (void)hipFree(d_counts);
+  };
+  if ((status = hipMalloc(reinterpret_cast<void **>(&d_lines), sizeof(double) * 6 * line_count)) != 0 ||
+      (status = hipMalloc(reinterpret_cast<void **>(&d_keys), key_bytes)) != 0 ||
+      (status = hipMalloc(reinterpret_cast<void **>(&d_counts), sizeof(uint32_t) * line_count)) != 0)
+  {
+    cleanup();
+    return status;
+  }
+  status = hipMemcpyAsync(d_lines, lines, sizeof(double) * 6 * line_count, hipMemcpyHostToDevice, s);
+  if (!status)
+  {
+    hipLaunchKernelGGL(k_line_keys, dim3(uint32_t((line_count + 255) / 256)), dim3(256), 0, s, m->mc, d_lines,
+                       uint32_t(line_count), max_keys_per_line, d_keys, d_counts);
+    status = hipMemcpyAsync(keys_out, d_keys, key_bytes, hipMemcpyDeviceToHost, s);
+  }
+  if (!status)
+  {
+    status = hipMemcpyAsync(counts_out, d_counts, sizeof(uint32_t) * line_count, hipMemcpyDeviceToHost, s);
+  }
+  if (!status)
+  {
+    status = hipStreamSynchronize(s);
+  }
+  cleanup();
+  return status;
+}
+
 int ohmhip_map_clear(ohmhip_map_t m)
 {
   if (!m)

@@ -400,6 +400,102 @@ __global__ void __launch_bounds__(256)
     hit_mask[size_t(slot) * mask_words + w] = bits;
   }
 }
+/// GpuKey layout of the reference (ohmgpu/GpuKey.h:37-46): short region[3]; uchar voxel[4].
+struct GpuKeyOut
+{
+  int16_t region[3];
+  uint8_t voxel[4];
+};
+
+/// LineKeysQueryGpu / `calculateLines` (ohmgpu/gpu/LineKeys.cl:66-100) with the CPU walk's semantics
+/// (ohm/LineWalk.h:112-129 walkSegmentKeys, flags 0: start and end voxel included): one lane per query line writes the
+/// keys of every voxel on the line, in walk order.  counts[i] is the full number of voxels even when it exceeds
+/// max_keys_per_line (only the first max_keys_per_line keys are stored).
+__global__ void __launch_bounds__(256)
+  k_line_keys(MapConst mc, const double *__restrict__ lines, uint32_t n_lines, uint32_t max_keys_per_line,
+              GpuKeyOut *__restrict__ keys_out, uint32_t *__restrict__ counts)
+{
+  const uint32_t line = blockIdx.x * blockDim.x + threadIdx.x;
+  if (line >= n_lines)
+  {
+    return;
+  }
+  double start[3], end[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    start[a] = lines[size_t(line) * 6 + a];
+    end[a] = lines[size_t(line) * 6 + 3 + a];
+  }
+  MapConst nofilter = mc;
+  nofilter.filter_mode = OHMHIP_FILTER_NONE;
+  RayWalk rw;
+  setupRay(nofilter, start, end, OHMHIP_RF_END_POINT_AS_FREE, rw);
+  if (!(rw.flags & kRwValid))
+  {
+    counts[line] = 0;
+    return;
+  }
+  const int d0 = rwDir(rw, 0), d1 = rwDir(rw, 1), d2 = rwDir(rw, 2);
+  int g0 = rw.g0[0], g1 = rw.g0[1], g2 = rw.g0[2];
+  int rem0 = rw.total[0], rem1 = rw.total[1], rem2 = rw.total[2];
+  const double inf = dInf();
+  double k0 = 0, k1 = 0, k2 = 0;
+  double t0 = rem0 ? rw.init[0] : inf;
+  double t1 = rem1 ? rw.init[1] : inf;
+  double t2 = rem2 ? rw.init[2] : inf;
+  uint32_t n = 0;
+  GpuKeyOut *out = keys_out + size_t(line) * max_keys_per_line;
+  while (true)
+  {
+    if (n < max_keys_per_line)
+    {
+      int r0, r1, r2, l0, l1, l2;
+      splitGlobal(g0, mc.dim[0], r0, l0);
+      splitGlobal(g1, mc.dim[1], r1, l1);
+      splitGlobal(g2, mc.dim[2], r2, l2);
+      GpuKeyOut k;
+      k.region[0] = int16_t(r0);
+      k.region[1] = int16_t(r1);
+      k.region[2] = int16_t(r2);
+      k.voxel[0] = uint8_t(l0);
+      k.voxel[1] = uint8_t(l1);
+      k.voxel[2] = uint8_t(l2);
+      k.voxel[3] = 0;
+      out[n] = k;
+    }
+    ++n;
+    if ((rem0 | rem1 | rem2) == 0)
+    {
+      break;
+    }
+    const bool c01 = t0 < t1;
+    const double t01 = c01 ? t0 : t1;
+    const bool c2 = t01 < t2;
+    if (!c2)
+    {
+      g2 += d2;
+      --rem2;
+      k2 += 1.0;
+      t2 = rem2 ? rw.init[2] + rw.delta[2] * k2 : inf;
+    }
+    else if (c01)
+    {
+      g0 += d0;
+      --rem0;
+      k0 += 1.0;
+      t0 = rem0 ? rw.init[0] + rw.delta[0] * k0 : inf;
+    }
+    else
+    {
+      g1 += d1;
+      --rem1;
+      k1 += 1.0;
+      t1 = rem1 ? rw.init[1] + rw.delta[1] * k1 : inf;
+    }
+  }
+  counts[line] = n;
+}
 }  // namespace ohmhip
 
 #endif  // OHMHIP_REPLAY_KERNELS_H

@@ -310,6 +310,19 @@ class GpuMap(RayMapper):
         L.check(L.lib.ohmhip_map_clear_dirty(self._handle), "clear_dirty")
         self.wait()
 
+    def lineKeys(self, lines, max_keys_per_line=1024):
+        """LineKeysQueryGpu equivalent: voxel keys along each query line (start/end pairs, (2N, 3) float64).
+        Returns (keys, counts): keys is (N, max_keys, 10) uint8 viewed as int16 region[3] + uint8 voxel[4]."""
+        lines = np.ascontiguousarray(lines, dtype=np.float64).reshape(-1, 6)
+        n = lines.shape[0]
+        keys = np.zeros((n, max_keys_per_line, 10), dtype=np.uint8)
+        counts = np.zeros(n, dtype=np.uint32)
+        L.check(L.lib.ohmhip_map_line_keys(self._handle, lines.ctypes.data, n, max_keys_per_line, keys.ctypes.data,
+                                           counts.ctypes.data), "lineKeys")
+        regions = keys[:, :, :6].copy().view(np.int16).reshape(n, max_keys_per_line, 3)
+        voxels = keys[:, :, 6:9]
+        return regions, voxels, counts
+
     def _upload_existing(self):
         """gpumap::enableGpu + GpuLayerCache::upload for regions the CPU map already holds."""
         if not self._map.chunks:
