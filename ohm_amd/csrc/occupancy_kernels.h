@@ -299,8 +299,10 @@ __device__ inline uint32_t ltabFind(const LdsRegionTable &tab, uint64_t key)
   return kLtabSize;
 }
 
-/// Walk the regions a ray crosses and call f(region key, s0, s1, s2, first) for every ray-region segment which
-/// produces at least one miss visit.  (s0, s1, s2) are the per-axis step counts at the moment the region is entered.
+/// Walk the regions a ray crosses and call f(region key, s0, s1, s2) for every ray-region segment which produces at
+/// least one voxel visit.  With `with_resume_state` the three words are the packed Segment fields (see Segment): the
+/// per-axis step counts at the moment the region is entered, the first / end flags and the number of voxels visited in
+/// the region; otherwise they are zero (the counting passes only need the keys).
 template <typename F>
 __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, bool with_resume_state, F f)
 {
@@ -312,9 +314,20 @@ __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, boo
   const bool include_end = (rw.flags & kRwIncludeEnd) != 0;
   RegionCursor rc;
   regionCursorInit(mc, rw, rc);
+  // A segment's voxel count is known once the NEXT region entry is: emission trails the enumeration by one.
+  bool have = false;
+  uint64_t p_key = 0;
+  uint32_t p0 = 0, p1 = 0, p2 = 0;
+  int p_sum = 0;
   if (manhattan > 0 || include_end)
   {
-    f(packRegionKey(rc.region[0], rc.region[1], rc.region[2]), kSegFirst, 0u, 0u);
+    p_key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
+    p0 = kSegFirst;
+    have = true;
+    if (!with_resume_state)
+    {
+      f(p_key, 0u, 0u, 0u);
+    }
   }
   int axis, j;
   while (regionCursorNext(mc, rw, rc, axis, j))
@@ -324,16 +337,34 @@ __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, boo
     {
       continue;
     }
-    uint32_t rs0 = 0, rs1 = 0, rs2 = 0;
-    if (with_resume_state)
+    const uint64_t key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
+    if (!with_resume_state)
     {
-      const double ta = stepTime(sel3(axis, rw.init[0], rw.init[1], rw.init[2]),
-                                 sel3(axis, rw.delta[0], rw.delta[1], rw.delta[2]), j);
-      rs0 = uint32_t((axis == 0) ? j : stepsBefore(rw.init[0], rw.delta[0], rw.total[0], 0, axis, ta));
-      rs1 = uint32_t((axis == 1) ? j : stepsBefore(rw.init[1], rw.delta[1], rw.total[1], 1, axis, ta));
-      rs2 = uint32_t((axis == 2) ? j : stepsBefore(rw.init[2], rw.delta[2], rw.total[2], 2, axis, ta));
+      f(key, 0u, 0u, 0u);
+      continue;
     }
-    f(packRegionKey(rc.region[0], rc.region[1], rc.region[2]), rs0, rs1, rs2);
+    const double ta = stepTime(sel3(axis, rw.init[0], rw.init[1], rw.init[2]),
+                               sel3(axis, rw.delta[0], rw.delta[1], rw.delta[2]), j);
+    const uint32_t rs0 = uint32_t((axis == 0) ? j : stepsBefore(rw.init[0], rw.delta[0], rw.total[0], 0, axis, ta));
+    const uint32_t rs1 = uint32_t((axis == 1) ? j : stepsBefore(rw.init[1], rw.delta[1], rw.total[1], 1, axis, ta));
+    const uint32_t rs2 = uint32_t((axis == 2) ? j : stepsBefore(rw.init[2], rw.delta[2], rw.total[2], 2, axis, ta));
+    const int sum = int(rs0 + rs1 + rs2);
+    if (have)
+    {
+      const uint32_t count = uint32_t(sum - p_sum);
+      f(p_key, p0, p1 | (count << 24), p2 | ((count >> 8) << 24));
+    }
+    p_key = key;
+    p0 = rs0;
+    p1 = rs1;
+    p2 = rs2;
+    p_sum = sum;
+    have = true;
+  }
+  if (have && with_resume_state)
+  {
+    const uint32_t count = uint32_t(manhattan - p_sum) + (include_end ? 1u : 0u);
+    f(p_key, p0 | (include_end ? kSegEnd : 0u), p1 | (count << 24), p2 | ((count >> 8) << 24));
   }
 }
 
@@ -804,20 +835,23 @@ __device__ inline uint32_t subVoxelUpdate(uint32_t coord, uint32_t point_count, 
 // k_region_walk: the hot kernel.
 //
 // One workgroup (16 waves) per chunk of <= kChunkSegments ray-region segments of ONE region.  The region's miss-count
-// tile (u16 per voxel, 64 KiB for 32^3) and its hit bitmask live in LDS.  Every lane resumes one ray's fp64 walk at
-// the step that enters the region and walks until the ray leaves the region or ends.  Idle lanes are refilled in
+// tile lives in LDS: one u16 per voxel, 15 bits of count and the top bit holding the voxel's mask flag ("also receives
+// samples"), so ONE returning LDS atomic per visit both counts the miss and fetches the flag.  Every lane resumes one
+// ray's fp64 walk at the step that enters the region and visits the segment's voxels.  Idle lanes are refilled in
 // batches from a workgroup-wide LDS cursor so waves stay mostly full although segments differ in length.
 //
-// A miss on a voxel which ALSO receives samples in this batch must be ordered against those samples.  Resolving that
-// needs a search in the region's sorted hit list (global memory latency), so such visits are not resolved here: they
-// are appended to a per-wave LDS queue (no atomics: the queue cursor is wave-uniform) which is flushed to a global
-// event list in coalesced bursts and resolved by k_flagged_events with full memory-level parallelism.
+// A miss on a masked voxel must be ordered against that voxel's samples.  Such visits are appended to a per-wave LDS
+// queue (no atomics: the queue cursor is wave-uniform) and resolved in bursts: against the region's sorted sample keys
+// staged in LDS when they fit, otherwise through a global event list (k_flagged_events).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kWalkThreads = 1024;
 constexpr int kWalkWaves = kWalkThreads / 64;
 constexpr int kQueueCap = 128;     ///< deferred events per wave (8 B each)
 constexpr int kLdsHits = 7168;     ///< a region's sample list is staged in LDS when it has at most this many samples
 constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
+constexpr uint32_t kTileFlag = 0x8000u;       ///< mask flag inside a u16 tile entry
+constexpr uint32_t kTileCountMask = 0x7fffu;  ///< count bits of a u16 tile entry (a chunk adds <= kMaxChunkSegments)
+constexpr uint32_t kMaxChunkSegments = 16384;
 
 /// Resolve one deferred miss event: find the first sample of the same voxel with a larger ray index; the miss counts
 /// towards the interval before that sample, or towards the voxel's trailing count if there is none.
@@ -844,14 +878,16 @@ __device__ inline void resolveFlaggedMiss(unsigned long long key, const BatchScr
   }
 }
 
-/// Drain one wave's deferred-miss queue.  Preferred: order each miss against the region's samples in LDS (binary search
-/// over the staged sorted keys, LDS atomics on the interval / trailing counters).  Otherwise append the events to the
-/// global list in one coalesced burst (resolved by k_flagged_events, or sorted and replayed for NDT / TSDF).
-__device__ inline void flushQueue(const unsigned long long *queue, uint32_t qcount, unsigned lane, bool lds_resolve,
-                                  const unsigned long long *l_hits, uint32_t n_region_hits, uint32_t hb,
-                                  uint32_t *l_intervals, uint32_t *l_counts, unsigned long long *__restrict__ events,
-                                  uint32_t event_capacity, uint32_t *__restrict__ event_count, int defer_all,
-                                  const BatchScratch &bs, const unsigned long long *__restrict__ sorted_hits,
+/// Drain one wave's deferred-miss queue of (voxel, ray) pairs.  Preferred: order each miss against the region's samples
+/// in LDS (binary search over the staged sorted keys, LDS atomics on the interval / trailing counters).  Otherwise
+/// append the events to the global list in one coalesced burst (resolved by k_flagged_events, or sorted and replayed
+/// for NDT / TSDF).
+__device__ inline void flushQueue(const uint2 *queue, uint32_t qcount, unsigned lane, unsigned long long slot_bits,
+                                  int ray_shift, bool lds_resolve, const unsigned long long *l_hits,
+                                  uint32_t n_region_hits, uint32_t *l_intervals, uint32_t *l_counts,
+                                  unsigned long long *__restrict__ events, uint32_t event_capacity,
+                                  uint32_t *__restrict__ event_count, int defer_all, const BatchScratch &bs,
+                                  const unsigned long long *__restrict__ sorted_hits,
                                   uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts,
                                   int region_voxels)
 {
@@ -859,7 +895,9 @@ __device__ inline void flushQueue(const unsigned long long *queue, uint32_t qcou
   {
     for (uint32_t q = lane; q < qcount; q += 64)
     {
-      const unsigned long long ev = queue[q];
+      const uint2 e = queue[q];
+      const unsigned long long ev =
+        slot_bits | ((unsigned long long)e.x << kHitRayBits) | ((unsigned long long)e.y << ray_shift);
       // First staged sample with key > ev.
       uint32_t lo = 0, hi = n_region_hits;
       while (lo < hi)
@@ -877,9 +915,8 @@ __device__ inline void flushQueue(const unsigned long long *queue, uint32_t qcou
       if (lo < n_region_hits && (l_hits[lo] >> kHitRayBits) == (ev >> kHitRayBits))
       {
         // Belongs before a later sample of the voxel: move it from the voxel's count to that sample's interval.
-        const uint32_t vi = uint32_t(ev >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
         atomicAdd(&l_intervals[lo >> 1], 1u << ((lo & 1u) * 16u));
-        atomicSub(&l_counts[vi >> 1], 1u << ((vi & 1u) * 16u));
+        atomicSub(&l_counts[e.x >> 1], 1u << ((e.x & 1u) * 16u));
       }
     }
     return;
@@ -892,7 +929,9 @@ __device__ inline void flushQueue(const unsigned long long *queue, uint32_t qcou
   gbase = __shfl(gbase, 0);
   for (uint32_t q = lane; q < qcount; q += 64)
   {
-    const unsigned long long ev = queue[q];
+    const uint2 e = queue[q];
+    const unsigned long long ev =
+      slot_bits | ((unsigned long long)e.x << kHitRayBits) | ((unsigned long long)e.y << ray_shift);
     if (gbase + q < event_capacity)
     {
       events[gbase + q] = ev;
@@ -930,8 +969,8 @@ struct WalkArgs
 };
 
 /// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
-/// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every active
-/// lane sits on a voxel that takes a miss, and a lane retires the moment it steps onto its ray's end voxel.
+/// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every iteration
+/// of an active lane is a miss.
 /// kTraversal: also accumulate the ray length inside every visited voxel (traversal layer, ohm/RayMapperOccupancy.cpp:
 /// 166-173).  Float adds in arbitrary order: that layer matches the CPU to summation-order rounding, not bit for bit.
 template <bool kSpecial, bool kTraversal>
@@ -939,25 +978,23 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const MapConst &mc = args.mc;
-  // Layout: [queues][staged sample keys][interval counters][count words: ceil(region_voxels / 2)][mask words][cursor]
+  // Layout: [count tile: ceil(region_voxels / 2) words][queues][staged sample keys][interval counters][cursor].
+  // The tile sits at offset 0 so the per-visit atomic needs no base add.
   const uint32_t count_words = uint32_t(mc.region_voxels + 1) >> 1;
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
-  unsigned long long *l_queues = reinterpret_cast<unsigned long long *>(lds);
-  unsigned long long *l_hits = l_queues + kWalkWaves * kQueueCap;           // [kLdsHits] region's sorted sample keys
+  uint32_t *l_counts = lds;
+  uint2 *l_queues = reinterpret_cast<uint2 *>(lds + ((count_words + 3u) & ~3u));
+  unsigned long long *l_hits = reinterpret_cast<unsigned long long *>(l_queues + kWalkWaves * kQueueCap);
   uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] u16 interval counters
-  uint32_t *l_counts = l_intervals + kLdsHits / 2;
-  uint32_t *l_mask = l_counts + count_words;
-  uint32_t *l_cursor = l_mask + mask_words;
+  uint32_t *l_cursor = l_intervals + kLdsHits / 2;
 
   const Chunk chunk = args.chunks[blockIdx.x];
   const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
+  // Tile entries start at zero count with the voxel's mask flag in the top bit.
   for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
   {
-    l_counts[i] = 0;
-  }
-  for (uint32_t i = threadIdx.x; i < mask_words; i += kWalkThreads)
-  {
-    l_mask[i] = g_mask[i];
+    const uint32_t two = (g_mask[i >> 4] >> ((i & 15u) * 2u)) & 3u;
+    l_counts[i] = ((two & 1u) << 15) | ((two & 2u) << 30);
   }
   if (threadIdx.x == 0)
   {
@@ -977,14 +1014,14 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     }
     for (uint32_t i = threadIdx.x; i < (n_region_hits + 1) / 2; i += kWalkThreads)
     {
-      l_intervals[i] = 0;  // two u16 counters per word (a chunk adds at most kChunkSegments to one counter)
+      l_intervals[i] = 0;  // two u16 counters per word (a chunk adds at most kMaxChunkSegments to one counter)
     }
   }
   __syncthreads();
 
   const unsigned lane = laneId();
   const unsigned wave = threadIdx.x >> 6;
-  unsigned long long *queue = l_queues + wave * kQueueCap;
+  uint2 *queue = l_queues + wave * kQueueCap;
   const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
   const int dimx = mc.dim[0];
   const int dimxy = mc.dim[0] * mc.dim[1];
@@ -992,54 +1029,49 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
   const int ray_shift = args.ray_shift;
   const int refill_min_idle = args.refill_min_idle;
-  const unsigned dbg = args.dbg;
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  const bool refill_only = (args.dbg & 16u) != 0;
 
-  // Per-lane walk state (all named scalars: no run-time indexed arrays).  Predicates that feed back into the walk
-  // state are kept as 0/1 integers in VGPRs and combined arithmetically: lane-mask logic would bounce every
-  // dependency through the scalar ALU (VALU -> SALU -> VALU costs tens of cycles per hop and this loop is a chain of
-  // such hops).
-  uint32_t act = 0;          // 1 while the lane has a voxel to visit / steps to take
-  uint32_t skip = 0;         // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
-  uint32_t include_end = 0;  // kSpecial only: the end voxel takes a miss too
+  // Per-lane walk state (all named scalars: no run-time indexed arrays).
+  int left = 0;  // voxels this lane still has to visit in its segment (<= 0: idle)
   double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
-  double t0 = 0, t1 = 0, t2 = 0, k0 = 0, k1 = 0, k2 = 0;  // time_next / steps taken per axis
-  int room0 = 0, room1 = 0, room2 = 0, rem0 = 0, rem1 = 0, rem2 = 0;
+  double t0 = 0, t1 = 0, t2 = 0;                          // time_next per axis
+  int k0 = 0, k1 = 0, k2 = 0, tot0 = 0, tot1 = 0, tot2 = 0;  // steps taken / steps in the whole ray per axis
   int sx = 0, sy = 0, sz = 0;
   uint32_t vi = 0;
   uint32_t ray = 0;
-  double t_enter = 0;  // kTraversal: range at which the current voxel was entered
-  double ray_len = 0;  // kTraversal && kSpecial: exit range of the end voxel
+  uint32_t skip = 0;      // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
+  uint32_t end_last = 0;  // kSpecial only: the segment's last voxel is the ray's end voxel
+  double t_enter = 0;     // kTraversal: range at which the current voxel was entered
+  double ray_len = 0;     // kTraversal && kSpecial: exit range of the end voxel
   uint32_t qcount = 0;     // wave-uniform
   bool exhausted = false;  // wave-uniform
-  uint32_t pend_word = 0, pend_vi = 0, pend_visit = 0, pend_ray = 0;  // previous iteration's mask test
-  uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;
+  uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;  // wave-uniform
 
   while (true)
   {
     // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
-    unsigned long long am = __ballot(act != 0);
+    unsigned long long am = __ballot(left > 0);
     const int n_idle = 64 - __popcll(am);
     if (!exhausted && (n_idle >= refill_min_idle))
     {
       ++dbg_refills;
-      const unsigned long long idle = ~am;
       uint32_t base = 0;
       if (lane == 0)
       {
         base = atomicAdd(l_cursor, uint32_t(n_idle));
       }
-      base = __shfl(base, 0);
+      base = __builtin_amdgcn_readfirstlane(base);
       exhausted = base + uint32_t(n_idle) >= n_seg;
-      const uint32_t mine = base + uint32_t(__popcll(idle & lane_lt));
-      if (act == 0 && mine < n_seg)
+      const unsigned long long idle = ~am;
+      const uint32_t mine =
+        base + __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
+      if (left <= 0 && mine < n_seg)
       {
         const Segment seg = args.segments[chunk.seg_begin + mine];
         const RayWalk rw = args.walks[seg.ray];
-        const bool first_segment = (seg.s0 & kSegFirst) != 0;
-        const int s0 = int(seg.s0 & ~kSegFirst);
-        const int s1 = int(seg.s1);
-        const int s2 = int(seg.s2);
+        const int s0 = int(seg.s0 & kSegStepMask);
+        const int s1 = int(seg.s1 & kSegStepMask);
+        const int s2 = int(seg.s2 & kSegStepMask);
         i0 = rw.init[0];
         i1 = rw.init[1];
         i2 = rw.init[2];
@@ -1052,25 +1084,22 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         const int l0 = localCoord(rw.g0[0] + d0 * s0, mc.dim[0]);
         const int l1 = localCoord(rw.g0[1] + d1 * s1, mc.dim[1]);
         const int l2 = localCoord(rw.g0[2] + d2 * s2, mc.dim[2]);
-        // room*: steps that can still be taken along an axis before the ray leaves the region.
-        room0 = (d0 > 0) ? (mc.dim[0] - 1 - l0) : l0;
-        room1 = (d1 > 0) ? (mc.dim[1] - 1 - l1) : l1;
-        room2 = (d2 > 0) ? (mc.dim[2] - 1 - l2) : l2;
-        rem0 = rw.total[0] - s0;
-        rem1 = rw.total[1] - s1;
-        rem2 = rw.total[2] - s2;
-        k0 = double(s0);
-        k1 = double(s1);
-        k2 = double(s2);
+        k0 = s0;
+        k1 = s1;
+        k2 = s2;
+        tot0 = rw.total[0];
+        tot1 = rw.total[1];
+        tot2 = rw.total[2];
         // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
-        t0 = rem0 ? ((s0 == 0) ? i0 : i0 + e0 * k0) : inf;
-        t1 = rem1 ? ((s1 == 0) ? i1 : i1 + e1 * k1) : inf;
-        t2 = rem2 ? ((s2 == 0) ? i2 : i2 + e2 * k2) : inf;
+        t0 = (s0 < tot0) ? ((s0 == 0) ? i0 : i0 + e0 * double(s0)) : inf;
+        t1 = (s1 < tot1) ? ((s1 == 0) ? i1 : i1 + e1 * double(s1)) : inf;
+        t2 = (s2 < tot2) ? ((s2 == 0) ? i2 : i2 + e2 * double(s2)) : inf;
         sx = d0;
         sy = d1 * dimx;
         sz = d2 * dimxy;
         vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
         ray = seg.ray;
+        left = int((seg.s1 >> 24) | ((seg.s2 >> 24) << 8));
         if (kTraversal)
         {
           // The step which entered this region is the latest step taken so far.
@@ -1085,39 +1114,32 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         }
         if (kSpecial)
         {
-          skip = (first_segment && (rw.flags & kRwExcludeStart)) ? 1u : 0u;
-          include_end = (rw.flags & kRwIncludeEnd) ? 1u : 0u;
-          act = 1u;
+          skip = ((seg.s0 & kSegFirst) && (rw.flags & kRwExcludeStart)) ? 1u : 0u;
+          end_last = (seg.s0 & kSegEnd) ? 1u : 0u;
         }
-        else
-        {
-          // A segment whose entry voxel is the ray's end voxel never exists here (k_ray_bin drops it).
-          act = ((rem0 | rem1 | rem2) != 0) ? 1u : 0u;
-        }
-        act = (dbg & 16u) ? 0u : act;
+        left = refill_only ? 0 : left;
       }
-      am = __ballot(act != 0);
+      am = __ballot(left > 0);
     }
     if (am == 0)
     {
       break;
     }
 
-    // ---- visit: count the miss.  Masked voxels (which also receive samples) are counted too; the ordering pass
-    // ---- moves such a miss to an interval counter when a later sample of the voxel exists.
-    const uint32_t not_end = kSpecial ? uint32_t(min(uint32_t(rem0 | rem1 | rem2), 1u)) : 1u;
-    // kSpecial: at the end voxel visit iff include_end, elsewhere iff !skip.
-    const uint32_t visit = kSpecial ? (act & (not_end ? (skip ^ 1u) : include_end)) : act;
+    // ---- visit: count the miss and fetch the voxel's mask flag with one returning LDS atomic.  Masked voxels (which
+    // ---- also receive samples) are counted too; the ordering pass moves such a miss to an interval counter when a
+    // ---- later sample of the voxel exists.
+    const bool active = left > 0;
+    // kSpecial: the ray's end voxel (last voxel of a kSegEnd segment) is always visited; kRfExcludeOrigin drops the
+    // first voxel of the ray otherwise.
+    const bool at_end = kSpecial && end_last && left == 1;
+    const bool visit = kSpecial ? (active && (at_end || !skip)) : active;
     const uint32_t vi_visit = vi;
-    const uint32_t ray_visit = ray;
-    uint32_t mword = 0;
+    const uint32_t sh = (vi_visit & 1u) << 4;
+    uint32_t old = 0;
     if (visit)
     {
-      mword = l_mask[vi_visit >> 5];
-      if (!(dbg & 1u))
-      {
-        atomicAdd(&l_counts[vi_visit >> 1], 1u << ((vi_visit & 1u) * 16u));
-      }
+      old = atomicAdd(&l_counts[vi_visit >> 1], 1u << sh);
     }
     double t_exit = 0;
     if (kTraversal)
@@ -1127,11 +1149,16 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       t_exit = (tm01 < t2) ? tm01 : t2;
       if (kSpecial)
       {
-        t_exit = not_end ? t_exit : ray_len;
+        t_exit = at_end ? ray_len : t_exit;
       }
       if (visit)
       {
         atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + vi_visit], float(t_exit - t_enter));
+        t_enter = t_exit;
+      }
+      else if (active)
+      {
+        t_enter = t_exit;
       }
     }
     if (kSpecial)
@@ -1140,96 +1167,61 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     }
     ++dbg_iters;
 
-    // ---- one branch-free walk step.  The axis is an integer in a VGPR (3 == no step); all three axes' candidate
-    // ---- updates are computed (independent fp64 chains) and committed with selects on (axis == a).
-    // ---- walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the higher axis.
+    // ---- one branch-free walk step, taken by every lane (an idle lane's state is dead, and the step after a
+    // ---- segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the
+    // ---- higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
     {
-      const uint32_t stepping = kSpecial ? (act & not_end) : act;
-      int axis = (t0 < t1) ? 0 : 1;
-      const double t01 = (t0 < t1) ? t0 : t1;
-      axis = (t01 < t2) ? axis : 2;
-      axis = stepping ? axis : 3;
-      const double k0n = k0 + 1.0;
-      const double k1n = k1 + 1.0;
-      const double k2n = k2 + 1.0;
-      const double t0n = i0 + e0 * k0n;  // ohm/LineWalkCompute.h:299-301
-      const double t1n = i1 + e1 * k1n;
-      const double t2n = i2 + e2 * k2n;
-      rem0 -= (axis == 0);
-      rem1 -= (axis == 1);
-      rem2 -= (axis == 2);
-      room0 -= (axis == 0);
-      room1 -= (axis == 1);
-      room2 -= (axis == 2);
-      k0 = (axis == 0) ? k0n : k0;
-      k1 = (axis == 1) ? k1n : k1;
-      k2 = (axis == 2) ? k2n : k2;
-      const double t0m = rem0 ? t0n : inf;
-      const double t1m = rem1 ? t1n : inf;
-      const double t2m = rem2 ? t2n : inf;
-      t0 = (axis == 0) ? t0m : t0;
-      t1 = (axis == 1) ? t1m : t1;
-      t2 = (axis == 2) ? t2m : t2;
-      int stride = (axis == 0) ? sx : 0;
-      stride = (axis == 1) ? sy : stride;
-      stride = (axis == 2) ? sz : stride;
+      const bool c01 = t0 < t1;
+      const double t01 = c01 ? t0 : t1;
+      const bool c2 = t01 < t2;
+      const bool a0 = c2 && c01;
+      const bool a1 = c2 && !c01;
+      const bool a2 = !c2;
+      k0 = a0 ? k0 + 1 : k0;
+      k1 = a1 ? k1 + 1 : k1;
+      k2 = a2 ? k2 + 1 : k2;
+      const double n0 = (k0 < tot0) ? i0 + e0 * double(k0) : inf;
+      const double n1 = (k1 < tot1) ? i1 + e1 * double(k1) : inf;
+      const double n2 = (k2 < tot2) ? i2 + e2 * double(k2) : inf;
+      t0 = a0 ? n0 : t0;
+      t1 = a1 ? n1 : t1;
+      t2 = a2 ? n2 : t2;
+      int stride = a0 ? sx : sy;
+      stride = a2 ? sz : stride;
       vi += uint32_t(stride);
-      // inside: no room counter went negative (sign bit of the OR); more: steps remain (non-negative values).
-      const uint32_t inside = (uint32_t(room0 | room1 | room2) >> 31) ^ 1u;
-      const uint32_t more = min(uint32_t(rem0 | rem1 | rem2), 1u);
-      // Retire on leaving the region; the lean instantiation also retires on reaching the end voxel (no miss there).
-      act = kSpecial ? (stepping & inside) : (stepping & inside & more);
-      if (kTraversal)
-      {
-        t_enter = stepping ? t_exit : t_enter;
-      }
+      left -= 1;
     }
 
-    // ---- deferred ordering of misses on masked voxels, software pipelined by one iteration: the mask word fetched
-    // ---- for THIS iteration's voxel is consumed at the end of the NEXT iteration, so its LDS latency never stalls
-    // ---- the wave (a use in the same iteration gets hoisted right behind the ds_read by the compiler).
+    // ---- deferred ordering of misses on masked voxels.  Consumed after the step so the atomic's return latency is
+    // ---- covered by the step arithmetic: the empty asm pins the step's results ahead of this point (the optimiser
+    // ---- otherwise sinks the step below the flag test and the wave waits on the LDS round trip every iteration).
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(k0), "+v"(k1), "+v"(k2), "+v"(vi), "+v"(left));
+    __builtin_amdgcn_sched_barrier(0);
     {
-      const uint32_t flagged = (dbg & 10u) ? 0u : (pend_visit & (pend_word >> (pend_vi & 31)));
-      const unsigned long long fm = __ballot((flagged & 1u) != 0);
+      const bool flagged = ((old >> sh) & kTileFlag) != 0;
+      const unsigned long long fm = __ballot(flagged);
       if (args.dbg_counters)
       {
-        dbg_active += uint32_t(__popcll(__ballot(visit != 0)));
+        dbg_active += uint32_t(__popcll(__ballot(visit)));
         dbg_fm += fm ? 1u : 0u;
       }
       if (fm)
       {
-        if (flagged & 1u)
+        if (flagged)
         {
-          queue[qcount + uint32_t(__popcll(fm & lane_lt))] =
-            slot_bits | ((unsigned long long)pend_vi << kHitRayBits) | ((unsigned long long)pend_ray << ray_shift);
+          const uint32_t pos =
+            qcount + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u));
+          queue[pos] = make_uint2(vi_visit, ray);
         }
         qcount += uint32_t(__popcll(fm));
         if (qcount > uint32_t(kQueueCap - 64))
         {
-          flushQueue(queue, qcount, lane, lds_resolve, l_hits, n_region_hits, hb, l_intervals, l_counts, args.events,
-                     args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits, args.miss_counts,
-                     args.interval_counts, mc.region_voxels);
+          flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals,
+                     l_counts, args.events, args.event_capacity, args.event_count, defer_all, args.bs,
+                     args.sorted_hits, args.miss_counts, args.interval_counts, mc.region_voxels);
           qcount = 0;
         }
       }
-      pend_word = mword;
-      pend_vi = vi_visit;
-      pend_visit = visit;
-      pend_ray = ray_visit;
-    }
-  }
-  // Drain the last iteration's pending mask test.
-  {
-    const uint32_t flagged = (dbg & 10u) ? 0u : (pend_visit & (pend_word >> (pend_vi & 31)));
-    const unsigned long long fm = __ballot((flagged & 1u) != 0);
-    if (fm)
-    {
-      if (flagged & 1u)
-      {
-        queue[qcount + uint32_t(__popcll(fm & lane_lt))] =
-          slot_bits | ((unsigned long long)pend_vi << kHitRayBits) | ((unsigned long long)pend_ray << ray_shift);
-      }
-      qcount += uint32_t(__popcll(fm));
     }
   }
 
@@ -1243,9 +1235,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   // Final queue flush.
   if (qcount)
   {
-    flushQueue(queue, qcount, lane, lds_resolve, l_hits, n_region_hits, hb, l_intervals, l_counts, args.events,
-               args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits, args.miss_counts,
-               args.interval_counts, mc.region_voxels);
+    flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals, l_counts,
+               args.events, args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits,
+               args.miss_counts, args.interval_counts, mc.region_voxels);
   }
   __syncthreads();
 
@@ -1270,16 +1262,17 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
     {
       const uint32_t w = l_counts[i];
-      if (w)
+      if (w & (kTileCountMask | (kTileCountMask << 16)))
       {
 #pragma unroll
         for (uint32_t half = 0; half < 2; ++half)
         {
-          const uint32_t n = (w >> (16u * half)) & 0xffffu;
+          const uint32_t entry = (w >> (16u * half)) & 0xffffu;
+          const uint32_t n = entry & kTileCountMask;
           if (n)
           {
             const uint32_t v = 2 * i + half;
-            if ((l_mask[v >> 5] >> (v & 31)) & 1u)
+            if (entry & kTileFlag)
             {
               if (!defer_all)
               {
@@ -1300,17 +1293,17 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   // entries of masked voxels are skipped -- their visits travel as events.)
   for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
   {
-    const uint32_t w = (dbg & 4u) ? 0u : l_counts[i];
-    if (w)
+    const uint32_t w = l_counts[i];
+    if (w & (kTileCountMask | (kTileCountMask << 16)))
     {
 #pragma unroll
       for (uint32_t half = 0; half < 2; ++half)
       {
-        const uint32_t n = (w >> (16u * half)) & 0xffffu;
-        const uint32_t v = 2 * i + half;
-        if (n && !(defer_all && ((l_mask[v >> 5] >> (v & 31)) & 1u)))
+        const uint32_t entry = (w >> (16u * half)) & 0xffffu;
+        const uint32_t n = entry & kTileCountMask;
+        if (n && !(defer_all && (entry & kTileFlag)))
         {
-          atomicAdd(&g_counts[v], n);
+          atomicAdd(&g_counts[2 * i + half], n);
         }
       }
     }

@@ -92,15 +92,21 @@ enum : unsigned
   kRwWalk = 1u << 7           ///< ray part is walked (not kRfExcludeRay)
 };
 
-/// One (ray, region) unit of line-walk work: "resume ray `ray` with these per-axis step counts", i.e. the walk state
-/// at the step that enters the region (all zero for the ray's first segment).  Computed densely by k_ray_bin so the
-/// walk kernel's lane refill is a couple of loads.  Bit 31 of s0 marks the ray's first segment.
+/// One (ray, region) unit of line-walk work: "resume ray `ray` with these per-axis step counts and visit `count`
+/// voxels", i.e. the walk state at the step that enters the region (all zero for the ray's first segment) and the number
+/// of voxels the ray visits before it leaves the region or ends.  Computed densely by k_ray_bin so the walk kernel's
+/// lane refill is a couple of loads and its loop needs one counter instead of six.
+/// Packing: s0/s1/s2 hold the step counts in their low 24 bits (a ray crosses at most 2^16 regions x 255 voxels per
+/// axis); s0 bit 31 marks the ray's first segment, s0 bit 30 that the segment's last voxel is the ray's end voxel
+/// (visited as part of the ray); the voxel count (<= 3 x 255 + 1) sits in the top bytes of s1 (low 8 bits) and s2.
 struct Segment
 {
   uint32_t ray;
   uint32_t s0, s1, s2;
 };
 constexpr uint32_t kSegFirst = 0x80000000u;
+constexpr uint32_t kSegEnd = 0x40000000u;
+constexpr uint32_t kSegStepMask = 0x00ffffffu;
 
 struct Chunk
 {

@@ -100,7 +100,7 @@ struct ohmhip_map_s
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
   uint32_t event_demand = 0;
-  uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= 65535 (u16 LDS counters)
+  uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= kMaxChunkSegments (15-bit LDS counters)
   unsigned debug_flags = 0;  ///< OHMHIP_DEBUG_FLAGS: timing experiments only (breaks results)
   int refill_min_idle = kRefillMinIdle;      ///< tunable (OHMHIP_REFILL_MIN_IDLE)  ///< events the previous batch produced (sizes the next batch's list)
   void *h_stage = nullptr;  ///< pinned staging for host rays / region copies
@@ -404,8 +404,9 @@ unsigned sortEndBit(ohmhip_map_t m)
 
 size_t walkLdsBytes(const MapConst &mc)
 {
-  return (size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) + size_t((mc.region_voxels + 1) / 2) +
-          size_t((mc.region_voxels + 31) / 32) + 4) *
+  // [count tile, padded to 16 B][per-wave queues][staged sample keys][interval counters][cursor + pad]
+  const size_t count_words = (size_t((mc.region_voxels + 1) / 2) + 3u) & ~size_t(3);
+  return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) + 4) *
          sizeof(uint32_t);
 }
 
@@ -894,7 +895,7 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   }
   if (const char *env = std::getenv("OHMHIP_CHUNK_SEGMENTS"))
   {
-    m->chunk_segments = uint32_t(std::max(64, std::min(65535, std::atoi(env))));
+    m->chunk_segments = uint32_t(std::max(64, std::min(int(kMaxChunkSegments), std::atoi(env))));
   }
   if (const char *env = std::getenv("OHMHIP_DEBUG_FLAGS"))
   {
