@@ -501,10 +501,12 @@ __global__ void __launch_bounds__(1024)
   k_plan(RegionTable rt, BatchScratch bs, Chunk *__restrict__ chunks, uint32_t chunk_capacity,
          uint32_t chunk_segments)
 {
+  constexpr uint32_t kSizeClasses = 32;  // chunk size classes for the largest-first order (class = 32 * size / max)
   __shared__ uint32_t s_seg[1024];
   __shared__ uint32_t s_chk[1024];
   __shared__ uint32_t s_seg_base;
   __shared__ uint32_t s_chk_base;
+  __shared__ uint32_t s_class[kSizeClasses + 1];
   const uint32_t n = bs.info->n_touched;
   const uint32_t tid = threadIdx.x;
   if (tid == 0)
@@ -512,7 +514,13 @@ __global__ void __launch_bounds__(1024)
     s_seg_base = 0;
     s_chk_base = 0;
   }
+  if (tid <= kSizeClasses)
+  {
+    s_class[tid] = 0;
+  }
   __syncthreads();
+  // Pass 1: segment offsets per region (prefix sum in touched order) and the chunk size histogram.  A region with
+  // more than chunk_segments segments is split into equal chunks.
   for (uint32_t base = 0; base < n; base += 1024)
   {
     const uint32_t i = base + tid;
@@ -541,7 +549,6 @@ __global__ void __launch_bounds__(1024)
       __syncthreads();
     }
     const uint32_t seg_excl = s_seg_base + s_seg[tid] - cnt;
-    const uint32_t chk_excl = s_chk_base + s_chk[tid] - nchk;
     if (i < n)
     {
       const uint32_t slot = rt.vals[h];
@@ -553,16 +560,13 @@ __global__ void __launch_bounds__(1024)
         bs.hit_end[slot] = 0;
         bs.dirty[slot] = 1;
       }
-      for (uint32_t c = 0; c < nchk; ++c)
+      if (nchk)
       {
-        if (chk_excl + c < chunk_capacity)
+        const uint32_t per = (cnt + nchk - 1) / nchk;
+        for (uint32_t c = 0; c < nchk; ++c)
         {
-          Chunk ch;
-          ch.slot = slot;
-          ch.seg_begin = seg_excl + c * chunk_segments;
-          ch.seg_end = seg_excl + min(cnt, (c + 1) * chunk_segments);
-          ch.hash_index = h | ((nchk == 1) ? 0x80000000u : 0u);
-          chunks[chk_excl + c] = ch;
+          const uint32_t size = min(cnt, (c + 1) * per) - c * per;
+          atomicAdd(&s_class[min(size * kSizeClasses / chunk_segments, kSizeClasses)], 1u);
         }
       }
     }
@@ -573,6 +577,51 @@ __global__ void __launch_bounds__(1024)
       s_chk_base += s_chk[1023];
     }
     __syncthreads();
+  }
+  // Chunks are emitted largest class first: the persistent walk workgroups take them in this order, so the launch
+  // ends on its smallest chunks.
+  if (tid == 0)
+  {
+    uint32_t run = 0;
+    for (int c = int(kSizeClasses); c >= 0; --c)
+    {
+      const uint32_t count = s_class[c];
+      s_class[c] = run;
+      run += count;
+    }
+  }
+  __syncthreads();
+  // Pass 2: emit the chunk records.
+  for (uint32_t base = 0; base < n; base += 1024)
+  {
+    const uint32_t i = base + tid;
+    if (i < n)
+    {
+      const uint32_t h = bs.touched[i];
+      const uint32_t cnt = bs.seg_count[h];
+      const uint32_t nchk = (cnt + chunk_segments - 1) / chunk_segments;
+      if (nchk)
+      {
+        const uint32_t seg_excl = bs.seg_offset[h];
+        const uint32_t slot = rt.vals[h];
+        const uint32_t per = (cnt + nchk - 1) / nchk;
+        for (uint32_t c = 0; c < nchk; ++c)
+        {
+          const uint32_t begin = c * per;
+          const uint32_t end = min(cnt, (c + 1) * per);
+          const uint32_t pos = atomicAdd(&s_class[min((end - begin) * kSizeClasses / chunk_segments, kSizeClasses)], 1u);
+          if (pos < chunk_capacity)
+          {
+            Chunk ch;
+            ch.slot = slot;
+            ch.seg_begin = seg_excl + begin;
+            ch.seg_end = seg_excl + end;
+            ch.hash_index = h | ((nchk == 1) ? 0x80000000u : 0u);
+            chunks[pos] = ch;
+          }
+        }
+      }
+    }
   }
   if (tid == 0)
   {
@@ -851,7 +900,10 @@ constexpr int kLdsHits = 7168;     ///< a region's sample list is staged in LDS 
 constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
 constexpr uint32_t kTileFlag = 0x8000u;       ///< mask flag inside a u16 tile entry
 constexpr uint32_t kTileCountMask = 0x7fffu;  ///< count bits of a u16 tile entry (a chunk adds <= kMaxChunkSegments)
-constexpr uint32_t kMaxChunkSegments = 16384;
+constexpr uint32_t kMaxChunkSegments = 8192;  ///< bounded by the 15-bit counters and by the LDS order array
+constexpr uint32_t kTraceChunks = 4096;  ///< debug trace: records kept per launch
+constexpr uint32_t kTraceWords = 32;     ///< debug trace: u64 words per record
+constexpr uint32_t kLengthClasses = 128;      ///< segment length histogram bins (lengths above the last bin share it)
 
 /// Resolve one deferred miss event: find the first sample of the same voxel with a larger ray index; the miss counts
 /// towards the interval before that sample, or towards the voxel's trailing count if there is none.
@@ -966,6 +1018,8 @@ struct WalkArgs
   unsigned ray_flags;
   unsigned long long *dbg_counters;
   float *traversal;  ///< kTraversal instantiations: per-visit ray length accumulation (global float atomics)
+  uint32_t *chunk_cursor;  ///< device-wide next-chunk cursor (zeroed before the launch)
+  uint32_t n_chunks;
 };
 
 /// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
@@ -978,8 +1032,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const MapConst &mc = args.mc;
-  // Layout: [count tile: ceil(region_voxels / 2) words][queues][staged sample keys][interval counters][cursor].
-  // The tile sits at offset 0 so the per-visit atomic needs no base add.
+  // Layout: [count tile: ceil(region_voxels / 2) words][queues][staged sample keys][interval counters][cursor]
+  // [length histogram][segment order: u16 per segment].  The tile sits at offset 0 so the per-visit atomic needs no
+  // base add.
   const uint32_t count_words = uint32_t(mc.region_voxels + 1) >> 1;
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
   uint32_t *l_counts = lds;
@@ -987,42 +1042,187 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   unsigned long long *l_hits = reinterpret_cast<unsigned long long *>(l_queues + kWalkWaves * kQueueCap);
   uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] u16 interval counters
   uint32_t *l_cursor = l_intervals + kLdsHits / 2;
+  uint32_t *l_hist = l_cursor + 4;
+  uint16_t *l_order = reinterpret_cast<uint16_t *>(l_hist + kLengthClasses);
 
-  const Chunk chunk = args.chunks[blockIdx.x];
-  const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
-  // Tile entries start at zero count with the voxel's mask flag in the top bit.
-  for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
+  // Persistent workgroups: the launch has one workgroup per CU and each takes chunks from a device-wide cursor until
+  // none are left.  A static blockIdx -> chunk binding leaves the hardware's round-robin of workgroups over the 8 XCDs
+  // in charge of the balance, and chunk costs vary enough that some XCDs then finish in half the time of others.
+  if (threadIdx.x == 0)
   {
-    const uint32_t two = (g_mask[i >> 4] >> ((i & 15u) * 2u)) & 3u;
-    l_counts[i] = ((two & 1u) << 15) | ((two & 2u) << 30);
+    l_cursor[1] = atomicAdd(args.chunk_cursor, 1u);
+  }
+  __syncthreads();
+  // (readfirstlane: the value is wave-uniform, so the loop condition is a scalar branch and the barriers inside the
+  // loop are not restructured as if threads could leave at different trips.)
+  uint32_t chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
+  while (chunk_index < args.n_chunks)
+  {
+  const unsigned long long clk_start = args.dbg_counters ? wall_clock64() : 0ull;
+  const Chunk chunk = args.chunks[chunk_index];
+  const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
+  const Segment *chunk_segments = args.segments + chunk.seg_begin;
+  const int defer_all = args.defer_all;
+
+  // ---- prologue.  One workgroup owns the CU (the tile takes most of its LDS), so nothing overlaps this phase: every
+  // ---- global load that depends only on the chunk record is issued back to back, clamped instead of predicated so
+  // ---- the loads share one basic block, and consumed afterwards.
+  const uint32_t hb = defer_all ? 0u : args.bs.hit_begin[chunk.slot];
+  const uint32_t he = defer_all ? 0u : args.bs.hit_end[chunk.slot];
+  constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
+  constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
+  uint32_t lens[kSegPerThread];
+#pragma unroll
+  for (int j = 0; j < kSegPerThread; ++j)
+  {
+    const uint32_t i = min(threadIdx.x + uint32_t(j) * kWalkThreads, n_seg - 1u);
+    const uint2 w = *reinterpret_cast<const uint2 *>(&chunk_segments[i].s1);
+    lens[j] = min((w.x >> 24) | ((w.y >> 24) << 8), kLengthClasses - 1u);
+  }
+  const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
+  const uint32_t my_mask = g_mask[min(threadIdx.x, mask_words - 1u)];
+  // Stage the region's sorted sample keys so deferred misses can be ordered against them at LDS latency.
+  const uint32_t n_region_hits = he - hb;
+  const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(kLdsHits);
+  unsigned long long my_hits[kHitsPerThread];
+  if (lds_resolve && n_region_hits)
+  {
+#pragma unroll
+    for (int j = 0; j < kHitsPerThread; ++j)
+    {
+      my_hits[j] = args.sorted_hits[hb + min(threadIdx.x + uint32_t(j) * kWalkThreads, n_region_hits - 1u)];
+    }
+  }
+  if (threadIdx.x < kLengthClasses)
+  {
+    l_hist[threadIdx.x] = 0;
   }
   if (threadIdx.x == 0)
   {
-    *l_cursor = 0;
+    l_cursor[0] = 0;
+    l_cursor[1] = atomicAdd(args.chunk_cursor, 1u);  // next chunk of this workgroup (read at the end of the trip)
   }
-  // Stage the region's sorted sample keys so deferred misses can be ordered against them at LDS latency.
-  const int defer_all = args.defer_all;
-  const uint32_t hb = defer_all ? 0u : args.bs.hit_begin[chunk.slot];
-  const uint32_t he = defer_all ? 0u : args.bs.hit_end[chunk.slot];
-  const uint32_t n_region_hits = he - hb;
-  const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(kLdsHits);
-  if (lds_resolve)
+  const bool stamp = args.dbg_counters && threadIdx.x == 0;
+  unsigned long long clk_p[6] = { 0, 0, 0, 0, 0, 0 };
+  if (stamp)
   {
-    for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
+    clk_p[0] = wall_clock64();
+  }
+  // Tile entries start at zero count with the voxel's mask flag in the top bit: one mask word covers 16 tile words.
+  for (uint32_t w = threadIdx.x; w < mask_words; w += kWalkThreads)
+  {
+    const uint32_t mword = (w == threadIdx.x) ? my_mask : g_mask[w];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q)
     {
-      l_hits[i] = args.sorted_hits[hb + i];
+      uint32_t v[4];
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r)
+      {
+        const uint32_t two = (mword >> ((q * 4u + r) * 2u)) & 3u;
+        v[r] = ((two & 1u) << 15) | ((two & 2u) << 30);
+      }
+      if (w * 16u + q * 4u + 3u < count_words)
+      {
+        *reinterpret_cast<uint4 *>(&l_counts[w * 16u + q * 4u]) = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      else
+      {
+        for (uint32_t r = 0; r < 4; ++r)
+        {
+          if (w * 16u + q * 4u + r < count_words)
+          {
+            l_counts[w * 16u + q * 4u + r] = v[r];
+          }
+        }
+      }
     }
-    for (uint32_t i = threadIdx.x; i < (n_region_hits + 1) / 2; i += kWalkThreads)
+  }
+  if (stamp)
+  {
+    clk_p[1] = wall_clock64();
+  }
+  __syncthreads();
+  if (stamp)
+  {
+    clk_p[2] = wall_clock64();
+  }
+  // Longest segments first (counting sort on the voxel count, indices in LDS): lanes refilled together get segments
+  // of similar length and so retire together, and the workgroup drains on its SHORTEST segments instead of waiting
+  // for a few long stragglers.  The order inside a length class is arbitrary; integer counting does not care.
+#pragma unroll
+  for (int j = 0; j < kSegPerThread; ++j)
+  {
+    if (threadIdx.x + uint32_t(j) * kWalkThreads < n_seg)
     {
-      l_intervals[i] = 0;  // two u16 counters per word (a chunk adds at most kMaxChunkSegments to one counter)
+      atomicAdd(&l_hist[lens[j]], 1u);
+    }
+  }
+  if (lds_resolve && n_region_hits)
+  {
+#pragma unroll
+    for (int j = 0; j < kHitsPerThread; ++j)
+    {
+      const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
+      if (i < n_region_hits)
+      {
+        l_hits[i] = my_hits[j];
+      }
+      if (i < (n_region_hits + 1) / 2)
+      {
+        l_intervals[i] = 0;  // two u16 counters per word (a chunk adds at most kMaxChunkSegments to one counter)
+      }
     }
   }
   __syncthreads();
+  if (stamp)
+  {
+    clk_p[3] = wall_clock64();
+  }
+  if (threadIdx.x < 64)
+  {
+    // Exclusive scan over the classes in DESCENDING length order: lane l owns classes 127 - 2l and 126 - 2l.
+    const uint32_t hi_class = kLengthClasses - 1u - 2u * threadIdx.x;
+    const uint32_t a = l_hist[hi_class];
+    const uint32_t b = l_hist[hi_class - 1u];
+    uint32_t incl = a + b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t up = __shfl_up(incl, d);
+      incl += (int(threadIdx.x) >= d) ? up : 0u;
+    }
+    const uint32_t excl = incl - (a + b);
+    l_hist[hi_class] = excl;
+    l_hist[hi_class - 1u] = excl + a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kSegPerThread; ++j)
+  {
+    const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
+    if (i < n_seg)
+    {
+      l_order[atomicAdd(&l_hist[lens[j]], 1u)] = uint16_t(i);
+    }
+  }
+  __syncthreads();
+  if (stamp)
+  {
+    clk_p[4] = wall_clock64();
+    if (chunk_index < kTraceChunks)
+    {
+      unsigned long long *rec = args.dbg_counters + 16 + size_t(chunk_index) * kTraceWords;
+      rec[20] = clk_p[0];
+      rec[21] = clk_p[1];
+      rec[22] = clk_p[2];
+      rec[23] = clk_p[3];
+    }
+  }
 
   const unsigned lane = laneId();
   const unsigned wave = threadIdx.x >> 6;
   uint2 *queue = l_queues + wave * kQueueCap;
-  const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
   const int dimx = mc.dim[0];
   const int dimxy = mc.dim[0] * mc.dim[1];
   const double inf = dInf();
@@ -1046,6 +1246,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   uint32_t qcount = 0;     // wave-uniform
   bool exhausted = false;  // wave-uniform
   uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;  // wave-uniform
+  const unsigned long long clk_loop = args.dbg_counters ? wall_clock64() : 0ull;
 
   while (true)
   {
@@ -1067,7 +1268,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         base + __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
       if (left <= 0 && mine < n_seg)
       {
-        const Segment seg = args.segments[chunk.seg_begin + mine];
+        const Segment seg = chunk_segments[l_order[mine]];
         const RayWalk rw = args.walks[seg.ray];
         const int s0 = int(seg.s0 & kSegStepMask);
         const int s1 = int(seg.s1 & kSegStepMask);
@@ -1225,12 +1426,33 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     }
   }
 
+  unsigned long long clk_end_loop = 0;
   if (args.dbg_counters && lane == 0)
   {
-    atomicAdd(&args.dbg_counters[0], (unsigned long long)dbg_iters);
-    atomicAdd(&args.dbg_counters[1], (unsigned long long)dbg_active);
-    atomicAdd(&args.dbg_counters[2], (unsigned long long)dbg_refills);
-    atomicAdd(&args.dbg_counters[3], (unsigned long long)dbg_fm);
+    clk_end_loop = wall_clock64();
+    if (chunk_index < kTraceChunks)
+    {
+      unsigned long long *rec = args.dbg_counters + 16 + size_t(chunk_index) * kTraceWords;
+      if (wave < 15)
+      {
+        rec[2 + wave] = clk_end_loop;
+      }
+      if (wave == 0)
+      {
+        rec[0] = n_seg | ((unsigned long long)((chunk.hash_index >> 31) & 1u) << 32);
+        rec[1] = clk_loop;
+        rec[18] = clk_start;
+        rec[17] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
+                  ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_ID | XCC_ID
+      }
+    }
+    if (args.dbg & 128u)
+    {
+      atomicAdd(&args.dbg_counters[0], (unsigned long long)dbg_iters);
+      atomicAdd(&args.dbg_counters[1], (unsigned long long)dbg_active);
+      atomicAdd(&args.dbg_counters[2], (unsigned long long)dbg_refills);
+      atomicAdd(&args.dbg_counters[3], (unsigned long long)dbg_fm);
+    }
   }
   // Final queue flush.
   if (qcount)
@@ -1240,6 +1462,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
                args.miss_counts, args.interval_counts, mc.region_voxels);
   }
   __syncthreads();
+  if (stamp && chunk_index < kTraceChunks)
+  {
+    args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 24] = wall_clock64();  // epilogue start
+  }
 
   if (lds_resolve)
   {
@@ -1259,35 +1485,74 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // straight from LDS (no count round trip through HBM).  Voxels which also receive samples keep their count for
     // the ordered replay (occupancy: k_apply_hits; NDT: their visits are events, the tile entry is not used).
     float *g_occ = args.occupancy + size_t(chunk.slot) * size_t(mc.region_voxels);
-    for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
-    {
-      const uint32_t w = l_counts[i];
-      if (w & (kTileCountMask | (kTileCountMask << 16)))
-      {
+    // Two passes so the loads of all the voxels a thread updates are in flight together (a load -> update -> store
+    // loop would pay the memory latency once per touched word, and nothing else runs on this CU to hide it).
+    constexpr uint32_t kWordsPerThread = (1u << kHitVoxelBits) / 2u / kWalkThreads;
+    uint32_t words[kWordsPerThread];
+    float2 values[kWordsPerThread];
+    const bool even_voxels = (mc.region_voxels & 1) == 0;
 #pragma unroll
-        for (uint32_t half = 0; half < 2; ++half)
+    for (uint32_t j = 0; j < kWordsPerThread; ++j)
+    {
+      const uint32_t i = threadIdx.x + j * kWalkThreads;
+      uint32_t w = (i < count_words) ? l_counts[i] : 0u;
+      // Keep only the entries applied here: unflagged voxels with a count.
+      w = (w & kTileFlag) ? (w & 0xffff0000u) : w;
+      w = (w & (kTileFlag << 16)) ? (w & 0x0000ffffu) : w;
+      const uint32_t flagged_w = (i < count_words) ? l_counts[i] : 0u;
+      if (!defer_all)
+      {
+        // Voxels which also receive samples keep their count for the ordered replay (k_apply_hits).
+        if ((flagged_w & kTileFlag) && (flagged_w & kTileCountMask))
         {
-          const uint32_t entry = (w >> (16u * half)) & 0xffffu;
-          const uint32_t n = entry & kTileCountMask;
-          if (n)
-          {
-            const uint32_t v = 2 * i + half;
-            if (entry & kTileFlag)
-            {
-              if (!defer_all)
-              {
-                atomicAdd(&g_counts[v], n);
-              }
-            }
-            else
-            {
-              g_occ[v] = occMissN(mc, args.ray_flags, g_occ[v], n);
-            }
-          }
+          atomicAdd(&g_counts[2 * i], flagged_w & kTileCountMask);
+        }
+        if ((flagged_w & (kTileFlag << 16)) && ((flagged_w >> 16) & kTileCountMask))
+        {
+          atomicAdd(&g_counts[2 * i + 1], (flagged_w >> 16) & kTileCountMask);
+        }
+      }
+      words[j] = w;
+      values[j] = make_float2(0.0f, 0.0f);
+      if (w)
+      {
+        if (even_voxels)
+        {
+          values[j] = *reinterpret_cast<const float2 *>(&g_occ[2 * i]);
+        }
+        else
+        {
+          values[j].x = g_occ[2 * i];
+          values[j].y = (2 * i + 1 < uint32_t(mc.region_voxels)) ? g_occ[2 * i + 1] : 0.0f;
         }
       }
     }
-    return;
+#pragma unroll
+    for (uint32_t j = 0; j < kWordsPerThread; ++j)
+    {
+      const uint32_t i = threadIdx.x + j * kWalkThreads;
+      const uint32_t w = words[j];
+      if (w)
+      {
+        const uint32_t n0 = w & kTileCountMask;
+        const uint32_t n1 = (w >> 16) & kTileCountMask;
+        if (n0)
+        {
+          g_occ[2 * i] = occMissN(mc, args.ray_flags, values[j].x, n0);
+        }
+        if (n1)
+        {
+          g_occ[2 * i + 1] = occMissN(mc, args.ray_flags, values[j].y, n1);
+        }
+      }
+    }
+    if (stamp && chunk_index < kTraceChunks)
+    {
+      args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
+    }
+    __syncthreads();
+    chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
+    continue;
   }
   // Flush the tile: integer adds, so the merge across chunks of one region is order independent.  (NDT / TSDF:
   // entries of masked voxels are skipped -- their visits travel as events.)
@@ -1308,6 +1573,14 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       }
     }
   }
+  if (stamp && chunk_index < kTraceChunks)
+  {
+    args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
+  }
+  // The tile is reused by the next trip: everyone must be done reading it.
+  __syncthreads();
+  chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
+  }  // chunk loop
 }
 
 /// Resolve the deferred miss events (grid-stride; the event count lives in device memory).

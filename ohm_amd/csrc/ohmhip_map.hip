@@ -96,7 +96,8 @@ struct ohmhip_map_s
   uint32_t chunk_capacity = 0;
 
   DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev, events;
-  uint32_t *d_event_count = nullptr;
+  uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor
+  uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
   uint32_t event_demand = 0;
@@ -402,11 +403,15 @@ unsigned sortEndBit(ohmhip_map_t m)
   return std::min<unsigned>(64u, unsigned(kHitSlotShift) + bits + 1u);
 }
 
-size_t walkLdsBytes(const MapConst &mc)
+constexpr size_t kDbgWords = 16 + size_t(kTraceChunks) * kTraceWords;
+
+size_t walkLdsBytes(const MapConst &mc, uint32_t chunk_segments)
 {
   // [count tile, padded to 16 B][per-wave queues][staged sample keys][interval counters][cursor + pad]
+  // [length histogram][segment order, u16 each]
   const size_t count_words = (size_t((mc.region_voxels + 1) / 2) + 3u) & ~size_t(3);
-  return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) + 4) *
+  return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) + 4 +
+          kLengthClasses + (chunk_segments + 1) / 2) *
          sizeof(uint32_t);
 }
 
@@ -551,7 +556,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     {
       for (int walk_attempt = 0; walk_attempt < 4; ++walk_attempt)
       {
-        OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, sizeof(uint32_t), s));
+        OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, 2 * sizeof(uint32_t), s));
         WalkArgs wa;
         wa.mc = m->mc;
         wa.bs = batchScratch(m);
@@ -573,11 +578,13 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.ray_flags = ray_flags;
         wa.dbg_counters = (m->debug_flags & 64u) ? m->d_dbg : nullptr;
         wa.traversal = sec.traversal;
+        wa.chunk_cursor = m->d_event_count + 1;
+        wa.n_chunks = info.n_chunks;
         // The lean instantiation applies unless some ray's end voxel is part of its walk or origins are excluded.
         const bool special = (ray_flags & (OHMHIP_RF_END_POINT_AS_FREE | OHMHIP_RF_EXCLUDE_ORIGIN)) ||
                              m->mc.filter_mode == OHMHIP_FILTER_CLIP;
-        const dim3 wgrid(info.n_chunks), wblock(kWalkThreads);
-        const size_t wlds = walkLdsBytes(m->mc);
+        const dim3 wgrid(std::min<uint32_t>(info.n_chunks, m->walk_workgroups)), wblock(kWalkThreads);
+        const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments);
         if (special && sec.traversal)
         {
           hipLaunchKernelGGL((k_region_walk<true, true>), wgrid, wblock, wlds, s, wa);
@@ -855,15 +862,15 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   {
     return fail(err);
   }
-  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_event_count), sizeof(uint32_t))) != 0)
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_event_count), 2 * sizeof(uint32_t))) != 0)
   {
     return fail(err);
   }
-  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_dbg), 8 * sizeof(unsigned long long))) != 0)
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_dbg), kDbgWords * sizeof(unsigned long long))) != 0)
   {
     return fail(err);
   }
-  (void)hipMemset(m->d_dbg, 0, 8 * sizeof(unsigned long long));
+  (void)hipMemset(m->d_dbg, 0, kDbgWords * sizeof(unsigned long long));
   if ((err = hipHostMalloc(reinterpret_cast<void **>(&m->h_info), 2 * sizeof(BatchInfo), hipHostMallocDefault)) != 0)
   {
     return fail(err);
@@ -880,8 +887,25 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   {
     return fail(err);
   }
-  // The walk kernel stages a region's count tile + hit mask in LDS (68 KiB for 32^3).
-  const size_t lds_bytes = walkLdsBytes(mc);
+  {
+    int device = 0, cus = 0;
+    if (hipGetDevice(&device) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+    {
+      m->walk_workgroups = uint32_t(cus);
+    }
+  }
+  if (const char *env = std::getenv("OHMHIP_CHUNK_SEGMENTS"))
+  {
+    m->chunk_segments = uint32_t(std::max(64, std::min(int(kMaxChunkSegments), std::atoi(env))));
+  }
+  // The walk kernel keeps a region's count tile, the staged samples and the chunk's segment order in LDS (about
+  // 150 KiB of the CU's 160 KiB for 32^3 regions): the chunk size gives way if the region tile is large.
+  while (walkLdsBytes(mc, m->chunk_segments) > size_t(160) * 1024 && m->chunk_segments > 64)
+  {
+    m->chunk_segments /= 2;
+  }
+  const size_t lds_bytes = walkLdsBytes(mc, m->chunk_segments);
   const void *walk_kernels[4] = { reinterpret_cast<const void *>(k_region_walk<false, false>),
                                   reinterpret_cast<const void *>(k_region_walk<false, true>),
                                   reinterpret_cast<const void *>(k_region_walk<true, false>),
@@ -892,10 +916,6 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
     {
       return fail(err);
     }
-  }
-  if (const char *env = std::getenv("OHMHIP_CHUNK_SEGMENTS"))
-  {
-    m->chunk_segments = uint32_t(std::max(64, std::min(int(kMaxChunkSegments), std::atoi(env))));
   }
   if (const char *env = std::getenv("OHMHIP_DEBUG_FLAGS"))
   {
@@ -1104,10 +1124,31 @@ int ohmhip_map_sync(ohmhip_map_t m)
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   if (m->debug_flags & 64u)
   {
-    unsigned long long c[8];
+    static unsigned long long c[kDbgWords];
     OHMHIP_CHECK(hipMemcpy(c, m->d_dbg, sizeof(c), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "[ohmhip dbg] wave-iterations %llu visits %llu refills %llu flagged-iterations %llu\n", c[0], c[1], c[2],
                  c[3]);
+    if (const char *path = std::getenv("OHMHIP_DEBUG_TRACE"))
+    {
+      if (FILE *f = std::fopen(path, "w"))
+      {
+        for (size_t b = 0; b < kTraceChunks; ++b)
+        {
+          const unsigned long long *rec = c + 16 + b * kTraceWords;
+          if (rec[1] == 0)
+          {
+            continue;
+          }
+          std::fprintf(f, "%zu", b);
+          for (int k = 0; k < 25; ++k)
+          {
+            std::fprintf(f, " %llu", rec[k]);
+          }
+          std::fprintf(f, "\n");
+        }
+        std::fclose(f);
+      }
+    }
     OHMHIP_CHECK(hipMemset(m->d_dbg, 0, sizeof(c)));
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
