@@ -48,6 +48,19 @@ struct BatchScratch
   uint32_t *dirty;         ///< [slot_capacity]
   uint32_t *voxel_first_hit;  ///< [slot_capacity * region_voxels] index of a voxel's first sample in the sorted list
   BatchInfo *info;
+  struct WgRegion *wg_regions;  ///< [workgroups * kLtabSize] regions each binning workgroup feeds (k_ray_setup -> bin)
+  uint32_t *wg_region_count;    ///< [workgroups]
+};
+
+/// One region a binning workgroup feeds: written by k_ray_setup, consumed by k_ray_bin (same workgroup -> rays mapping),
+/// which therefore does not have to enumerate the rays' regions a second time just to count.
+struct WgRegion
+{
+  unsigned long long key;
+  uint32_t count;  ///< segments of the workgroup's rays in the region
+  uint32_t entry;  ///< position in the workgroup's LDS region table
+  uint32_t hash;   ///< index in the global region table
+  uint32_t pad;
 };
 
 enum : uint32_t
@@ -250,7 +263,7 @@ __device__ inline void waveMatch(bool has, uint32_t value, unsigned lane, int &l
 // one address serialise at the memory side (that, not arithmetic, dominated the first version of these kernels).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kBinThreads = 512;
-constexpr int kBinRaysPerBlock = 2048;
+constexpr int kBinRaysPerBlock = 1024;
 constexpr uint32_t kLtabSize = 2048;  ///< entries (power of two)
 
 struct LdsRegionTable
@@ -329,6 +342,14 @@ __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, boo
       f(p_key, 0u, 0u, 0u);
     }
   }
+  // Reciprocals of the step deltas for the step-count estimates (one division per axis per ray, not per crossing).
+  double r0 = 0, r1 = 0, r2 = 0;
+  if (with_resume_state)
+  {
+    r0 = 1.0 / rw.delta[0];
+    r1 = 1.0 / rw.delta[1];
+    r2 = 1.0 / rw.delta[2];
+  }
   int axis, j;
   while (regionCursorNext(mc, rw, rc, axis, j))
   {
@@ -345,9 +366,9 @@ __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, boo
     }
     const double ta = stepTime(sel3(axis, rw.init[0], rw.init[1], rw.init[2]),
                                sel3(axis, rw.delta[0], rw.delta[1], rw.delta[2]), j);
-    const uint32_t rs0 = uint32_t((axis == 0) ? j : stepsBefore(rw.init[0], rw.delta[0], rw.total[0], 0, axis, ta));
-    const uint32_t rs1 = uint32_t((axis == 1) ? j : stepsBefore(rw.init[1], rw.delta[1], rw.total[1], 1, axis, ta));
-    const uint32_t rs2 = uint32_t((axis == 2) ? j : stepsBefore(rw.init[2], rw.delta[2], rw.total[2], 2, axis, ta));
+    const uint32_t rs0 = uint32_t((axis == 0) ? j : stepsBefore(rw.init[0], rw.delta[0], r0, rw.total[0], 0, axis, ta));
+    const uint32_t rs1 = uint32_t((axis == 1) ? j : stepsBefore(rw.init[1], rw.delta[1], r1, rw.total[1], 1, axis, ta));
+    const uint32_t rs2 = uint32_t((axis == 2) ? j : stepsBefore(rw.init[2], rw.delta[2], r2, rw.total[2], 2, axis, ta));
     const int sum = int(rs0 + rs1 + rs2);
     if (have)
     {
@@ -400,6 +421,7 @@ __global__ void __launch_bounds__(kBinThreads)
   __shared__ LdsRegionTable tab;
   __shared__ unsigned long long s_visits;
   __shared__ uint32_t s_rays_ok;
+  __shared__ uint32_t s_list_n;
   for (uint32_t i = threadIdx.x; i < kLtabSize; i += kBinThreads)
   {
     tab.keys[i] = 0;
@@ -409,6 +431,7 @@ __global__ void __launch_bounds__(kBinThreads)
   {
     s_visits = 0;
     s_rays_ok = 0;
+    s_list_n = 0;
   }
   __syncthreads();
 
@@ -490,7 +513,19 @@ __global__ void __launch_bounds__(kBinThreads)
         atomicAdd(&bs.seg_count[h], c);
       }
       markTouched(bs, h);
+      WgRegion wr;
+      wr.key = key;
+      wr.count = c;
+      wr.entry = e;
+      wr.hash = h;
+      wr.pad = 0;
+      bs.wg_regions[size_t(blockIdx.x) * kLtabSize + atomicAdd(&s_list_n, 1u)] = wr;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    bs.wg_region_count[blockIdx.x] = s_list_n;
   }
 }
 
@@ -659,7 +694,19 @@ __global__ void __launch_bounds__(kBinThreads)
   const uint32_t last = min(first + kBinRaysPerBlock, n_rays);
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
 
-  // Step 1: per-region segment counts of this workgroup; sample keys and mask bits on the way.
+  // Step 1: the workgroup's regions and segment counts come from k_ray_setup (same rays, same LDS table layout);
+  // reserve one contiguous range in every region bucket it feeds.
+  const uint32_t n_wg_regions = bs.wg_region_count[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < n_wg_regions; i += kBinThreads)
+  {
+    const WgRegion wr = bs.wg_regions[size_t(blockIdx.x) * kLtabSize + i];
+    tab.keys[wr.entry] = wr.key;
+    if (wr.count)
+    {
+      tab.cursor[wr.entry] = bs.seg_offset[wr.hash] + atomicAdd(&bs.seg_cursor[wr.hash], wr.count);
+    }
+  }
+  // Step 2: sample keys and mask bits.
   uint32_t my_hits = 0;
   for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
   {
@@ -682,13 +729,6 @@ __global__ void __launch_bounds__(kBinThreads)
       }
     }
     hit_keys[ray] = hk;
-    forEachSegment(mc, rw, false, [&](uint64_t key, uint32_t, uint32_t, uint32_t) {
-      const uint32_t e = ltabFindOrInsert(tab, key);
-      if (e < kLtabSize)
-      {
-        atomicAdd(&tab.count[e], 1u);
-      }
-    });
   }
   atomicAdd(&s_hits, my_hits);
   __syncthreads();
@@ -696,18 +736,6 @@ __global__ void __launch_bounds__(kBinThreads)
   {
     atomicAdd(&bs.info->n_hits, s_hits);
   }
-  // Step 2: reserve this workgroup's range in every region bucket it feeds.
-  for (uint32_t e = threadIdx.x; e < kLtabSize; e += kBinThreads)
-  {
-    const unsigned long long key = tab.keys[e];
-    const uint32_t c = tab.count[e];
-    if (key && c)
-    {
-      const uint32_t h = regionFind(rt, key);
-      tab.cursor[e] = bs.seg_offset[h] + atomicAdd(&bs.seg_cursor[h], c);
-    }
-  }
-  __syncthreads();
   // Step 3: scatter.
   for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
   {

@@ -96,6 +96,7 @@ struct ohmhip_map_s
   uint32_t chunk_capacity = 0;
 
   DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev, events;
+  DevBuf wg_regions, wg_region_count;
   uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
@@ -142,6 +143,8 @@ BatchScratch batchScratch(ohmhip_map_t m)
   bs.hit_end = m->d_hit_end;
   bs.dirty = m->d_dirty;
   bs.info = m->d_info;
+  bs.wg_regions = static_cast<WgRegion *>(m->wg_regions.ptr);
+  bs.wg_region_count = static_cast<uint32_t *>(m->wg_region_count.ptr);
   return bs;
 }
 
@@ -403,6 +406,11 @@ unsigned sortEndBit(ohmhip_map_t m)
   return std::min<unsigned>(64u, unsigned(kHitSlotShift) + bits + 1u);
 }
 
+/// rocPRIM falls back to a 20-launch merge sort for up to 2^20 keys by default; the one-sweep radix path is several
+/// times faster on the 1M-key sample lists of a typical batch.
+using SortConfig =
+  rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, size_t(1) << 15>;
+
 constexpr size_t kDbgWords = 16 + size_t(kTraceChunks) * kTraceWords;
 
 size_t walkLdsBytes(const MapConst &mc, uint32_t chunk_segments)
@@ -455,13 +463,15 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   sec.time_base = m->first_ray_time;
 
   OHMHIP_CHECK(m->walks.ensure(sizeof(RayWalk) * size_t(n_rays), false, s));
+  OHMHIP_CHECK(m->wg_regions.ensure(sizeof(WgRegion) * size_t(bin_blocks) * kLtabSize, false, s));
+  OHMHIP_CHECK(m->wg_region_count.ensure(sizeof(uint32_t) * size_t(bin_blocks), false, s));
   if (occupancy_mode)
   {
     OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
     OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
     OHMHIP_CHECK(m->interval_counts.ensure(sizeof(uint32_t) * size_t(n_rays), true, s));
     size_t sort_bytes = 0;
-    OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, static_cast<unsigned long long *>(m->hit_keys_a.ptr),
+    OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(nullptr, sort_bytes, static_cast<unsigned long long *>(m->hit_keys_a.ptr),
                                           static_cast<unsigned long long *>(m->hit_keys_b.ptr), size_t(n_rays),
                                           kHitRayBits, sortEndBit(m), s));
     OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
@@ -540,7 +550,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       size_t temp_bytes = m->sort_temp.bytes;
       // Sample keys are emitted in ray order and the radix sort is stable: sorting on the (slot, voxel) bits alone
       // leaves each voxel's samples in ray order.
-      OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays), kHitRayBits,
+      OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays), kHitRayBits,
                                             sortEndBit(m), s));
       hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m), m->mc.region_voxels);
     }
@@ -665,10 +675,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     {
       const size_t total = size_t(n_rays) + size_t(n_events);
       size_t sort_bytes = 0;
-      OHMHIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
+      OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(nullptr, sort_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
       OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
       size_t temp_bytes = m->sort_temp.bytes;
-      OHMHIP_CHECK(rocprim::radix_sort_keys(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
+      OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
       const uint32_t replay_blocks = uint32_t((total + 127) / 128);
       if (ndt_mode)
       {
@@ -954,6 +964,8 @@ int ohmhip_map_destroy(ohmhip_map_t m)
   m->intens_dev.release();
   m->times_dev.release();
   m->events.release();
+  m->wg_regions.release();
+  m->wg_region_count.release();
   if (m->d_event_count)
   {
     (void)hipFree(m->d_event_count);

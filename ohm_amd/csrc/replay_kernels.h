@@ -298,9 +298,9 @@ __global__ void __launch_bounds__(256)
   if (t_star > 0)
   {
     // Steps strictly before t_star form a valid prefix of the walk (axis == 3 disables the tie rule).
-    s0 = stepsBefore(rw.init[0], rw.delta[0], rw.total[0], 0, 3, t_star);
-    s1 = stepsBefore(rw.init[1], rw.delta[1], rw.total[1], 1, 3, t_star);
-    s2 = stepsBefore(rw.init[2], rw.delta[2], rw.total[2], 2, 3, t_star);
+    s0 = stepsBefore(rw.init[0], rw.delta[0], 1.0 / rw.delta[0], rw.total[0], 0, 3, t_star);
+    s1 = stepsBefore(rw.init[1], rw.delta[1], 1.0 / rw.delta[1], rw.total[1], 1, 3, t_star);
+    s2 = stepsBefore(rw.init[2], rw.delta[2], 1.0 / rw.delta[2], rw.total[2], 2, 3, t_star);
   }
   const int d0 = rwDir(rw, 0), d1 = rwDir(rw, 1), d2 = rwDir(rw, 2);
   int g0 = rw.g0[0] + d0 * s0, g1 = rw.g0[1] + d1 * s1, g2 = rw.g0[2] + d2 * s2;

@@ -120,9 +120,11 @@ __device__ inline T sel3(int axis, T v0, T v1, T v2)
 }
 
 /// Number of steps already taken along axis b at the moment the j-th step of axis a (time ta) is about to be taken.
-/// T_b(i) is non-decreasing in i so the preceding steps form a prefix [1, n]; estimate n by division and fix up with
-/// the exact predicate so the result is identical to running the reference walk step by step.
-__device__ inline int stepsBefore(double init, double delta, int total, int b, int a, double ta)
+/// T_b(i) is non-decreasing in i so the preceding steps form a prefix [1, n]; estimate n arithmetically and fix up
+/// with the exact predicate so the result is identical to running the reference walk step by step.  The estimate only
+/// has to be close: `rdelta` is a (rounded) reciprocal of delta computed once per ray, which keeps the fp64 division
+/// out of the per-crossing work.
+__device__ inline int stepsBefore(double init, double delta, double rdelta, int total, int b, int a, double ta)
 {
   if (total == 0)
   {
@@ -131,7 +133,7 @@ __device__ inline int stepsBefore(double init, double delta, int total, int b, i
   int n;
   if (delta > 0 && delta < dInf())
   {
-    const double x = (ta - init) / delta;
+    const double x = (ta - init) * rdelta;
     // T_b(i) <= ta  <=>  i - 1 <= x
     n = (x < 0) ? 0 : ((x >= double(total)) ? total : int(x) + 1);
     n = (n > total) ? total : n;
