@@ -537,56 +537,90 @@ __global__ void __launch_bounds__(1024)
          uint32_t chunk_segments)
 {
   constexpr uint32_t kSizeClasses = 32;  // chunk size classes for the largest-first order (class = 32 * size / max)
-  __shared__ uint32_t s_seg[1024];
-  __shared__ uint32_t s_chk[1024];
+  constexpr int kRounds = 4;             // touched regions held in registers between the two passes: 4 x 1024
+  constexpr uint32_t kBigQueue = 256;
+  __shared__ uint32_t s_seg[16];
+  __shared__ uint32_t s_chk[16];
   __shared__ uint32_t s_seg_base;
   __shared__ uint32_t s_chk_base;
   __shared__ uint32_t s_class[kSizeClasses + 1];
+  __shared__ uint32_t s_big_n;
+  __shared__ uint32_t s_big[kBigQueue][4];  // hash index, slot, segment offset, segment count
   const uint32_t n = bs.info->n_touched;
   const uint32_t tid = threadIdx.x;
   if (tid == 0)
   {
     s_seg_base = 0;
     s_chk_base = 0;
+    s_big_n = 0;
   }
   if (tid <= kSizeClasses)
   {
     s_class[tid] = 0;
   }
   __syncthreads();
+  auto sizeClass = [&](uint32_t size) { return min(size * kSizeClasses / chunk_segments, kSizeClasses); };
+  auto emit = [&](uint32_t h, uint32_t slot, uint32_t seg_excl, uint32_t cnt, uint32_t nchk, uint32_t per, uint32_t c) {
+    const uint32_t begin = c * per;
+    const uint32_t end = min(cnt, (c + 1) * per);
+    const uint32_t pos = atomicAdd(&s_class[sizeClass(end - begin)], 1u);
+    if (pos < chunk_capacity)
+    {
+      Chunk ch;
+      ch.slot = slot;
+      ch.seg_begin = seg_excl + begin;
+      ch.seg_end = seg_excl + end;
+      ch.hash_index = h | ((nchk == 1) ? 0x80000000u : 0u);
+      chunks[pos] = ch;
+    }
+  };
+
   // Pass 1: segment offsets per region (prefix sum in touched order) and the chunk size histogram.  A region with
-  // more than chunk_segments segments is split into equal chunks.
-  for (uint32_t base = 0; base < n; base += 1024)
+  // more than chunk_segments segments is split into equal chunks: nchk - 1 of `per` segments and a last one with the
+  // rest.  The first kRounds x 1024 regions stay in registers for pass 2.
+  uint32_t r_h[kRounds], r_cnt[kRounds], r_slot[kRounds], r_off[kRounds];
+  for (uint32_t base = 0, round = 0; base < n; base += 1024, ++round)
   {
     const uint32_t i = base + tid;
-    uint32_t h = 0, cnt = 0, nchk = 0;
+    uint32_t h = 0, cnt = 0, nchk = 0, slot = 0;
     if (i < n)
     {
       h = bs.touched[i];
       cnt = bs.seg_count[h];
+      slot = rt.vals[h];
       nchk = (cnt + chunk_segments - 1) / chunk_segments;
     }
-    s_seg[tid] = cnt;
-    s_chk[tid] = nchk;
-    __syncthreads();
-    // Hillis-Steele inclusive scan (n_touched is small; this kernel is not on the critical path).
-    for (uint32_t off = 1; off < 1024; off <<= 1)
+    // Inclusive scan of (segments, chunks) over the 1024 threads: shuffles inside a wave, wave totals through LDS.
+    uint32_t inc_seg = cnt, inc_chk = nchk;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
     {
-      uint32_t a = 0, b = 0;
-      if (tid >= off)
+      const uint32_t a = __shfl_up(inc_seg, d);
+      const uint32_t b = __shfl_up(inc_chk, d);
+      if (int(tid & 63u) >= d)
       {
-        a = s_seg[tid - off];
-        b = s_chk[tid - off];
+        inc_seg += a;
+        inc_chk += b;
       }
-      __syncthreads();
-      s_seg[tid] += a;
-      s_chk[tid] += b;
-      __syncthreads();
     }
-    const uint32_t seg_excl = s_seg_base + s_seg[tid] - cnt;
+    if ((tid & 63u) == 63u)
+    {
+      s_seg[tid >> 6] = inc_seg;
+      s_chk[tid >> 6] = inc_chk;
+    }
+    __syncthreads();
+    uint32_t wave_seg = 0, all_seg = 0, all_chk = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w)
+    {
+      const uint32_t a = s_seg[w];
+      wave_seg += (w < (tid >> 6)) ? a : 0u;
+      all_seg += a;
+      all_chk += s_chk[w];
+    }
+    const uint32_t seg_excl = s_seg_base + wave_seg + inc_seg - cnt;
     if (i < n)
     {
-      const uint32_t slot = rt.vals[h];
       bs.seg_offset[h] = seg_excl;
       bs.seg_cursor[h] = 0;
       if (slot < rt.slot_capacity)
@@ -598,18 +632,29 @@ __global__ void __launch_bounds__(1024)
       if (nchk)
       {
         const uint32_t per = (cnt + nchk - 1) / nchk;
-        for (uint32_t c = 0; c < nchk; ++c)
+        if (nchk > 1)
         {
-          const uint32_t size = min(cnt, (c + 1) * per) - c * per;
-          atomicAdd(&s_class[min(size * kSizeClasses / chunk_segments, kSizeClasses)], 1u);
+          atomicAdd(&s_class[sizeClass(per)], nchk - 1);
         }
+        atomicAdd(&s_class[sizeClass(cnt - (nchk - 1) * per)], 1u);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k)
+    {
+      if (uint32_t(k) == round)
+      {
+        r_h[k] = h;
+        r_cnt[k] = cnt;
+        r_slot[k] = slot;
+        r_off[k] = seg_excl;
       }
     }
     __syncthreads();
     if (tid == 1023)
     {
-      s_seg_base += s_seg[1023];
-      s_chk_base += s_chk[1023];
+      s_seg_base += all_seg;
+      s_chk_base += all_chk;
     }
     __syncthreads();
   }
@@ -626,36 +671,65 @@ __global__ void __launch_bounds__(1024)
     }
   }
   __syncthreads();
-  // Pass 2: emit the chunk records.
-  for (uint32_t base = 0; base < n; base += 1024)
+  // Pass 2: emit the chunk records.  Regions with a few chunks are written by their own thread; the big ones (the
+  // regions around the sensor split into hundreds of chunks) are queued and written by the whole workgroup.
+  for (uint32_t base = 0, round = 0; base < n; base += 1024, ++round)
   {
     const uint32_t i = base + tid;
-    if (i < n)
+    uint32_t h = 0, cnt = 0, slot = 0, seg_excl = 0;
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k)
     {
-      const uint32_t h = bs.touched[i];
-      const uint32_t cnt = bs.seg_count[h];
-      const uint32_t nchk = (cnt + chunk_segments - 1) / chunk_segments;
-      if (nchk)
+      if (uint32_t(k) == round)
       {
-        const uint32_t seg_excl = bs.seg_offset[h];
-        const uint32_t slot = rt.vals[h];
-        const uint32_t per = (cnt + nchk - 1) / nchk;
+        h = r_h[k];
+        cnt = r_cnt[k];
+        slot = r_slot[k];
+        seg_excl = r_off[k];
+      }
+    }
+    if (round >= uint32_t(kRounds) && i < n)
+    {
+      h = bs.touched[i];
+      cnt = bs.seg_count[h];
+      slot = rt.vals[h];
+      seg_excl = bs.seg_offset[h];
+    }
+    const uint32_t nchk = (i < n) ? (cnt + chunk_segments - 1) / chunk_segments : 0u;
+    if (nchk)
+    {
+      const uint32_t per = (cnt + nchk - 1) / nchk;
+      uint32_t q = kBigQueue;
+      if (nchk > 4)
+      {
+        q = atomicAdd(&s_big_n, 1u);
+      }
+      if (q < kBigQueue)
+      {
+        s_big[q][0] = h;
+        s_big[q][1] = slot;
+        s_big[q][2] = seg_excl;
+        s_big[q][3] = cnt;
+      }
+      else
+      {
         for (uint32_t c = 0; c < nchk; ++c)
         {
-          const uint32_t begin = c * per;
-          const uint32_t end = min(cnt, (c + 1) * per);
-          const uint32_t pos = atomicAdd(&s_class[min((end - begin) * kSizeClasses / chunk_segments, kSizeClasses)], 1u);
-          if (pos < chunk_capacity)
-          {
-            Chunk ch;
-            ch.slot = slot;
-            ch.seg_begin = seg_excl + begin;
-            ch.seg_end = seg_excl + end;
-            ch.hash_index = h | ((nchk == 1) ? 0x80000000u : 0u);
-            chunks[pos] = ch;
-          }
+          emit(h, slot, seg_excl, cnt, nchk, per, c);
         }
       }
+    }
+  }
+  __syncthreads();
+  const uint32_t n_big = min(s_big_n, kBigQueue);
+  for (uint32_t q = 0; q < n_big; ++q)
+  {
+    const uint32_t cnt = s_big[q][3];
+    const uint32_t nchk = (cnt + chunk_segments - 1) / chunk_segments;
+    const uint32_t per = (cnt + nchk - 1) / nchk;
+    for (uint32_t c = tid; c < nchk; c += 1024)
+    {
+      emit(s_big[q][0], s_big[q][1], s_big[q][2], cnt, nchk, per, c);
     }
   }
   if (tid == 0)
@@ -1406,9 +1480,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       const bool a0 = c2 && c01;
       const bool a1 = c2 && !c01;
       const bool a2 = !c2;
-      k0 = a0 ? k0 + 1 : k0;
-      k1 = a1 ? k1 + 1 : k1;
-      k2 = a2 ? k2 + 1 : k2;
+      k0 += int(a0);
+      k1 += int(a1);
+      k2 += int(a2);
       const double n0 = (k0 < tot0) ? i0 + e0 * double(k0) : inf;
       const double n1 = (k1 < tot1) ? i1 + e1 * double(k1) : inf;
       const double n2 = (k2 < tot2) ? i2 + e2 * double(k2) : inf;
@@ -1427,7 +1501,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(k0), "+v"(k1), "+v"(k2), "+v"(vi), "+v"(left));
     __builtin_amdgcn_sched_barrier(0);
     {
-      const bool flagged = ((old >> sh) & kTileFlag) != 0;
+      const bool flagged = __builtin_amdgcn_ubfe(old, sh + 15u, 1u) != 0;
       const unsigned long long fm = __ballot(flagged);
       if (args.dbg_counters)
       {
