@@ -43,6 +43,8 @@ struct BatchScratch
   uint32_t *seg_offset;    ///< [hash_capacity]
   uint32_t *touched_flag;  ///< [hash_capacity]
   uint32_t *touched;       ///< [hash_capacity] list of touched hash indices
+  uint32_t *hit_count;     ///< [hash_capacity] samples per region (k_ray_setup -> k_plan, which zeroes it again)
+  uint32_t *sort_list;     ///< [hash_capacity] regions receiving samples, most samples first (k_plan -> sort)
   uint32_t *hit_begin;     ///< [slot_capacity] first sample of the region in the sorted list
   uint32_t *hit_end;       ///< [slot_capacity]
   uint32_t *dirty;         ///< [slot_capacity]
@@ -60,7 +62,7 @@ struct WgRegion
   uint32_t count;  ///< segments of the workgroup's rays in the region
   uint32_t entry;  ///< position in the workgroup's LDS region table
   uint32_t hash;   ///< index in the global region table
-  uint32_t pad;
+  uint32_t hits;   ///< samples of the workgroup's rays in the region
 };
 
 enum : uint32_t
@@ -269,8 +271,9 @@ constexpr uint32_t kLtabSize = 2048;  ///< entries (power of two)
 struct LdsRegionTable
 {
   unsigned long long keys[kLtabSize];
-  uint32_t count[kLtabSize];   ///< segments of this workgroup in the region
-  uint32_t cursor[kLtabSize];  ///< k_ray_bin: next free position (global index) of the workgroup's reserved range
+  uint32_t count[kLtabSize];   ///< k_ray_setup: segments of this workgroup in the region; k_ray_bin: sample cursor
+  uint32_t cursor[kLtabSize];  ///< k_ray_setup: samples of this workgroup in the region; k_ray_bin: segment cursor
+                               ///< (next free global position of the workgroup's reserved range)
 };
 
 /// Find or insert `key`; returns the entry index or kLtabSize when the table is full (caller falls back to global).
@@ -426,6 +429,7 @@ __global__ void __launch_bounds__(kBinThreads)
   {
     tab.keys[i] = 0;
     tab.count[i] = 0;
+    tab.cursor[i] = 0;
   }
   if (threadIdx.x == 0)
   {
@@ -486,9 +490,16 @@ __global__ void __launch_bounds__(kBinThreads)
       uint64_t key;
       uint32_t vi;
       sampleVoxel(mc, rw, key, vi);
-      if (ltabFindOrInsert(tab, key) >= kLtabSize)
+      const uint32_t e = ltabFindOrInsert(tab, key);
+      if (e < kLtabSize)
       {
-        markTouched(bs, regionInsert(rt, key, &bs.info->error));
+        atomicAdd(&tab.cursor[e], 1u);
+      }
+      else
+      {
+        const uint32_t h = regionInsert(rt, key, &bs.info->error);
+        atomicAdd(&bs.hit_count[h], 1u);
+        markTouched(bs, h);
       }
     }
   }
@@ -513,12 +524,17 @@ __global__ void __launch_bounds__(kBinThreads)
         atomicAdd(&bs.seg_count[h], c);
       }
       markTouched(bs, h);
+      const uint32_t hits = tab.cursor[e];
+      if (hits)
+      {
+        atomicAdd(&bs.hit_count[h], hits);
+      }
       WgRegion wr;
       wr.key = key;
       wr.count = c;
       wr.entry = e;
       wr.hash = h;
-      wr.pad = 0;
+      wr.hits = hits;
       bs.wg_regions[size_t(blockIdx.x) * kLtabSize + atomicAdd(&s_list_n, 1u)] = wr;
     }
   }
@@ -541,9 +557,13 @@ __global__ void __launch_bounds__(1024)
   constexpr uint32_t kBigQueue = 256;
   __shared__ uint32_t s_seg[16];
   __shared__ uint32_t s_chk[16];
+  __shared__ uint32_t s_hit[16];
   __shared__ uint32_t s_seg_base;
   __shared__ uint32_t s_chk_base;
+  __shared__ uint32_t s_hit_base;
+  __shared__ uint32_t s_hit_max;
   __shared__ uint32_t s_class[kSizeClasses + 1];
+  __shared__ uint32_t s_hclass[33];  // regions per sample-count class (class = bits of count - 1)
   __shared__ uint32_t s_big_n;
   __shared__ uint32_t s_big[kBigQueue][4];  // hash index, slot, segment offset, segment count
   const uint32_t n = bs.info->n_touched;
@@ -552,13 +572,17 @@ __global__ void __launch_bounds__(1024)
   {
     s_seg_base = 0;
     s_chk_base = 0;
+    s_hit_base = 0;
+    s_hit_max = 0;
     s_big_n = 0;
   }
   if (tid <= kSizeClasses)
   {
     s_class[tid] = 0;
+    s_hclass[tid] = 0;
   }
   __syncthreads();
+  auto hitClass = [](uint32_t hits) { return uint32_t(32 - __clz(int(hits - 1u))) & 31u; };
   auto sizeClass = [&](uint32_t size) { return min(size * kSizeClasses / chunk_segments, kSizeClasses); };
   auto emit = [&](uint32_t h, uint32_t slot, uint32_t seg_excl, uint32_t cnt, uint32_t nchk, uint32_t per, uint32_t c) {
     const uint32_t begin = c * per;
@@ -578,55 +602,71 @@ __global__ void __launch_bounds__(1024)
   // Pass 1: segment offsets per region (prefix sum in touched order) and the chunk size histogram.  A region with
   // more than chunk_segments segments is split into equal chunks: nchk - 1 of `per` segments and a last one with the
   // rest.  The first kRounds x 1024 regions stay in registers for pass 2.
-  uint32_t r_h[kRounds], r_cnt[kRounds], r_slot[kRounds], r_off[kRounds];
+  uint32_t r_h[kRounds], r_cnt[kRounds], r_slot[kRounds], r_off[kRounds], r_hits[kRounds];
   for (uint32_t base = 0, round = 0; base < n; base += 1024, ++round)
   {
     const uint32_t i = base + tid;
-    uint32_t h = 0, cnt = 0, nchk = 0, slot = 0;
+    uint32_t h = 0, cnt = 0, nchk = 0, slot = 0, hits = 0;
     if (i < n)
     {
       h = bs.touched[i];
       cnt = bs.seg_count[h];
+      hits = bs.hit_count[h];
       slot = rt.vals[h];
       nchk = (cnt + chunk_segments - 1) / chunk_segments;
+      if (hits)
+      {
+        atomicMax(&s_hit_max, hits);
+        atomicAdd(&s_hclass[hitClass(hits)], 1u);
+      }
     }
-    // Inclusive scan of (segments, chunks) over the 1024 threads: shuffles inside a wave, wave totals through LDS.
-    uint32_t inc_seg = cnt, inc_chk = nchk;
+    // Inclusive scan of (segments, chunks, samples) over the 1024 threads: shuffles inside a wave, wave totals
+    // through LDS.
+    uint32_t inc_seg = cnt, inc_chk = nchk, inc_hit = hits;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1)
     {
       const uint32_t a = __shfl_up(inc_seg, d);
       const uint32_t b = __shfl_up(inc_chk, d);
+      const uint32_t c = __shfl_up(inc_hit, d);
       if (int(tid & 63u) >= d)
       {
         inc_seg += a;
         inc_chk += b;
+        inc_hit += c;
       }
     }
     if ((tid & 63u) == 63u)
     {
       s_seg[tid >> 6] = inc_seg;
       s_chk[tid >> 6] = inc_chk;
+      s_hit[tid >> 6] = inc_hit;
     }
     __syncthreads();
-    uint32_t wave_seg = 0, all_seg = 0, all_chk = 0;
+    uint32_t wave_seg = 0, wave_hit = 0, all_seg = 0, all_chk = 0, all_hit = 0;
 #pragma unroll
     for (uint32_t w = 0; w < 16; ++w)
     {
       const uint32_t a = s_seg[w];
+      const uint32_t c = s_hit[w];
       wave_seg += (w < (tid >> 6)) ? a : 0u;
+      wave_hit += (w < (tid >> 6)) ? c : 0u;
       all_seg += a;
       all_chk += s_chk[w];
+      all_hit += c;
     }
     const uint32_t seg_excl = s_seg_base + wave_seg + inc_seg - cnt;
+    const uint32_t hit_excl = s_hit_base + wave_hit + inc_hit - hits;
     if (i < n)
     {
       bs.seg_offset[h] = seg_excl;
       bs.seg_cursor[h] = 0;
       if (slot < rt.slot_capacity)
       {
-        bs.hit_begin[slot] = 0;
-        bs.hit_end[slot] = 0;
+        // The region's range in the sample list; hit_end doubles as the scatter cursor of k_ray_bin and ends up at
+        // hit_begin + samples.
+        bs.hit_begin[slot] = hit_excl;
+        bs.hit_end[slot] = hit_excl;
         bs.dirty[slot] = 1;
       }
       if (nchk)
@@ -648,6 +688,7 @@ __global__ void __launch_bounds__(1024)
         r_cnt[k] = cnt;
         r_slot[k] = slot;
         r_off[k] = seg_excl;
+        r_hits[k] = hits;
       }
     }
     __syncthreads();
@@ -655,6 +696,7 @@ __global__ void __launch_bounds__(1024)
     {
       s_seg_base += all_seg;
       s_chk_base += all_chk;
+      s_hit_base += all_hit;
     }
     __syncthreads();
   }
@@ -670,13 +712,24 @@ __global__ void __launch_bounds__(1024)
       run += count;
     }
   }
+  if (tid == 64)
+  {
+    uint32_t run = 0;
+    for (int c = 31; c >= 0; --c)
+    {
+      const uint32_t count = s_hclass[c];
+      s_hclass[c] = run;
+      run += count;
+    }
+    s_hclass[32] = run;
+  }
   __syncthreads();
   // Pass 2: emit the chunk records.  Regions with a few chunks are written by their own thread; the big ones (the
   // regions around the sensor split into hundreds of chunks) are queued and written by the whole workgroup.
   for (uint32_t base = 0, round = 0; base < n; base += 1024, ++round)
   {
     const uint32_t i = base + tid;
-    uint32_t h = 0, cnt = 0, slot = 0, seg_excl = 0;
+    uint32_t h = 0, cnt = 0, slot = 0, seg_excl = 0, hits = 0;
 #pragma unroll
     for (int k = 0; k < kRounds; ++k)
     {
@@ -686,6 +739,7 @@ __global__ void __launch_bounds__(1024)
         cnt = r_cnt[k];
         slot = r_slot[k];
         seg_excl = r_off[k];
+        hits = r_hits[k];
       }
     }
     if (round >= uint32_t(kRounds) && i < n)
@@ -694,6 +748,12 @@ __global__ void __launch_bounds__(1024)
       cnt = bs.seg_count[h];
       slot = rt.vals[h];
       seg_excl = bs.seg_offset[h];
+      hits = bs.hit_count[h];
+    }
+    if (i < n && hits)
+    {
+      bs.hit_count[h] = 0;
+      bs.sort_list[atomicAdd(&s_hclass[hitClass(hits)], 1u)] = h;
     }
     const uint32_t nchk = (i < n) ? (cnt + chunk_segments - 1) / chunk_segments : 0u;
     if (nchk)
@@ -737,6 +797,9 @@ __global__ void __launch_bounds__(1024)
     bs.info->n_segments = s_seg_base;
     bs.info->n_chunks = s_chk_base;
     bs.info->n_slots = *rt.n_slots;
+    bs.info->n_hits = s_hit_base;
+    bs.info->max_region_hits = s_hit_max;
+    bs.info->n_hit_regions = s_hclass[32];
   }
 }
 
@@ -748,19 +811,14 @@ __global__ void __launch_bounds__(1024)
 __global__ void __launch_bounds__(kBinThreads)
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
-            uint32_t *__restrict__ hit_mask, int ray_shift)
+            uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits)
 {
   __shared__ LdsRegionTable tab;
-  __shared__ uint32_t s_hits;
   for (uint32_t i = threadIdx.x; i < kLtabSize; i += kBinThreads)
   {
     tab.keys[i] = 0;
     tab.count[i] = 0;
     tab.cursor[i] = 0;
-  }
-  if (threadIdx.x == 0)
-  {
-    s_hits = 0;
   }
   __syncthreads();
 
@@ -768,8 +826,8 @@ __global__ void __launch_bounds__(kBinThreads)
   const uint32_t last = min(first + kBinRaysPerBlock, n_rays);
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
 
-  // Step 1: the workgroup's regions and segment counts come from k_ray_setup (same rays, same LDS table layout);
-  // reserve one contiguous range in every region bucket it feeds.
+  // Step 1: the workgroup's regions with their segment and sample counts come from k_ray_setup (same rays, same LDS
+  // table layout); reserve one contiguous range in every region bucket it feeds.
   const uint32_t n_wg_regions = bs.wg_region_count[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < n_wg_regions; i += kBinThreads)
   {
@@ -779,36 +837,54 @@ __global__ void __launch_bounds__(kBinThreads)
     {
       tab.cursor[wr.entry] = bs.seg_offset[wr.hash] + atomicAdd(&bs.seg_cursor[wr.hash], wr.count);
     }
+    if (bucket_hits && wr.hits)
+    {
+      tab.count[wr.entry] = atomicAdd(&bs.hit_end[rt.vals[wr.hash]], wr.hits);
+    }
   }
-  // Step 2: sample keys and mask bits.
-  uint32_t my_hits = 0;
+  __syncthreads();
+  // Step 2: sample keys and mask bits.  bucket_hits: the keys go straight into their region's range of the sample
+  // list (k_sort_region_hits orders each range); otherwise they are written in ray order for a device-wide sort.
   for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
   {
     const RayWalk rw = walks[ray];
     unsigned long long hk = kHitInvalid;
+    uint32_t pos = ray;
     if ((rw.flags & kRwValid) && (rw.flags & kRwApplySample))
     {
       uint64_t key;
       uint32_t vi;
       sampleVoxel(mc, rw, key, vi);
-      const uint32_t h = regionFind(rt, key);
-      const uint32_t slot = (h != 0xffffffffu) ? rt.vals[h] : kSlotUnassigned;
+      const uint32_t e = bucket_hits ? ltabFind(tab, key) : kLtabSize;
+      uint32_t slot;
+      if (e < kLtabSize)
+      {
+        // The table does not carry the slot; it is in the reserved position's region range, but the key needs it.
+        const uint32_t h = regionFind(rt, key);
+        slot = rt.vals[h];
+        pos = atomicAdd(&tab.count[e], 1u);
+      }
+      else
+      {
+        const uint32_t h = regionFind(rt, key);
+        slot = (h != 0xffffffffu) ? rt.vals[h] : kSlotUnassigned;
+        if (bucket_hits && slot < rt.slot_capacity)
+        {
+          pos = atomicAdd(&bs.hit_end[slot], 1u);  // LDS table overflow in k_ray_setup: counted globally there too
+        }
+      }
       if (slot < rt.slot_capacity)
       {
         // ray_shift == 1 (NDT / TSDF event streams): the low bit tags the key as a sample (hit) event.
         hk = ((unsigned long long)slot << kHitSlotShift) | ((unsigned long long)vi << kHitRayBits) |
              ((unsigned long long)ray << ray_shift) | (unsigned long long)(ray_shift ? 1u : 0u);
         atomicOr(&hit_mask[size_t(slot) * mask_words + (vi >> 5)], 1u << (vi & 31));
-        ++my_hits;
       }
     }
-    hit_keys[ray] = hk;
-  }
-  atomicAdd(&s_hits, my_hits);
-  __syncthreads();
-  if (threadIdx.x == 0 && s_hits)
-  {
-    atomicAdd(&bs.info->n_hits, s_hits);
+    if (!bucket_hits || hk != kHitInvalid)
+    {
+      hit_keys[pos] = hk;
+    }
   }
   // Step 3: scatter.
   for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
@@ -900,6 +976,131 @@ __global__ void __launch_bounds__(256)
   if (i + 1 == n_hits || uint32_t(sorted[i + 1] >> kHitSlotShift) != slot)
   {
     bs.hit_end[slot] = i + 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_sort_region_hits: one workgroup per touched region orders the region's samples by (voxel, ray) in LDS (bitonic
+// network over the next power of two) and records each voxel's first sample.  Replaces a device-wide radix sort of all
+// sample keys plus k_hit_bounds when no region holds more than kSortRegionHits samples.
+// ---------------------------------------------------------------------------------------------------------------------
+/// LDS position of sort element i: one pad element per 32 keeps the power-of-two strides of the network (8 consecutive
+/// keys per lane in the last trip of every merge level) off a single group of banks.
+__device__ inline uint32_t sortSlot(uint32_t i)
+{
+  return i + (i >> 5);
+}
+
+/// R fused bitonic stages on the 2^R elements they connect (register butterflies between one LDS read and write).
+template <int R>
+__device__ inline void bitonicFused(unsigned long long *l_keys, uint32_t g, uint32_t s_shift, uint32_t k)
+{
+  constexpr uint32_t kCount = 1u << R;
+  const uint32_t low = g & ((1u << s_shift) - 1u);
+  const uint32_t base = ((g >> s_shift) << (s_shift + R)) | low;
+  const bool ascending = (base & k) == 0;
+  unsigned long long v[kCount];
+#pragma unroll
+  for (uint32_t m = 0; m < kCount; ++m)
+  {
+    v[m] = l_keys[sortSlot(base | (m << s_shift))];
+  }
+#pragma unroll
+  for (int t = 0; t < R; ++t)
+  {
+    const uint32_t d = 1u << (R - 1 - t);
+#pragma unroll
+    for (uint32_t m = 0; m < kCount; ++m)
+    {
+      if ((m & d) == 0)
+      {
+        const unsigned long long a = v[m];
+        const unsigned long long c = v[m | d];
+        const bool swap = (a > c) == ascending;
+        v[m] = swap ? c : a;
+        v[m | d] = swap ? a : c;
+      }
+    }
+  }
+#pragma unroll
+  for (uint32_t m = 0; m < kCount; ++m)
+  {
+    l_keys[sortSlot(base | (m << s_shift))] = v[m];
+  }
+}
+
+constexpr uint32_t kSortRegionHits = 8192;
+constexpr int kSortThreads = 1024;
+
+__global__ void __launch_bounds__(kSortThreads)
+  k_sort_region_hits(RegionTable rt, BatchScratch bs, const unsigned long long *__restrict__ keys,
+                     unsigned long long *__restrict__ sorted, int region_voxels, int debug_skip)
+{
+  __shared__ unsigned long long l_keys[kSortRegionHits + kSortRegionHits / 32];
+  const uint32_t h = bs.sort_list[blockIdx.x];
+  const uint32_t slot = rt.vals[h];
+  if (slot >= rt.slot_capacity)
+  {
+    return;
+  }
+  const uint32_t begin = bs.hit_begin[slot];
+  const uint32_t n = bs.hit_end[slot] - begin;
+  if (n == 0 || n > kSortRegionHits)
+  {
+    return;
+  }
+  uint32_t padded = 64;
+  while (padded < n)
+  {
+    padded <<= 1;
+  }
+  for (uint32_t i = threadIdx.x; i < padded; i += kSortThreads)
+  {
+    l_keys[sortSlot(i)] = (i < n) ? keys[begin + i] : ~0ull;
+  }
+  __syncthreads();
+  // Bitonic network, up to three consecutive compare distances (j, j/2, j/4) fused per LDS round trip: a thread pulls
+  // the 8 (4, 2) elements those stages connect into registers, runs the butterflies there and writes them back.
+  // The network is LDS-bandwidth bound, so this cuts its cost by the same factor as the traffic (~2.6x).
+  for (uint32_t k = 2; k <= padded && !(debug_skip & 1); k <<= 1)
+  {
+    uint32_t j = k >> 1;
+    while (j > 0)
+    {
+      // levels fused this trip: r in 1..3, distances j, j/2, .., s = j >> (r - 1)
+      const uint32_t levels_left = uint32_t(32 - __clz(int(j)));  // log2(j) + 1
+      const uint32_t r = min(3u, levels_left);
+      const uint32_t s_shift = levels_left - r;  // log2 of the smallest distance s
+      const uint32_t group_count = padded >> r;
+      for (uint32_t g = threadIdx.x; g < group_count; g += kSortThreads)
+      {
+        if (r == 3)
+        {
+          bitonicFused<3>(l_keys, g, s_shift, k);
+        }
+        else if (r == 2)
+        {
+          bitonicFused<2>(l_keys, g, s_shift, k);
+        }
+        else
+        {
+          bitonicFused<1>(l_keys, g, s_shift, k);
+        }
+      }
+      __syncthreads();
+      j >>= r;
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
+  {
+    const unsigned long long key = l_keys[sortSlot(i)];
+    sorted[begin + i] = key;
+    if (!(debug_skip & 2) && (i == 0 || (l_keys[sortSlot(i - 1)] >> kHitRayBits) != (key >> kHitRayBits)))
+    {
+      // First sample of its voxel: entry point for ordering misses against this voxel's samples.
+      const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
+      bs.voxel_first_hit[size_t(slot) * size_t(region_voxels) + vi] = begin + i;
+    }
   }
 }
 

@@ -127,6 +127,8 @@ struct BatchInfo
   uint32_t n_slots;
   uint32_t error;
   uint32_t n_hits;
+  uint32_t max_region_hits;  ///< most samples any one region receives in the batch
+  uint32_t n_hit_regions;    ///< regions receiving samples (length of the sort list)
 };
 
 constexpr uint32_t kChunkSegments = 4096;

@@ -85,6 +85,7 @@ struct ohmhip_map_s
   uint64_t *d_slot_keys = nullptr;
   uint32_t *d_n_slots = nullptr;
   // scratch
+  uint32_t *d_hit_count = nullptr, *d_sort_list = nullptr;
   uint32_t *d_seg_count = nullptr, *d_seg_cursor = nullptr, *d_seg_offset = nullptr, *d_touched_flag = nullptr,
            *d_touched = nullptr;
   uint32_t *d_voxel_first_hit = nullptr, *d_hit_begin = nullptr, *d_hit_end = nullptr, *d_dirty = nullptr;
@@ -138,6 +139,8 @@ BatchScratch batchScratch(ohmhip_map_t m)
   bs.seg_offset = m->d_seg_offset;
   bs.touched_flag = m->d_touched_flag;
   bs.touched = m->d_touched;
+  bs.hit_count = m->d_hit_count;
+  bs.sort_list = m->d_sort_list;
   bs.voxel_first_hit = m->d_voxel_first_hit;
   bs.hit_begin = m->d_hit_begin;
   bs.hit_end = m->d_hit_end;
@@ -206,7 +209,7 @@ void freePool(ohmhip_map_t m)
   }
   void *ptrs[] = { m->d_keys,       m->d_vals,        m->d_slot_keys, m->d_seg_count, m->d_seg_cursor,
                    m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_voxel_first_hit, m->d_hit_begin, m->d_hit_end,
-                   m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks };
+                   m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks,    m->d_hit_count, m->d_sort_list };
   for (void *p : ptrs)
   {
     if (p)
@@ -221,6 +224,7 @@ void freePool(ohmhip_map_t m)
   m->d_voxel_first_hit = m->d_hit_begin = m->d_hit_end = m->d_dirty = nullptr;
   m->d_miss_counts = m->d_hit_mask = nullptr;
   m->d_chunks = nullptr;
+  m->d_hit_count = m->d_sort_list = nullptr;
 }
 
 /// (Re)allocate the region pool for `capacity` regions, preserving the first `keep` slots' contents.
@@ -288,7 +292,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   }
   void *old[] = { m->d_keys,       m->d_vals,         m->d_slot_keys, m->d_seg_count, m->d_seg_cursor,
                   m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_voxel_first_hit, m->d_hit_begin, m->d_hit_end,
-                  m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks };
+                  m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks,    m->d_hit_count, m->d_sort_list };
   for (void *p : old)
   {
     if (p)
@@ -311,6 +315,8 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_vals), sizeof(uint32_t) * hash_cap);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_count), sizeof(uint32_t) * hash_cap);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_cursor), sizeof(uint32_t) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_count), sizeof(uint32_t) * hash_cap);
+  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_sort_list), sizeof(uint32_t) * hash_cap);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_offset), sizeof(uint32_t) * hash_cap);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_touched_flag), sizeof(uint32_t) * hash_cap);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_touched), sizeof(uint32_t) * hash_cap);
@@ -535,9 +541,12 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       event_capacity = uint32_t(std::min<size_t>(std::min(cap_a, cap_b), 0xfffffff0u - n_rays));
     }
 
+    // Occupancy: sample keys are bucketed per region and ordered by one workgroup per region in LDS, unless some
+    // region holds more samples than that kernel's LDS takes (then: ray-order keys + device-wide radix sort).
+    const bool bucket_hits = occupancy_mode && info.max_region_hits <= kSortRegionHits;
     hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(kBinThreads), 0, s, m->mc, regionTable(m), batchScratch(m),
                        static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
-                       seg_cap, keys_a, m->d_hit_mask, ray_shift);
+                       seg_cap, keys_a, m->d_hit_mask, ray_shift, bucket_hits ? 1 : 0);
     if (tsdf_mode)
     {
       hipLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
@@ -545,7 +554,15 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     }
     OHMHIP_CHECK(hipEventRecord(m->ev[1], s));
     const unsigned long long *sorted = keys_b;
-    if (occupancy_mode)
+    if (bucket_hits)
+    {
+      if (info.n_hit_regions)
+      {
+        hipLaunchKernelGGL(k_sort_region_hits, dim3(info.n_hit_regions), dim3(kSortThreads), 0, s, regionTable(m),
+                           batchScratch(m), keys_a, keys_b, m->mc.region_voxels, int(m->debug_flags >> 8));
+      }
+    }
+    else if (occupancy_mode)
     {
       size_t temp_bytes = m->sort_temp.bytes;
       // Sample keys are emitted in ray order and the radix sort is stable: sorting on the (slot, voxel) bits alone

@@ -116,3 +116,23 @@ def test_pool_growth(gpu):
     rays = synth.rays_c0(n=4000, length=9.0)
     stats, gm, om, total = run_case(rays, batch=1000, region_capacity=64)
     assert_parity(stats)
+
+
+def test_dense_region_samples_fall_back_to_device_sort(gpu):
+    # More samples in one region than the per-region LDS sort takes (8192): the batch must go through the device-wide
+    # radix sort and the global deferred-event path, with the same bit-exact result.  Sensor rays also cross the
+    # sample voxels, so misses have to be ordered against samples there.
+    n = 12000
+    i = np.arange(n)
+    ends = np.stack([2.0 + 0.9 * synth.uniform01(77, i, 1), 0.9 * synth.uniform01(77, i, 2) - 0.45,
+                     0.9 * synth.uniform01(77, i, 3) - 0.45], axis=1)
+    far = ends * 2.5
+    starts = np.zeros_like(ends)
+    rays = np.empty((4 * n, 3), dtype=np.float64)
+    rays[0::4] = starts
+    rays[1::4] = ends
+    rays[2::4] = starts
+    rays[3::4] = far
+    stats, gm, om, total = run_case(rays, layers=("occupancy", "mean"))
+    assert total == 4 * n
+    assert_parity(stats)
