@@ -1199,7 +1199,7 @@ __device__ inline uint32_t subVoxelUpdate(uint32_t coord, uint32_t point_count, 
 constexpr int kWalkThreads = 1024;
 constexpr int kWalkWaves = kWalkThreads / 64;
 constexpr int kQueueCap = 128;     ///< deferred events per wave (8 B each)
-constexpr int kLdsHits = 7168;     ///< a region's sample list is staged in LDS when it has at most this many samples
+constexpr int kLdsHits = 6144;     ///< a region's sample list is staged in LDS when it has at most this many samples
 constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
 constexpr uint32_t kTileFlag = 0x8000u;       ///< mask flag inside a u16 tile entry
 constexpr uint32_t kTileCountMask = 0x7fffu;  ///< count bits of a u16 tile entry (a chunk adds <= kMaxChunkSegments)
@@ -1345,33 +1345,54 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   unsigned long long *l_hits = reinterpret_cast<unsigned long long *>(l_queues + kWalkWaves * kQueueCap);
   uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] u16 interval counters
   uint32_t *l_cursor = l_intervals + kLdsHits / 2;
-  uint32_t *l_hist = l_cursor + 4;
+  uint32_t *l_hist = l_cursor + 8;  // l_cursor[0]: segment cursor, [1]: next chunk index, [2..5]: its record, [6..7]: its hits
   uint16_t *l_order = reinterpret_cast<uint16_t *>(l_hist + kLengthClasses);
 
   // Persistent workgroups: the launch has one workgroup per CU and each takes chunks from a device-wide cursor until
   // none are left.  A static blockIdx -> chunk binding leaves the hardware's round-robin of workgroups over the 8 XCDs
   // in charge of the balance, and chunk costs vary enough that some XCDs then finish in half the time of others.
+  // The chunk record (and the region's range in the sample list) travels with the index through LDS: thread 0 fetches
+  // the next one while the other waves are still finishing their loop, so a trip does not start with a chain of
+  // dependent global loads.
+  const int defer_all = args.defer_all;
+  auto fetchNextChunk = [&]() {
+    const uint32_t next = atomicAdd(args.chunk_cursor, 1u);
+    l_cursor[1] = next;
+    if (next < args.n_chunks)
+    {
+      const Chunk c = args.chunks[next];
+      l_cursor[2] = c.slot;
+      l_cursor[3] = c.seg_begin;
+      l_cursor[4] = c.seg_end;
+      l_cursor[5] = c.hash_index;
+      l_cursor[6] = defer_all ? 0u : args.bs.hit_begin[c.slot];
+      l_cursor[7] = defer_all ? 0u : args.bs.hit_end[c.slot];
+    }
+  };
   if (threadIdx.x == 0)
   {
-    l_cursor[1] = atomicAdd(args.chunk_cursor, 1u);
+    fetchNextChunk();
   }
   __syncthreads();
-  // (readfirstlane: the value is wave-uniform, so the loop condition is a scalar branch and the barriers inside the
+  // (readfirstlane: the values are wave-uniform, so the loop condition is a scalar branch and the barriers inside the
   // loop are not restructured as if threads could leave at different trips.)
   uint32_t chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
   while (chunk_index < args.n_chunks)
   {
   const unsigned long long clk_start = args.dbg_counters ? wall_clock64() : 0ull;
-  const Chunk chunk = args.chunks[chunk_index];
+  Chunk chunk;
+  chunk.slot = __builtin_amdgcn_readfirstlane(l_cursor[2]);
+  chunk.seg_begin = __builtin_amdgcn_readfirstlane(l_cursor[3]);
+  chunk.seg_end = __builtin_amdgcn_readfirstlane(l_cursor[4]);
+  chunk.hash_index = __builtin_amdgcn_readfirstlane(l_cursor[5]);
+  const uint32_t hb = __builtin_amdgcn_readfirstlane(l_cursor[6]);
+  const uint32_t he = __builtin_amdgcn_readfirstlane(l_cursor[7]);
   const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
   const Segment *chunk_segments = args.segments + chunk.seg_begin;
-  const int defer_all = args.defer_all;
 
   // ---- prologue.  One workgroup owns the CU (the tile takes most of its LDS), so nothing overlaps this phase: every
   // ---- global load that depends only on the chunk record is issued back to back, clamped instead of predicated so
   // ---- the loads share one basic block, and consumed afterwards.
-  const uint32_t hb = defer_all ? 0u : args.bs.hit_begin[chunk.slot];
-  const uint32_t he = defer_all ? 0u : args.bs.hit_end[chunk.slot];
   constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
   constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
   uint32_t lens[kSegPerThread];
@@ -1403,7 +1424,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   if (threadIdx.x == 0)
   {
     l_cursor[0] = 0;
-    l_cursor[1] = atomicAdd(args.chunk_cursor, 1u);  // next chunk of this workgroup (read at the end of the trip)
   }
   const bool stamp = args.dbg_counters && threadIdx.x == 0;
   unsigned long long clk_p[6] = { 0, 0, 0, 0, 0, 0 };
@@ -1763,6 +1783,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals, l_counts,
                args.events, args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits,
                args.miss_counts, args.interval_counts, mc.region_voxels);
+  }
+  if (threadIdx.x == 0)
+  {
+    fetchNextChunk();  // overlaps with the other waves finishing their loop
   }
   __syncthreads();
   if (stamp && chunk_index < kTraceChunks)

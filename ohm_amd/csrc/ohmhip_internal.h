@@ -131,7 +131,7 @@ struct BatchInfo
   uint32_t n_hit_regions;    ///< regions receiving samples (length of the sort list)
 };
 
-constexpr uint32_t kChunkSegments = 4096;
+constexpr uint32_t kChunkSegments = 8192;
 constexpr uint64_t kKeyOccupied = 1ull << 63;
 constexpr uint32_t kSlotUnassigned = 0xffffffffu;
 

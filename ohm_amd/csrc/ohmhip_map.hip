@@ -424,7 +424,7 @@ size_t walkLdsBytes(const MapConst &mc, uint32_t chunk_segments)
   // [count tile, padded to 16 B][per-wave queues][staged sample keys][interval counters][cursor + pad]
   // [length histogram][segment order, u16 each]
   const size_t count_words = (size_t((mc.region_voxels + 1) / 2) + 3u) & ~size_t(3);
-  return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) + 4 +
+  return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) + 8 +
           kLengthClasses + (chunk_segments + 1) / 2) *
          sizeof(uint32_t);
 }
