@@ -203,6 +203,12 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, siz
 int ohmhip_map_sync(ohmhip_map_t map);
 int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);
 
+/* Device phase times of one of the last 32 batches (batches_back = 0: the latest): ms[0] first kernel start -> last kernel
+ * end, ms[1] ray setup + binning, ms[2] the region walk kernel, ms[3] sample ordering + ordered apply.  hipEvents on the
+ * map's stream (the gputil::Event / Queue::mark() bookkeeping of ohmgpu/GpuMap.cpp:1036-1191 serves the same purpose);
+ * waits for that batch only.  Lets a caller time a run of batches without synchronising after each one. */
+int ohmhip_map_batch_timings(ohmhip_map_t map, uint32_t batches_back, float ms[4]);
+
 /* Region table (replaces GpuLayerCache::lookup, ohmgpu/GpuLayerCache.cpp:104-119). keys = int16 xyz triples. */
 int ohmhip_map_region_count(ohmhip_map_t map, size_t *count);
 int ohmhip_map_regions(ohmhip_map_t map, int16_t *keys_xyz, size_t capacity, size_t *count);

@@ -66,6 +66,8 @@ struct DevBuf
 };
 }  // namespace
 
+constexpr uint32_t kTimingRing = 32;
+
 struct ohmhip_map_s
 {
   ohmhip_map_config config;
@@ -74,6 +76,10 @@ struct ohmhip_map_s
   hipStream_t stream = nullptr;       ///< compute stream
   hipStream_t copy_stream = nullptr;  ///< side stream for region upload/download
   hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  /// Timing events of the last kTimingRing batches (start, binned, samples ordered, walked, done): reading a batch's
+  /// phase times does not have to synchronise the host with every batch.
+  hipEvent_t tev[kTimingRing][5] = {};
+  uint64_t batch_seq = 0;
 
   uint32_t slot_capacity = 0;
   uint32_t hash_capacity = 0;
@@ -444,6 +450,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                    uint32_t n_rays, unsigned ray_flags)
 {
   hipStream_t s = m->stream;
+  hipEvent_t *tev = m->tev[m->batch_seq % kTimingRing];
   const uint32_t ray_blocks = (n_rays + 255) / 256;
   const uint32_t bin_blocks = (n_rays + kBinRaysPerBlock - 1) / kBinRaysPerBlock;
   const int mode = m->config.mode;
@@ -486,7 +493,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   for (int attempt = 0; attempt < 8; ++attempt)
   {
     OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, sizeof(BatchInfo), s));
-    OHMHIP_CHECK(hipEventRecord(m->ev[0], s));
+    OHMHIP_CHECK(hipEventRecord(tev[0], s));
     hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(kBinThreads), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
                        n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr));
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
@@ -552,7 +559,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       hipLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
                          static_cast<const RayWalk *>(m->walks.ptr), d_rays, n_rays, m->d_hit_mask);
     }
-    OHMHIP_CHECK(hipEventRecord(m->ev[1], s));
+    OHMHIP_CHECK(hipEventRecord(tev[1], s));
     const unsigned long long *sorted = keys_b;
     if (bucket_hits)
     {
@@ -571,7 +578,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                                             sortEndBit(m), s));
       hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m), m->mc.region_voxels);
     }
-    OHMHIP_CHECK(hipEventRecord(m->ev[2], s));
+    OHMHIP_CHECK(hipEventRecord(tev[2], s));
 
     // Single-chunk regions are applied by the walk kernel straight from LDS (plain log-odds misses only).
     float *direct_occ = (occupancy_mode || mode == OHMHIP_MODE_NDT_OM) ?
@@ -628,7 +635,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         {
           hipLaunchKernelGGL((k_region_walk<false, false>), wgrid, wblock, wlds, s, wa);
         }
-        OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
+        OHMHIP_CHECK(hipEventRecord(tev[3], s));
         if (occupancy_mode)
         {
           hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m), events, event_capacity,
@@ -669,7 +676,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     }
     else
     {
-      OHMHIP_CHECK(hipEventRecord(m->ev[5], s));
+      OHMHIP_CHECK(hipEventRecord(tev[3], s));
     }
     OHMHIP_CHECK(hipEventRecord(m->ev[3], s));
 
@@ -728,7 +735,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         }
       }
     }
-    OHMHIP_CHECK(hipEventRecord(m->ev[4], s));
+    OHMHIP_CHECK(hipEventRecord(tev[4], s));
     OHMHIP_CHECK(hipGetLastError());
 
     m->stats = {};
@@ -739,6 +746,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     m->stats.regions_touched = info.n_touched;
     m->stats.regions_resident = info.n_slots;
     m->stats_pending = true;
+    ++m->batch_seq;
     return OHMHIP_OK;
   }
   return OHMHIP_ERR_CAPACITY;
@@ -881,6 +889,16 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
       return fail(err);
     }
   }
+  for (auto &set : m->tev)
+  {
+    for (auto &e : set)
+    {
+      if ((err = hipEventCreate(&e)) != 0)
+      {
+        return fail(err);
+      }
+    }
+  }
   if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_n_slots), sizeof(uint32_t))) != 0)
   {
     return fail(err);
@@ -1008,6 +1026,16 @@ int ohmhip_map_destroy(ohmhip_map_t m)
     if (e)
     {
       (void)hipEventDestroy(e);
+    }
+  }
+  for (auto &set : m->tev)
+  {
+    for (auto &e : set)
+    {
+      if (e)
+      {
+        (void)hipEventDestroy(e);
+      }
     }
   }
   if (m->stream)
@@ -1184,6 +1212,28 @@ int ohmhip_map_sync(ohmhip_map_t m)
   return OHMHIP_OK;
 }
 
+int ohmhip_map_batch_timings(ohmhip_map_t m, uint32_t batches_back, float ms[4])
+{
+  if (!m || !ms)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (batches_back >= kTimingRing || uint64_t(batches_back) >= m->batch_seq)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  hipEvent_t *tev = m->tev[(m->batch_seq - 1 - batches_back) % kTimingRing];
+  OHMHIP_CHECK(hipEventSynchronize(tev[4]));
+  float sort_ms = 0, apply_ms = 0;
+  OHMHIP_CHECK(hipEventElapsedTime(&ms[0], tev[0], tev[4]));
+  OHMHIP_CHECK(hipEventElapsedTime(&ms[1], tev[0], tev[1]));
+  OHMHIP_CHECK(hipEventElapsedTime(&ms[2], tev[2], tev[3]));
+  OHMHIP_CHECK(hipEventElapsedTime(&sort_ms, tev[1], tev[2]));
+  OHMHIP_CHECK(hipEventElapsedTime(&apply_ms, tev[3], tev[4]));
+  ms[3] = sort_ms + apply_ms;
+  return OHMHIP_OK;
+}
+
 int ohmhip_map_last_stats(ohmhip_map_t m, ohmhip_batch_stats *stats)
 {
   if (!m || !stats)
@@ -1192,20 +1242,14 @@ int ohmhip_map_last_stats(ohmhip_map_t m, ohmhip_batch_stats *stats)
   }
   if (m->stats_pending)
   {
-    OHMHIP_CHECK(hipEventSynchronize(m->ev[4]));
-    float ms = 0;
-    OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[0], m->ev[4]));
-    m->stats.ms_total = ms;
-    OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
-    m->stats.ms_setup = ms;
-    OHMHIP_CHECK(hipEventElapsedTime(&ms, m->ev[2], m->ev[5]));
-    m->stats.ms_walk = ms;
+    float ms[4] = { 0, 0, 0, 0 };
+    OHMHIP_CHECK(ohmhip_map_batch_timings(m, 0, ms));
+    m->stats.ms_total = ms[0];
+    m->stats.ms_setup = ms[1];
+    m->stats.ms_walk = ms[2];
+    m->stats.ms_apply = ms[3];
     // The previous batch's deferred-event demand sizes the next batch's event list.
     m->event_demand = *reinterpret_cast<const uint32_t *>(&m->h_info[1]);
-    float ms_sort = 0, ms_apply = 0;
-    OHMHIP_CHECK(hipEventElapsedTime(&ms_sort, m->ev[1], m->ev[2]));
-    OHMHIP_CHECK(hipEventElapsedTime(&ms_apply, m->ev[5], m->ev[4]));
-    m->stats.ms_apply = ms_sort + ms_apply;
     m->stats_pending = false;
   }
   *stats = m->stats;

@@ -275,6 +275,12 @@ class GpuMap(RayMapper):
         L.check(L.lib.ohmhip_map_last_stats(self._handle, C.byref(st)), "stats")
         return {name: getattr(st, name) for name, _ in L.BatchStats._fields_}
 
+    def batchTimings(self, batches_back=0):
+        """Device phase times (ms) of one of the last 32 batches: total, setup + bin, walk kernel, order + apply."""
+        ms = (C.c_float * 4)()
+        L.check(L.lib.ohmhip_map_batch_timings(self._handle, batches_back, ms), "batch_timings")
+        return {"ms_total": ms[0], "ms_setup": ms[1], "ms_walk": ms[2], "ms_apply": ms[3]}
+
     def wait(self):
         L.check(L.lib.ohmhip_map_sync(self._handle), "sync")
 
