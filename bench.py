@@ -192,6 +192,38 @@ def main():
                            "walk_ms": float(st2["ms_walk"])}
             L.lib.ohmhip_buffer_destroy(b2)
             g2.close()
+        # C1 variants SURVEY 8d asks to be reported next to the headline (never the headline `value`):
+        # (i) the same batch fed as 4096-ray calls (the reference tools' default batch size): launch-latency bound;
+        # (ii) end to end from HOST memory: pinned staging + H2D + integrate + syncVoxels into the host MapChunk blocks.
+        m3 = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+        g3 = ohm_amd.GpuMap(m3, gpu_mem_size=8 << 30)
+        small = 4096
+        n_small = min(n_rays // small, 64)
+        stride = 2 * small * 3 * 8
+        g3.integrateRaysDevice(dptr, rays.shape[0])
+        g3.wait()
+        t1 = time.perf_counter()
+        for b in range(n_small):
+            g3.integrateRaysDevice(C.c_void_p(dptr.value + b * stride), 2 * small)
+        g3.wait()
+        dt = time.perf_counter() - t1
+        extra["C1_4096_ray_batches"] = {"rays_per_s": n_small * small / dt, "ms_per_batch": dt * 1e3 / n_small,
+                                        "batches": n_small}
+        g3.close()
+        m4 = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+        g4 = ohm_amd.GpuMap(m4, gpu_mem_size=8 << 30)
+        g4.integrateRays(rays)
+        g4.syncVoxels()
+        t1 = time.perf_counter()
+        g4.integrateRays(rays)
+        t2 = time.perf_counter()
+        g4.syncVoxels()
+        t3 = time.perf_counter()
+        extra["C1_host_end_to_end"] = {"rays_per_s_integrate": n_rays / (t2 - t1),
+                                       "rays_per_s_with_sync_voxels": n_rays / (t3 - t1),
+                                       "integrate_ms": (t2 - t1) * 1e3, "sync_voxels_ms": (t3 - t2) * 1e3,
+                                       "note": "host-pointer rays (48 B/ray over PCIe) + all modified regions copied back"}
+        g4.close()
         out["other_configs"] = extra
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(rays, resolution, min(args.cpu_sample, n_rays))

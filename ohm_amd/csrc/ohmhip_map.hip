@@ -16,6 +16,7 @@
 #include <limits>
 #include <new>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 using namespace ohmhip;
@@ -1394,17 +1395,54 @@ int ohmhip_map_read_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xy
   }
   char *stage[2] = { static_cast<char *>(m->h_stage), static_cast<char *>(m->h_stage) + burst * stride };
   hipEvent_t done[2] = { m->ev[6], nullptr };
+  // Requests in pool-slot order: consecutive slots are one contiguous device range and travel as ONE copy (a first
+  // sync of a freshly built map is a handful of large copies instead of one small copy per region).
+  std::vector<std::pair<uint32_t, size_t>> order(count);
+  for (size_t k = 0; k < count; ++k)
+  {
+    const int16_t *key = keys_xyz + 3 * k;
+    const auto it = m->region_slots.find(packRegionKey(key[0], key[1], key[2]));
+    if (it == m->region_slots.end())
+    {
+      return OHMHIP_ERR_NOT_FOUND;
+    }
+    order[k] = { it->second, k };
+  }
+  std::sort(order.begin(), order.end());
   OHMHIP_CHECK(hipEventCreate(&done[1]));
   size_t pending_base[2] = { 0, 0 };
   size_t pending_n[2] = { 0, 0 };
   int status = OHMHIP_OK;
+  auto scatter = [&](int b, size_t first, size_t last) {
+    for (size_t k = first; k < last; ++k)
+    {
+      std::memcpy(dsts[order[pending_base[b] + k].second], stage[b] + k * stride, stride);
+    }
+  };
   auto drain = [&](int b) -> int {
     if (pending_n[b])
     {
       OHMHIP_CHECK(hipEventSynchronize(done[b]));
-      for (size_t k = 0; k < pending_n[b]; ++k)
+      // The host-side scatter into the callers' blocks is memory-bandwidth work: a few threads share a large burst.
+      const size_t n = pending_n[b];
+      const size_t workers = (n * stride >= (size_t(4) << 20)) ? 4 : 1;
+      if (workers == 1)
       {
-        std::memcpy(dsts[pending_base[b] + k], stage[b] + k * stride, stride);
+        scatter(b, 0, n);
+      }
+      else
+      {
+        std::vector<std::thread> pool;
+        const size_t per = (n + workers - 1) / workers;
+        for (size_t w = 1; w < workers; ++w)
+        {
+          pool.emplace_back(scatter, b, std::min(n, w * per), std::min(n, (w + 1) * per));
+        }
+        scatter(b, 0, std::min(n, per));
+        for (auto &t : pool)
+        {
+          t.join();
+        }
       }
       pending_n[b] = 0;
     }
@@ -1419,22 +1457,21 @@ int ohmhip_map_read_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xy
       break;
     }
     const size_t n = std::min(burst, count - base);
-    for (size_t k = 0; k < n; ++k)
+    for (size_t k = 0; k < n && status == OHMHIP_OK;)
     {
-      const int16_t *key = keys_xyz + 3 * (base + k);
-      const auto it = m->region_slots.find(packRegionKey(key[0], key[1], key[2]));
-      if (it == m->region_slots.end())
+      size_t run = 1;
+      while (k + run < n && order[base + k + run].first == order[base + k].first + uint32_t(run))
       {
-        status = OHMHIP_ERR_NOT_FOUND;
-        break;
+        ++run;
       }
-      const char *src = static_cast<const char *>(m->layers[layer_id]) + size_t(it->second) * stride;
-      const hipError_t e = hipMemcpyAsync(stage[b] + k * stride, src, stride, hipMemcpyDeviceToHost, m->copy_stream);
+      const char *src = static_cast<const char *>(m->layers[layer_id]) + size_t(order[base + k].first) * stride;
+      const hipError_t e =
+        hipMemcpyAsync(stage[b] + k * stride, src, run * stride, hipMemcpyDeviceToHost, m->copy_stream);
       if (e != hipSuccess)
       {
         status = int(e);
-        break;
       }
+      k += run;
     }
     if (status == OHMHIP_OK)
     {

@@ -306,7 +306,7 @@ class GpuMap(RayMapper):
             for k in keys:
                 chunk = self._map.chunks.setdefault((int(k[0]), int(k[1]), int(k[2])), {})
                 if name not in chunk:
-                    chunk[name] = np.zeros(rv * comps, dtype=dtype)
+                    chunk[name] = np.empty(rv * comps, dtype=dtype)  # fully overwritten by the copy below
                 blocks.append(chunk[name])
             if not blocks:
                 continue
