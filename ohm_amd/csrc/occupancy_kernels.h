@@ -264,8 +264,9 @@ __device__ inline void waveMatch(bool has, uint32_t value, unsigned lane, int &l
 // the per-region counters of the regions around a sensor are otherwise hit by every wave of the launch, and atomics on
 // one address serialise at the memory side (that, not arithmetic, dominated the first version of these kernels).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kBinThreads = 512;
-constexpr int kBinRaysPerBlock = 1024;
+constexpr int kBinThreads = 512;        ///< workgroup size of the binning kernels for large batches (launch bound)
+constexpr int kBinRaysPerBlock = 1024;  ///< rays per binning workgroup for large batches; small batches use fewer so the
+                                        ///< launch still spreads over the CUs (the host picks both per batch)
 constexpr uint32_t kLtabSize = 2048;  ///< entries (power of two)
 
 struct LdsRegionTable
@@ -419,13 +420,13 @@ __device__ inline void markTouched(const BatchScratch &bs, uint32_t h)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBinThreads)
   k_ray_setup(MapConst mc, RegionTable rt, BatchScratch bs, const double *__restrict__ rays, uint32_t n_rays,
-              unsigned ray_flags, RayWalk *__restrict__ walks)
+              unsigned ray_flags, RayWalk *__restrict__ walks, uint32_t rays_per_block)
 {
   __shared__ LdsRegionTable tab;
   __shared__ unsigned long long s_visits;
   __shared__ uint32_t s_rays_ok;
   __shared__ uint32_t s_list_n;
-  for (uint32_t i = threadIdx.x; i < kLtabSize; i += kBinThreads)
+  for (uint32_t i = threadIdx.x; i < kLtabSize; i += blockDim.x)
   {
     tab.keys[i] = 0;
     tab.count[i] = 0;
@@ -439,11 +440,11 @@ __global__ void __launch_bounds__(kBinThreads)
   }
   __syncthreads();
 
-  const uint32_t first = blockIdx.x * kBinRaysPerBlock;
-  const uint32_t last = min(first + kBinRaysPerBlock, n_rays);
+  const uint32_t first = blockIdx.x * rays_per_block;
+  const uint32_t last = min(first + rays_per_block, n_rays);
   unsigned long long my_visits = 0;
   uint32_t my_ok = 0;
-  for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
+  for (uint32_t ray = first + threadIdx.x; ray < last; ray += blockDim.x)
   {
     RayWalk rw;
     double start[3], end[3];
@@ -512,7 +513,7 @@ __global__ void __launch_bounds__(kBinThreads)
     atomicAdd(&bs.info->rays_ok, (unsigned long long)s_rays_ok);
   }
   // One global insert + one counter atomic per (workgroup, region).
-  for (uint32_t e = threadIdx.x; e < kLtabSize; e += kBinThreads)
+  for (uint32_t e = threadIdx.x; e < kLtabSize; e += blockDim.x)
   {
     const unsigned long long key = tab.keys[e];
     if (key)
@@ -811,10 +812,10 @@ __global__ void __launch_bounds__(1024)
 __global__ void __launch_bounds__(kBinThreads)
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
-            uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits)
+            uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits, uint32_t rays_per_block)
 {
   __shared__ LdsRegionTable tab;
-  for (uint32_t i = threadIdx.x; i < kLtabSize; i += kBinThreads)
+  for (uint32_t i = threadIdx.x; i < kLtabSize; i += blockDim.x)
   {
     tab.keys[i] = 0;
     tab.count[i] = 0;
@@ -822,14 +823,14 @@ __global__ void __launch_bounds__(kBinThreads)
   }
   __syncthreads();
 
-  const uint32_t first = blockIdx.x * kBinRaysPerBlock;
-  const uint32_t last = min(first + kBinRaysPerBlock, n_rays);
+  const uint32_t first = blockIdx.x * rays_per_block;
+  const uint32_t last = min(first + rays_per_block, n_rays);
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
 
   // Step 1: the workgroup's regions with their segment and sample counts come from k_ray_setup (same rays, same LDS
   // table layout); reserve one contiguous range in every region bucket it feeds.
   const uint32_t n_wg_regions = bs.wg_region_count[blockIdx.x];
-  for (uint32_t i = threadIdx.x; i < n_wg_regions; i += kBinThreads)
+  for (uint32_t i = threadIdx.x; i < n_wg_regions; i += blockDim.x)
   {
     const WgRegion wr = bs.wg_regions[size_t(blockIdx.x) * kLtabSize + i];
     tab.keys[wr.entry] = wr.key;
@@ -845,7 +846,7 @@ __global__ void __launch_bounds__(kBinThreads)
   __syncthreads();
   // Step 2: sample keys and mask bits.  bucket_hits: the keys go straight into their region's range of the sample
   // list (k_sort_region_hits orders each range); otherwise they are written in ray order for a device-wide sort.
-  for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
+  for (uint32_t ray = first + threadIdx.x; ray < last; ray += blockDim.x)
   {
     const RayWalk rw = walks[ray];
     unsigned long long hk = kHitInvalid;
@@ -887,7 +888,7 @@ __global__ void __launch_bounds__(kBinThreads)
     }
   }
   // Step 3: scatter.
-  for (uint32_t ray = first + threadIdx.x; ray < last; ray += kBinThreads)
+  for (uint32_t ray = first + threadIdx.x; ray < last; ray += blockDim.x)
   {
     const RayWalk rw = walks[ray];
     forEachSegment(mc, rw, true, [&](uint64_t key, uint32_t rs0, uint32_t rs1, uint32_t rs2) {

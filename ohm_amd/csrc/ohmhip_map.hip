@@ -110,6 +110,7 @@ struct ohmhip_map_s
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
   uint32_t event_demand = 0;
+  double segments_per_ray = 10.0;            ///< running estimate (previous batch) used to size the next batch's chunks
   uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= kMaxChunkSegments (15-bit LDS counters)
   unsigned debug_flags = 0;  ///< OHMHIP_DEBUG_FLAGS: timing experiments only (breaks results)
   int refill_min_idle = kRefillMinIdle;      ///< tunable (OHMHIP_REFILL_MIN_IDLE)  ///< events the previous batch produced (sizes the next batch's list)
@@ -453,7 +454,24 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   hipStream_t s = m->stream;
   hipEvent_t *tev = m->tev[m->batch_seq % kTimingRing];
   const uint32_t ray_blocks = (n_rays + 255) / 256;
-  const uint32_t bin_blocks = (n_rays + kBinRaysPerBlock - 1) / kBinRaysPerBlock;
+  // Binning launch shape: 1024 rays per 512-thread workgroup for large batches; small batches use smaller workgroups
+  // with as many rays as threads so they still cover the CUs.
+  uint32_t bin_rays_per_block = kBinRaysPerBlock;
+  uint32_t bin_threads = kBinThreads;
+  while (bin_rays_per_block > 128 && n_rays / bin_rays_per_block < 2 * m->walk_workgroups)
+  {
+    bin_rays_per_block /= 2;
+  }
+  bin_threads = std::min<uint32_t>(bin_threads, bin_rays_per_block);
+  const uint32_t bin_blocks = (n_rays + bin_rays_per_block - 1) / bin_rays_per_block;
+  // Chunk size of this batch: small batches get smaller chunks so the walk still has a few chunks per CU (estimated
+  // from the previous batch's segments per ray; results do not depend on it).
+  const uint64_t expected_segments = uint64_t(double(n_rays) * m->segments_per_ray);
+  uint32_t batch_chunk_segments = m->chunk_segments;
+  while (batch_chunk_segments > 512 && expected_segments / batch_chunk_segments < 3ull * m->walk_workgroups)
+  {
+    batch_chunk_segments /= 2;
+  }
   const int mode = m->config.mode;
   const bool occupancy_mode = mode == OHMHIP_MODE_OCCUPANCY;
   const bool ndt_mode = mode == OHMHIP_MODE_NDT_OM || mode == OHMHIP_MODE_NDT_TM;
@@ -495,10 +513,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   {
     OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, sizeof(BatchInfo), s));
     OHMHIP_CHECK(hipEventRecord(tev[0], s));
-    hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(kBinThreads), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
-                       n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr));
+    hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
+                       n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr), bin_rays_per_block);
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
-                       m->chunk_capacity, m->chunk_segments);
+                       m->chunk_capacity, batch_chunk_segments);
     OHMHIP_CHECK(hipMemcpyAsync(m->h_info, m->d_info, sizeof(BatchInfo), hipMemcpyDeviceToHost, s));
     OHMHIP_CHECK(hipStreamSynchronize(s));
     OHMHIP_CHECK(hipGetLastError());
@@ -552,9 +570,9 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     // Occupancy: sample keys are bucketed per region and ordered by one workgroup per region in LDS, unless some
     // region holds more samples than that kernel's LDS takes (then: ray-order keys + device-wide radix sort).
     const bool bucket_hits = occupancy_mode && info.max_region_hits <= kSortRegionHits;
-    hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(kBinThreads), 0, s, m->mc, regionTable(m), batchScratch(m),
+    hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m),
                        static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
-                       seg_cap, keys_a, m->d_hit_mask, ray_shift, bucket_hits ? 1 : 0);
+                       seg_cap, keys_a, m->d_hit_mask, ray_shift, bucket_hits ? 1 : 0, bin_rays_per_block);
     if (tsdf_mode)
     {
       hipLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
@@ -585,7 +603,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     float *direct_occ = (occupancy_mode || mode == OHMHIP_MODE_NDT_OM) ?
                           static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]) :
                           nullptr;
-    const uint32_t direct_segments = direct_occ ? m->chunk_segments : 0u;
+    const uint32_t direct_segments = direct_occ ? batch_chunk_segments : 0u;
     uint32_t n_events = 0;
     if (info.n_chunks)
     {
@@ -744,6 +762,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     m->stats.rays_integrated = info.rays_ok;
     m->stats.voxel_visits = info.visits;
     m->stats.ray_region_segments = info.n_segments;
+    m->segments_per_ray = std::max(1.0, double(info.n_segments) / double(std::max<uint32_t>(n_rays, 1u)));
     m->stats.regions_touched = info.n_touched;
     m->stats.regions_resident = info.n_slots;
     m->stats_pending = true;
