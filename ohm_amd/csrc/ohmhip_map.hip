@@ -104,8 +104,8 @@ struct ohmhip_map_s
   uint32_t chunk_capacity = 0;
 
   DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev, events;
-  DevBuf wg_regions, wg_region_count;
-  uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor
+  DevBuf wg_regions, wg_region_count, group_heads;
+  uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
@@ -722,7 +722,21 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
       size_t temp_bytes = m->sort_temp.bytes;
       OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
-      const uint32_t replay_blocks = uint32_t((total + 127) / 128);
+      // NDT: one lane per voxel group -- compact the group heads, then replay grid-stride over them (a voxel's event
+      // list is long there and the maths heavy; a lane per event with the non-heads exiting ran at a few live lanes
+      // per wave).
+      uint32_t *heads = nullptr;
+      uint32_t *n_heads = m->d_event_count + 2;
+      uint32_t replay_blocks = uint32_t((total + 127) / 128);
+      if (ndt_mode)
+      {
+        OHMHIP_CHECK(m->group_heads.ensure(sizeof(uint32_t) * total, false, s));
+        heads = static_cast<uint32_t *>(m->group_heads.ptr);
+        OHMHIP_CHECK(hipMemsetAsync(n_heads, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_group_heads, dim3(uint32_t((total + kHeadsPerBlock - 1) / kHeadsPerBlock)), dim3(256), 0, s,
+                           sorted, uint32_t(total), heads, n_heads);
+        replay_blocks = uint32_t(std::min<size_t>(replay_blocks, size_t(m->walk_workgroups) * 32u));
+      }
       if (ndt_mode)
       {
         const bool tm = mode == OHMHIP_MODE_NDT_TM;
@@ -733,7 +747,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                            static_cast<float *>(m->layers[OHMHIP_LID_COVARIANCE]),
                            tm ? static_cast<float *>(m->layers[OHMHIP_LID_INTENSITY]) : nullptr,
                            tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr, sec,
-                           static_cast<const RayWalk *>(m->walks.ptr));
+                           static_cast<const RayWalk *>(m->walks.ptr), heads, n_heads);
         if (info.n_touched)
         {
           hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
@@ -745,7 +759,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       else
       {
         hipLaunchKernelGGL(k_replay_tsdf, dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
-                           uint32_t(total), d_rays, static_cast<float *>(m->layers[OHMHIP_LID_TSDF]));
+                           uint32_t(total), d_rays, static_cast<float *>(m->layers[OHMHIP_LID_TSDF]), heads, n_heads);
         if (info.n_touched)
         {
           hipLaunchKernelGGL(k_apply_counts_tsdf, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
@@ -927,7 +941,7 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   {
     return fail(err);
   }
-  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_event_count), 2 * sizeof(uint32_t))) != 0)
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_event_count), 4 * sizeof(uint32_t))) != 0)
   {
     return fail(err);
   }
@@ -1021,6 +1035,7 @@ int ohmhip_map_destroy(ohmhip_map_t m)
   m->events.release();
   m->wg_regions.release();
   m->wg_region_count.release();
+  m->group_heads.release();
   if (m->d_event_count)
   {
     (void)hipFree(m->d_event_count);

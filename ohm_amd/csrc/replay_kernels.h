@@ -30,6 +30,66 @@ __device__ inline void voxelCentreOf(const MapConst &mc, const RegionTable &rt, 
   centre[2] = voxelCentreAxis(mc, 2, rk[2], lz);
 }
 
+/// Compact the indices of the first event of every voxel group: the replay kernels then run one lane per VOXEL with full
+/// waves (launching one lane per event and letting the non-heads exit leaves a wave with one or two live lanes that
+/// each loop over a whole group).  Wave-aggregated append; the order of the list does not matter.
+constexpr uint32_t kHeadsPerBlock = 2048;  ///< events scanned by one k_group_heads workgroup (256 threads x 8)
+
+__global__ void __launch_bounds__(256)
+  k_group_heads(const unsigned long long *__restrict__ sorted, uint32_t n_events, uint32_t *__restrict__ heads,
+                uint32_t *__restrict__ n_heads)
+{
+  // Heads are collected in LDS and the workgroup reserves its output range with ONE global atomic (the counter is a
+  // single address: one atomic per wave serialises the whole launch on it).
+  __shared__ uint32_t s_list[kHeadsPerBlock];
+  __shared__ uint32_t s_count;
+  __shared__ uint32_t s_base;
+  if (threadIdx.x == 0)
+  {
+    s_count = 0;
+  }
+  __syncthreads();
+  const unsigned lane = __lane_id();
+  const uint32_t block_first = blockIdx.x * kHeadsPerBlock;
+#pragma unroll
+  for (uint32_t j = 0; j < kHeadsPerBlock / 256; ++j)
+  {
+    const uint32_t i = block_first + j * 256 + threadIdx.x;
+    bool head = false;
+    if (i < n_events)
+    {
+      const unsigned long long key = sorted[i];
+      head = key != kHitInvalid && (i == 0 || (sorted[i - 1] >> kHitRayBits) != (key >> kHitRayBits));
+    }
+    const unsigned long long mask = __ballot(head);
+    if (mask)
+    {
+      const int leader = __ffsll((long long)mask) - 1;
+      uint32_t base = 0;
+      if (int(lane) == leader)
+      {
+        base = atomicAdd(&s_count, uint32_t(__popcll(mask)));
+      }
+      base = __shfl(base, leader);
+      if (head)
+      {
+        s_list[base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)))] = i;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t count = s_count;
+  if (threadIdx.x == 0 && count)
+  {
+    s_base = atomicAdd(n_heads, count);
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < count; k += 256)
+  {
+    heads[s_base + k] = s_list[k];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // NDT: RayMapperNdt::integrateRays per-voxel semantics (ohm/RayMapperNdt.cpp:135-230 misses, :262-402 sample).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -37,23 +97,16 @@ __global__ void __launch_bounds__(128)
   k_replay_ndt(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
                const double *__restrict__ rays, const float *__restrict__ intensities, float *__restrict__ occupancy,
                uint32_t *__restrict__ mean_layer, float *__restrict__ cov_layer, float *__restrict__ intensity_layer,
-               uint32_t *__restrict__ hit_miss_layer, SecondaryLayers sec, const RayWalk *__restrict__ walks)
+               uint32_t *__restrict__ hit_miss_layer, SecondaryLayers sec, const RayWalk *__restrict__ walks,
+               const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_events)
+  // One lane per voxel group (k_group_heads), grid-stride.
+  const uint32_t head_count = *n_heads;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < head_count; h += gridDim.x * blockDim.x)
   {
-    return;
-  }
+  const uint32_t i = heads[h];
   const unsigned long long key = sorted[i];
-  if (key == kHitInvalid)
-  {
-    return;
-  }
   const unsigned long long group = key >> kHitRayBits;
-  if (i > 0 && (sorted[i - 1] >> kHitRayBits) == group)
-  {
-    return;  // not the first event of its voxel
-  }
   const uint32_t slot = uint32_t(key >> kHitSlotShift);
   const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
   const size_t gi = size_t(slot) * size_t(mc.region_voxels) + vi;
@@ -170,6 +223,7 @@ __global__ void __launch_bounds__(128)
     hit_miss_layer[2 * gi] = hm_hit;
     hit_miss_layer[2 * gi + 1] = hm_miss;
   }
+  }  // voxel groups
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -177,22 +231,20 @@ __global__ void __launch_bounds__(128)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(128)
   k_replay_tsdf(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
-                const double *__restrict__ rays, float *__restrict__ tsdf_layer)
+                const double *__restrict__ rays, float *__restrict__ tsdf_layer, const uint32_t *__restrict__ heads,
+                const uint32_t *__restrict__ n_heads)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_events)
+  // Grid-stride over the compacted voxel-group heads (k_group_heads) or, with heads == nullptr, over all events with
+  // the non-heads skipped (TSDF groups are short: the compaction pass costs more than it saves there).
+  const uint32_t head_count = heads ? *n_heads : n_events;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < head_count; h += gridDim.x * blockDim.x)
   {
-    return;
-  }
+  const uint32_t i = heads ? heads[h] : h;
   const unsigned long long key = sorted[i];
-  if (key == kHitInvalid)
-  {
-    return;
-  }
   const unsigned long long group = key >> kHitRayBits;
-  if (i > 0 && (sorted[i - 1] >> kHitRayBits) == group)
+  if (!heads && (key == kHitInvalid || (i > 0 && (sorted[i - 1] >> kHitRayBits) == group)))
   {
-    return;
+    continue;
   }
   const uint32_t slot = uint32_t(key >> kHitSlotShift);
   const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
@@ -218,6 +270,7 @@ __global__ void __launch_bounds__(128)
   }
   tsdf_layer[2 * gi] = weight;
   tsdf_layer[2 * gi + 1] = distance;
+  }  // voxel groups
 }
 
 /// TSDF: one block per touched region: voxels which only saw free-space visits this batch (count n, none flagged):
