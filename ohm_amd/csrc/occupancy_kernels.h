@@ -1035,7 +1035,7 @@ constexpr int kSortThreads = 1024;
 
 __global__ void __launch_bounds__(kSortThreads)
   k_sort_region_hits(RegionTable rt, BatchScratch bs, const unsigned long long *__restrict__ keys,
-                     unsigned long long *__restrict__ sorted, int region_voxels, int debug_skip)
+                     unsigned long long *__restrict__ sorted, int region_voxels)
 {
   __shared__ unsigned long long l_keys[kSortRegionHits + kSortRegionHits / 32];
   const uint32_t h = bs.sort_list[blockIdx.x];
@@ -1063,7 +1063,7 @@ __global__ void __launch_bounds__(kSortThreads)
   // Bitonic network, up to three consecutive compare distances (j, j/2, j/4) fused per LDS round trip: a thread pulls
   // the 8 (4, 2) elements those stages connect into registers, runs the butterflies there and writes them back.
   // The network is LDS-bandwidth bound, so this cuts its cost by the same factor as the traffic (~2.6x).
-  for (uint32_t k = 2; k <= padded && !(debug_skip & 1); k <<= 1)
+  for (uint32_t k = 2; k <= padded; k <<= 1)
   {
     uint32_t j = k >> 1;
     while (j > 0)
@@ -1096,7 +1096,7 @@ __global__ void __launch_bounds__(kSortThreads)
   {
     const unsigned long long key = l_keys[sortSlot(i)];
     sorted[begin + i] = key;
-    if (!(debug_skip & 2) && (i == 0 || (l_keys[sortSlot(i - 1)] >> kHitRayBits) != (key >> kHitRayBits)))
+    if (i == 0 || (l_keys[sortSlot(i - 1)] >> kHitRayBits) != (key >> kHitRayBits))
     {
       // First sample of its voxel: entry point for ordering misses against this voxel's samples.
       const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
@@ -1380,497 +1380,524 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   uint32_t chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
   while (chunk_index < args.n_chunks)
   {
-  const unsigned long long clk_start = args.dbg_counters ? wall_clock64() : 0ull;
-  Chunk chunk;
-  chunk.slot = __builtin_amdgcn_readfirstlane(l_cursor[2]);
-  chunk.seg_begin = __builtin_amdgcn_readfirstlane(l_cursor[3]);
-  chunk.seg_end = __builtin_amdgcn_readfirstlane(l_cursor[4]);
-  chunk.hash_index = __builtin_amdgcn_readfirstlane(l_cursor[5]);
-  const uint32_t hb = __builtin_amdgcn_readfirstlane(l_cursor[6]);
-  const uint32_t he = __builtin_amdgcn_readfirstlane(l_cursor[7]);
-  const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
-  const Segment *chunk_segments = args.segments + chunk.seg_begin;
+    const unsigned long long clk_start = args.dbg_counters ? wall_clock64() : 0ull;
+    Chunk chunk;
+    chunk.slot = __builtin_amdgcn_readfirstlane(l_cursor[2]);
+    chunk.seg_begin = __builtin_amdgcn_readfirstlane(l_cursor[3]);
+    chunk.seg_end = __builtin_amdgcn_readfirstlane(l_cursor[4]);
+    chunk.hash_index = __builtin_amdgcn_readfirstlane(l_cursor[5]);
+    const uint32_t hb = __builtin_amdgcn_readfirstlane(l_cursor[6]);
+    const uint32_t he = __builtin_amdgcn_readfirstlane(l_cursor[7]);
+    const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
+    const Segment *chunk_segments = args.segments + chunk.seg_begin;
 
-  // ---- prologue.  One workgroup owns the CU (the tile takes most of its LDS), so nothing overlaps this phase: every
-  // ---- global load that depends only on the chunk record is issued back to back, clamped instead of predicated so
-  // ---- the loads share one basic block, and consumed afterwards.
-  constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
-  constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
-  uint32_t lens[kSegPerThread];
-#pragma unroll
-  for (int j = 0; j < kSegPerThread; ++j)
-  {
-    const uint32_t i = min(threadIdx.x + uint32_t(j) * kWalkThreads, n_seg - 1u);
-    const uint2 w = *reinterpret_cast<const uint2 *>(&chunk_segments[i].s1);
-    lens[j] = min((w.x >> 24) | ((w.y >> 24) << 8), kLengthClasses - 1u);
-  }
-  const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
-  const uint32_t my_mask = g_mask[min(threadIdx.x, mask_words - 1u)];
-  // Stage the region's sorted sample keys so deferred misses can be ordered against them at LDS latency.
-  const uint32_t n_region_hits = he - hb;
-  const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(kLdsHits);
-  unsigned long long my_hits[kHitsPerThread];
-  if (lds_resolve && n_region_hits)
-  {
-#pragma unroll
-    for (int j = 0; j < kHitsPerThread; ++j)
+    // ---- prologue.  One workgroup owns the CU (the tile takes most of its LDS), so nothing overlaps this phase: every
+    // ---- global load that depends only on the chunk record is issued back to back, clamped instead of predicated so
+    // ---- the loads share one basic block, and consumed afterwards.
+    constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
+    constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
+    uint32_t lens[kSegPerThread];
+  #pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j)
     {
-      my_hits[j] = args.sorted_hits[hb + min(threadIdx.x + uint32_t(j) * kWalkThreads, n_region_hits - 1u)];
+      const uint32_t i = min(threadIdx.x + uint32_t(j) * kWalkThreads, n_seg - 1u);
+      const uint2 w = *reinterpret_cast<const uint2 *>(&chunk_segments[i].s1);
+      lens[j] = min((w.x >> 24) | ((w.y >> 24) << 8), kLengthClasses - 1u);
     }
-  }
-  if (threadIdx.x < kLengthClasses)
-  {
-    l_hist[threadIdx.x] = 0;
-  }
-  if (threadIdx.x == 0)
-  {
-    l_cursor[0] = 0;
-  }
-  const bool stamp = args.dbg_counters && threadIdx.x == 0;
-  unsigned long long clk_p[6] = { 0, 0, 0, 0, 0, 0 };
-  if (stamp)
-  {
-    clk_p[0] = wall_clock64();
-  }
-  // Tile entries start at zero count with the voxel's mask flag in the top bit: one mask word covers 16 tile words.
-  for (uint32_t w = threadIdx.x; w < mask_words; w += kWalkThreads)
-  {
-    const uint32_t mword = (w == threadIdx.x) ? my_mask : g_mask[w];
-#pragma unroll
-    for (uint32_t q = 0; q < 4; ++q)
+    const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
+    const uint32_t my_mask = g_mask[min(threadIdx.x, mask_words - 1u)];
+    // Stage the region's sorted sample keys so deferred misses can be ordered against them at LDS latency.
+    const uint32_t n_region_hits = he - hb;
+    const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(kLdsHits);
+    unsigned long long my_hits[kHitsPerThread];
+    if (lds_resolve && n_region_hits)
     {
-      uint32_t v[4];
-#pragma unroll
-      for (uint32_t r = 0; r < 4; ++r)
+  #pragma unroll
+      for (int j = 0; j < kHitsPerThread; ++j)
       {
-        const uint32_t two = (mword >> ((q * 4u + r) * 2u)) & 3u;
-        v[r] = ((two & 1u) << 15) | ((two & 2u) << 30);
+        my_hits[j] = args.sorted_hits[hb + min(threadIdx.x + uint32_t(j) * kWalkThreads, n_region_hits - 1u)];
       }
-      if (w * 16u + q * 4u + 3u < count_words)
+    }
+    if (threadIdx.x < kLengthClasses)
+    {
+      l_hist[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0)
+    {
+      l_cursor[0] = 0;
+    }
+    const bool stamp = args.dbg_counters && threadIdx.x == 0;
+    unsigned long long clk_p[6] = { 0, 0, 0, 0, 0, 0 };
+    if (stamp)
+    {
+      clk_p[0] = wall_clock64();
+    }
+    // Tile entries start at zero count with the voxel's mask flag in the top bit: one mask word covers 16 tile words.
+    for (uint32_t w = threadIdx.x; w < mask_words; w += kWalkThreads)
+    {
+      const uint32_t mword = (w == threadIdx.x) ? my_mask : g_mask[w];
+  #pragma unroll
+      for (uint32_t q = 0; q < 4; ++q)
       {
-        *reinterpret_cast<uint4 *>(&l_counts[w * 16u + q * 4u]) = make_uint4(v[0], v[1], v[2], v[3]);
-      }
-      else
-      {
+        uint32_t v[4];
+  #pragma unroll
         for (uint32_t r = 0; r < 4; ++r)
         {
-          if (w * 16u + q * 4u + r < count_words)
+          const uint32_t two = (mword >> ((q * 4u + r) * 2u)) & 3u;
+          v[r] = ((two & 1u) << 15) | ((two & 2u) << 30);
+        }
+        if (w * 16u + q * 4u + 3u < count_words)
+        {
+          *reinterpret_cast<uint4 *>(&l_counts[w * 16u + q * 4u]) = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        else
+        {
+          for (uint32_t r = 0; r < 4; ++r)
           {
-            l_counts[w * 16u + q * 4u + r] = v[r];
+            if (w * 16u + q * 4u + r < count_words)
+            {
+              l_counts[w * 16u + q * 4u + r] = v[r];
+            }
           }
         }
       }
     }
-  }
-  if (stamp)
-  {
-    clk_p[1] = wall_clock64();
-  }
-  __syncthreads();
-  if (stamp)
-  {
-    clk_p[2] = wall_clock64();
-  }
-  // Longest segments first (counting sort on the voxel count, indices in LDS): lanes refilled together get segments
-  // of similar length and so retire together, and the workgroup drains on its SHORTEST segments instead of waiting
-  // for a few long stragglers.  The order inside a length class is arbitrary; integer counting does not care.
-#pragma unroll
-  for (int j = 0; j < kSegPerThread; ++j)
-  {
-    if (threadIdx.x + uint32_t(j) * kWalkThreads < n_seg)
+    if (stamp)
     {
-      atomicAdd(&l_hist[lens[j]], 1u);
+      clk_p[1] = wall_clock64();
     }
-  }
-  if (lds_resolve && n_region_hits)
-  {
-#pragma unroll
-    for (int j = 0; j < kHitsPerThread; ++j)
+    __syncthreads();
+    if (stamp)
+    {
+      clk_p[2] = wall_clock64();
+    }
+    // Longest segments first (counting sort on the voxel count, indices in LDS): lanes refilled together get segments
+    // of similar length and so retire together, and the workgroup drains on its SHORTEST segments instead of waiting
+    // for a few long stragglers.  The order inside a length class is arbitrary; integer counting does not care.
+  #pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j)
+    {
+      if (threadIdx.x + uint32_t(j) * kWalkThreads < n_seg)
+      {
+        atomicAdd(&l_hist[lens[j]], 1u);
+      }
+    }
+    if (lds_resolve && n_region_hits)
+    {
+  #pragma unroll
+      for (int j = 0; j < kHitsPerThread; ++j)
+      {
+        const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
+        if (i < n_region_hits)
+        {
+          l_hits[i] = my_hits[j];
+        }
+        if (i < (n_region_hits + 1) / 2)
+        {
+          l_intervals[i] = 0;  // two u16 counters per word (a chunk adds at most kMaxChunkSegments to one counter)
+        }
+      }
+    }
+    __syncthreads();
+    if (stamp)
+    {
+      clk_p[3] = wall_clock64();
+    }
+    if (threadIdx.x < 64)
+    {
+      // Exclusive scan over the classes in DESCENDING length order: lane l owns classes 127 - 2l and 126 - 2l.
+      const uint32_t hi_class = kLengthClasses - 1u - 2u * threadIdx.x;
+      const uint32_t a = l_hist[hi_class];
+      const uint32_t b = l_hist[hi_class - 1u];
+      uint32_t incl = a + b;
+  #pragma unroll
+      for (int d = 1; d < 64; d <<= 1)
+      {
+        const uint32_t up = __shfl_up(incl, d);
+        incl += (int(threadIdx.x) >= d) ? up : 0u;
+      }
+      const uint32_t excl = incl - (a + b);
+      l_hist[hi_class] = excl;
+      l_hist[hi_class - 1u] = excl + a;
+    }
+    __syncthreads();
+  #pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j)
     {
       const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
-      if (i < n_region_hits)
+      if (i < n_seg)
       {
-        l_hits[i] = my_hits[j];
-      }
-      if (i < (n_region_hits + 1) / 2)
-      {
-        l_intervals[i] = 0;  // two u16 counters per word (a chunk adds at most kMaxChunkSegments to one counter)
+        l_order[atomicAdd(&l_hist[lens[j]], 1u)] = uint16_t(i);
       }
     }
-  }
-  __syncthreads();
-  if (stamp)
-  {
-    clk_p[3] = wall_clock64();
-  }
-  if (threadIdx.x < 64)
-  {
-    // Exclusive scan over the classes in DESCENDING length order: lane l owns classes 127 - 2l and 126 - 2l.
-    const uint32_t hi_class = kLengthClasses - 1u - 2u * threadIdx.x;
-    const uint32_t a = l_hist[hi_class];
-    const uint32_t b = l_hist[hi_class - 1u];
-    uint32_t incl = a + b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
+    __syncthreads();
+    if (stamp)
     {
-      const uint32_t up = __shfl_up(incl, d);
-      incl += (int(threadIdx.x) >= d) ? up : 0u;
-    }
-    const uint32_t excl = incl - (a + b);
-    l_hist[hi_class] = excl;
-    l_hist[hi_class - 1u] = excl + a;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < kSegPerThread; ++j)
-  {
-    const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
-    if (i < n_seg)
-    {
-      l_order[atomicAdd(&l_hist[lens[j]], 1u)] = uint16_t(i);
-    }
-  }
-  __syncthreads();
-  if (stamp)
-  {
-    clk_p[4] = wall_clock64();
-    if (chunk_index < kTraceChunks)
-    {
-      unsigned long long *rec = args.dbg_counters + 16 + size_t(chunk_index) * kTraceWords;
-      rec[20] = clk_p[0];
-      rec[21] = clk_p[1];
-      rec[22] = clk_p[2];
-      rec[23] = clk_p[3];
-    }
-  }
-
-  const unsigned lane = laneId();
-  const unsigned wave = threadIdx.x >> 6;
-  uint2 *queue = l_queues + wave * kQueueCap;
-  const int dimx = mc.dim[0];
-  const int dimxy = mc.dim[0] * mc.dim[1];
-  const double inf = dInf();
-  const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
-  const int ray_shift = args.ray_shift;
-  const int refill_min_idle = args.refill_min_idle;
-  const bool refill_only = (args.dbg & 16u) != 0;
-
-  // Per-lane walk state (all named scalars: no run-time indexed arrays).
-  int left = 0;  // voxels this lane still has to visit in its segment (<= 0: idle)
-  double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
-  double t0 = 0, t1 = 0, t2 = 0;                          // time_next per axis
-  int k0 = 0, k1 = 0, k2 = 0, tot0 = 0, tot1 = 0, tot2 = 0;  // steps taken / steps in the whole ray per axis
-  int sx = 0, sy = 0, sz = 0;
-  uint32_t vi = 0;
-  uint32_t ray = 0;
-  uint32_t skip = 0;      // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
-  uint32_t end_last = 0;  // kSpecial only: the segment's last voxel is the ray's end voxel
-  double t_enter = 0;     // kTraversal: range at which the current voxel was entered
-  double ray_len = 0;     // kTraversal && kSpecial: exit range of the end voxel
-  uint32_t qcount = 0;     // wave-uniform
-  bool exhausted = false;  // wave-uniform
-  uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;  // wave-uniform
-  const unsigned long long clk_loop = args.dbg_counters ? wall_clock64() : 0ull;
-
-  while (true)
-  {
-    // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
-    unsigned long long am = __ballot(left > 0);
-    const int n_idle = 64 - __popcll(am);
-    if (!exhausted && (n_idle >= refill_min_idle))
-    {
-      ++dbg_refills;
-      uint32_t base = 0;
-      if (lane == 0)
+      clk_p[4] = wall_clock64();
+      if (chunk_index < kTraceChunks)
       {
-        base = atomicAdd(l_cursor, uint32_t(n_idle));
+        unsigned long long *rec = args.dbg_counters + 16 + size_t(chunk_index) * kTraceWords;
+        rec[20] = clk_p[0];
+        rec[21] = clk_p[1];
+        rec[22] = clk_p[2];
+        rec[23] = clk_p[3];
       }
-      base = __builtin_amdgcn_readfirstlane(base);
-      exhausted = base + uint32_t(n_idle) >= n_seg;
-      const unsigned long long idle = ~am;
-      const uint32_t mine =
-        base + __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
-      if (left <= 0 && mine < n_seg)
+    }
+
+    const unsigned lane = laneId();
+    const unsigned wave = threadIdx.x >> 6;
+    uint2 *queue = l_queues + wave * kQueueCap;
+    const int dimx = mc.dim[0];
+    const int dimxy = mc.dim[0] * mc.dim[1];
+    const double inf = dInf();
+    const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
+    const int ray_shift = args.ray_shift;
+    const int refill_min_idle = args.refill_min_idle;
+    const bool refill_only = (args.dbg & 16u) != 0;
+
+    // Per-lane walk state (all named scalars: no run-time indexed arrays).
+    int left = 0;  // voxels this lane still has to visit in its segment (<= 0: idle)
+    double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
+    double t0 = 0, t1 = 0, t2 = 0;                          // time_next per axis
+    int k0 = 0, k1 = 0, k2 = 0, tot0 = 0, tot1 = 0, tot2 = 0;  // steps taken / steps in the whole ray per axis
+    int sx = 0, sy = 0, sz = 0;
+    uint32_t vi = 0;
+    uint32_t ray = 0;
+    uint32_t skip = 0;      // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
+    uint32_t end_last = 0;  // kSpecial only: the segment's last voxel is the ray's end voxel
+    double t_enter = 0;     // kTraversal: range at which the current voxel was entered
+    double ray_len = 0;     // kTraversal && kSpecial: exit range of the end voxel
+    uint32_t qcount = 0;     // wave-uniform
+    bool exhausted = false;  // wave-uniform
+    uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;  // wave-uniform
+    const unsigned long long clk_loop = args.dbg_counters ? wall_clock64() : 0ull;
+
+    while (true)
+    {
+      // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
+      unsigned long long am = __ballot(left > 0);
+      const int n_idle = 64 - __popcll(am);
+      if (!exhausted && (n_idle >= refill_min_idle))
       {
-        const Segment seg = chunk_segments[l_order[mine]];
-        const RayWalk rw = args.walks[seg.ray];
-        const int s0 = int(seg.s0 & kSegStepMask);
-        const int s1 = int(seg.s1 & kSegStepMask);
-        const int s2 = int(seg.s2 & kSegStepMask);
-        i0 = rw.init[0];
-        i1 = rw.init[1];
-        i2 = rw.init[2];
-        e0 = rw.delta[0];
-        e1 = rw.delta[1];
-        e2 = rw.delta[2];
-        const int d0 = rwDir(rw, 0);
-        const int d1 = rwDir(rw, 1);
-        const int d2 = rwDir(rw, 2);
-        const int l0 = localCoord(rw.g0[0] + d0 * s0, mc.dim[0]);
-        const int l1 = localCoord(rw.g0[1] + d1 * s1, mc.dim[1]);
-        const int l2 = localCoord(rw.g0[2] + d2 * s2, mc.dim[2]);
-        k0 = s0;
-        k1 = s1;
-        k2 = s2;
-        tot0 = rw.total[0];
-        tot1 = rw.total[1];
-        tot2 = rw.total[2];
-        // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
-        t0 = (s0 < tot0) ? ((s0 == 0) ? i0 : i0 + e0 * double(s0)) : inf;
-        t1 = (s1 < tot1) ? ((s1 == 0) ? i1 : i1 + e1 * double(s1)) : inf;
-        t2 = (s2 < tot2) ? ((s2 == 0) ? i2 : i2 + e2 * double(s2)) : inf;
-        sx = d0;
-        sy = d1 * dimx;
-        sz = d2 * dimxy;
-        vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
-        ray = seg.ray;
-        left = int((seg.s1 >> 24) | ((seg.s2 >> 24) << 8));
-        if (kTraversal)
+        ++dbg_refills;
+        uint32_t base = 0;
+        if (lane == 0)
         {
-          // The step which entered this region is the latest step taken so far.
-          double te = 0;
-          te = (s0 > 0) ? stepTime(i0, e0, s0) : te;
-          const double te1 = (s1 > 0) ? stepTime(i1, e1, s1) : 0.0;
-          const double te2 = (s2 > 0) ? stepTime(i2, e2, s2) : 0.0;
-          te = (te1 > te) ? te1 : te;
-          te = (te2 > te) ? te2 : te;
-          t_enter = te;
-          ray_len = rw.length;
+          base = atomicAdd(l_cursor, uint32_t(n_idle));
         }
-        if (kSpecial)
+        base = __builtin_amdgcn_readfirstlane(base);
+        exhausted = base + uint32_t(n_idle) >= n_seg;
+        const unsigned long long idle = ~am;
+        const uint32_t mine =
+          base + __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
+        if (left <= 0 && mine < n_seg)
         {
-          skip = ((seg.s0 & kSegFirst) && (rw.flags & kRwExcludeStart)) ? 1u : 0u;
-          end_last = (seg.s0 & kSegEnd) ? 1u : 0u;
+          const Segment seg = chunk_segments[l_order[mine]];
+          const RayWalk rw = args.walks[seg.ray];
+          const int s0 = int(seg.s0 & kSegStepMask);
+          const int s1 = int(seg.s1 & kSegStepMask);
+          const int s2 = int(seg.s2 & kSegStepMask);
+          i0 = rw.init[0];
+          i1 = rw.init[1];
+          i2 = rw.init[2];
+          e0 = rw.delta[0];
+          e1 = rw.delta[1];
+          e2 = rw.delta[2];
+          const int d0 = rwDir(rw, 0);
+          const int d1 = rwDir(rw, 1);
+          const int d2 = rwDir(rw, 2);
+          const int l0 = localCoord(rw.g0[0] + d0 * s0, mc.dim[0]);
+          const int l1 = localCoord(rw.g0[1] + d1 * s1, mc.dim[1]);
+          const int l2 = localCoord(rw.g0[2] + d2 * s2, mc.dim[2]);
+          k0 = s0;
+          k1 = s1;
+          k2 = s2;
+          tot0 = rw.total[0];
+          tot1 = rw.total[1];
+          tot2 = rw.total[2];
+          // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
+          t0 = (s0 < tot0) ? ((s0 == 0) ? i0 : i0 + e0 * double(s0)) : inf;
+          t1 = (s1 < tot1) ? ((s1 == 0) ? i1 : i1 + e1 * double(s1)) : inf;
+          t2 = (s2 < tot2) ? ((s2 == 0) ? i2 : i2 + e2 * double(s2)) : inf;
+          sx = d0;
+          sy = d1 * dimx;
+          sz = d2 * dimxy;
+          vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
+          ray = seg.ray;
+          left = int((seg.s1 >> 24) | ((seg.s2 >> 24) << 8));
+          if (kTraversal)
+          {
+            // The step which entered this region is the latest step taken so far.
+            double te = 0;
+            te = (s0 > 0) ? stepTime(i0, e0, s0) : te;
+            const double te1 = (s1 > 0) ? stepTime(i1, e1, s1) : 0.0;
+            const double te2 = (s2 > 0) ? stepTime(i2, e2, s2) : 0.0;
+            te = (te1 > te) ? te1 : te;
+            te = (te2 > te) ? te2 : te;
+            t_enter = te;
+            ray_len = rw.length;
+          }
+          if (kSpecial)
+          {
+            skip = ((seg.s0 & kSegFirst) && (rw.flags & kRwExcludeStart)) ? 1u : 0u;
+            end_last = (seg.s0 & kSegEnd) ? 1u : 0u;
+          }
+          left = refill_only ? 0 : left;
         }
-        left = refill_only ? 0 : left;
+        am = __ballot(left > 0);
       }
-      am = __ballot(left > 0);
-    }
-    if (am == 0)
-    {
-      break;
-    }
-
-    // ---- visit: count the miss and fetch the voxel's mask flag with one returning LDS atomic.  Masked voxels (which
-    // ---- also receive samples) are counted too; the ordering pass moves such a miss to an interval counter when a
-    // ---- later sample of the voxel exists.
-    const bool active = left > 0;
-    // kSpecial: the ray's end voxel (last voxel of a kSegEnd segment) is always visited; kRfExcludeOrigin drops the
-    // first voxel of the ray otherwise.
-    const bool at_end = kSpecial && end_last && left == 1;
-    const bool visit = kSpecial ? (active && (at_end || !skip)) : active;
-    const uint32_t vi_visit = vi;
-    const uint32_t sh = (vi_visit & 1u) << 4;
-    uint32_t old = 0;
-    if (visit)
-    {
-      old = atomicAdd(&l_counts[vi_visit >> 1], 1u << sh);
-    }
-    double t_exit = 0;
-    if (kTraversal)
-    {
-      // exit range of this voxel == time of the next step (the ray's length at its end voxel)
-      const double tm01 = (t0 < t1) ? t0 : t1;
-      t_exit = (tm01 < t2) ? tm01 : t2;
-      if (kSpecial)
+      if (am == 0)
       {
-        t_exit = at_end ? ray_len : t_exit;
+        break;
       }
+
+      // ---- visit: count the miss and fetch the voxel's mask flag with one returning LDS atomic.  Masked voxels (which
+      // ---- also receive samples) are counted too; the ordering pass moves such a miss to an interval counter when a
+      // ---- later sample of the voxel exists.
+      const bool active = left > 0;
+      // kSpecial: the ray's end voxel (last voxel of a kSegEnd segment) is always visited; kRfExcludeOrigin drops the
+      // first voxel of the ray otherwise.
+      const bool at_end = kSpecial && end_last && left == 1;
+      const bool visit = kSpecial ? (active && (at_end || !skip)) : active;
+      const uint32_t vi_visit = vi;
+      const uint32_t sh = (vi_visit & 1u) << 4;
+      uint32_t old = 0;
       if (visit)
       {
-        atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + vi_visit], float(t_exit - t_enter));
-        t_enter = t_exit;
+        old = atomicAdd(&l_counts[vi_visit >> 1], 1u << sh);
       }
-      else if (active)
+      double t_exit = 0;
+      if (kTraversal)
       {
-        t_enter = t_exit;
+        // exit range of this voxel == time of the next step (the ray's length at its end voxel)
+        const double tm01 = (t0 < t1) ? t0 : t1;
+        t_exit = (tm01 < t2) ? tm01 : t2;
+        if (kSpecial)
+        {
+          t_exit = at_end ? ray_len : t_exit;
+        }
+        if (visit)
+        {
+          atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + vi_visit], float(t_exit - t_enter));
+          t_enter = t_exit;
+        }
+        else if (active)
+        {
+          t_enter = t_exit;
+        }
       }
-    }
-    if (kSpecial)
-    {
-      skip = 0;
-    }
-    ++dbg_iters;
+      if (kSpecial)
+      {
+        skip = 0;
+      }
+      ++dbg_iters;
 
-    // ---- one branch-free walk step, taken by every lane (an idle lane's state is dead, and the step after a
-    // ---- segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the
-    // ---- higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
-    {
-      const bool c01 = t0 < t1;
-      const double t01 = c01 ? t0 : t1;
-      const bool c2 = t01 < t2;
-      const bool a0 = c2 && c01;
-      const bool a1 = c2 && !c01;
-      const bool a2 = !c2;
-      k0 += int(a0);
-      k1 += int(a1);
-      k2 += int(a2);
-      const double n0 = (k0 < tot0) ? i0 + e0 * double(k0) : inf;
-      const double n1 = (k1 < tot1) ? i1 + e1 * double(k1) : inf;
-      const double n2 = (k2 < tot2) ? i2 + e2 * double(k2) : inf;
-      t0 = a0 ? n0 : t0;
-      t1 = a1 ? n1 : t1;
-      t2 = a2 ? n2 : t2;
-      int stride = a0 ? sx : sy;
-      stride = a2 ? sz : stride;
-      vi += uint32_t(stride);
-      left -= 1;
+      // ---- one branch-free walk step, taken by every lane (an idle lane's state is dead, and the step after a
+      // ---- segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the
+      // ---- higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
+      {
+        const bool c01 = t0 < t1;
+        const double t01 = c01 ? t0 : t1;
+        const bool c2 = t01 < t2;
+        const bool a0 = c2 && c01;
+        const bool a1 = c2 && !c01;
+        const bool a2 = !c2;
+        k0 += int(a0);
+        k1 += int(a1);
+        k2 += int(a2);
+        const double n0 = (k0 < tot0) ? i0 + e0 * double(k0) : inf;
+        const double n1 = (k1 < tot1) ? i1 + e1 * double(k1) : inf;
+        const double n2 = (k2 < tot2) ? i2 + e2 * double(k2) : inf;
+        t0 = a0 ? n0 : t0;
+        t1 = a1 ? n1 : t1;
+        t2 = a2 ? n2 : t2;
+        int stride = a0 ? sx : sy;
+        stride = a2 ? sz : stride;
+        vi += uint32_t(stride);
+        left -= 1;
+      }
+
+      // ---- deferred ordering of misses on masked voxels.  Consumed after the step so the atomic's return latency is
+      // ---- covered by the step arithmetic: the empty asm pins the step's results ahead of this point (the optimiser
+      // ---- otherwise sinks the step below the flag test and the wave waits on the LDS round trip every iteration).
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(k0), "+v"(k1), "+v"(k2), "+v"(vi), "+v"(left));
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const bool flagged = __builtin_amdgcn_ubfe(old, sh + 15u, 1u) != 0;
+        const unsigned long long fm = __ballot(flagged);
+        if (args.dbg_counters)
+        {
+          dbg_active += uint32_t(__popcll(__ballot(visit)));
+          dbg_fm += fm ? 1u : 0u;
+        }
+        if (fm)
+        {
+          if (flagged)
+          {
+            const uint32_t pos =
+              qcount + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u));
+            queue[pos] = make_uint2(vi_visit, ray);
+          }
+          qcount += uint32_t(__popcll(fm));
+          if (qcount > uint32_t(kQueueCap - 64))
+          {
+            flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals,
+                       l_counts, args.events, args.event_capacity, args.event_count, defer_all, args.bs,
+                       args.sorted_hits, args.miss_counts, args.interval_counts, mc.region_voxels);
+            qcount = 0;
+          }
+        }
+      }
     }
 
-    // ---- deferred ordering of misses on masked voxels.  Consumed after the step so the atomic's return latency is
-    // ---- covered by the step arithmetic: the empty asm pins the step's results ahead of this point (the optimiser
-    // ---- otherwise sinks the step below the flag test and the wave waits on the LDS round trip every iteration).
-    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(k0), "+v"(k1), "+v"(k2), "+v"(vi), "+v"(left));
-    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long clk_end_loop = 0;
+    if (args.dbg_counters && lane == 0)
     {
-      const bool flagged = __builtin_amdgcn_ubfe(old, sh + 15u, 1u) != 0;
-      const unsigned long long fm = __ballot(flagged);
-      if (args.dbg_counters)
+      clk_end_loop = wall_clock64();
+      if (chunk_index < kTraceChunks)
       {
-        dbg_active += uint32_t(__popcll(__ballot(visit)));
-        dbg_fm += fm ? 1u : 0u;
+        unsigned long long *rec = args.dbg_counters + 16 + size_t(chunk_index) * kTraceWords;
+        if (wave < 15)
+        {
+          rec[2 + wave] = clk_end_loop;
+        }
+        if (wave == 0)
+        {
+          rec[0] = n_seg | ((unsigned long long)((chunk.hash_index >> 31) & 1u) << 32);
+          rec[1] = clk_loop;
+          rec[18] = clk_start;
+          rec[17] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
+                    ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_ID | XCC_ID
+        }
       }
-      if (fm)
+      if (args.dbg & 128u)
       {
-        if (flagged)
-        {
-          const uint32_t pos =
-            qcount + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u));
-          queue[pos] = make_uint2(vi_visit, ray);
-        }
-        qcount += uint32_t(__popcll(fm));
-        if (qcount > uint32_t(kQueueCap - 64))
-        {
-          flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals,
-                     l_counts, args.events, args.event_capacity, args.event_count, defer_all, args.bs,
-                     args.sorted_hits, args.miss_counts, args.interval_counts, mc.region_voxels);
-          qcount = 0;
-        }
+        atomicAdd(&args.dbg_counters[0], (unsigned long long)dbg_iters);
+        atomicAdd(&args.dbg_counters[1], (unsigned long long)dbg_active);
+        atomicAdd(&args.dbg_counters[2], (unsigned long long)dbg_refills);
+        atomicAdd(&args.dbg_counters[3], (unsigned long long)dbg_fm);
       }
     }
-  }
+    // Final queue flush.
+    if (qcount)
+    {
+      flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals, l_counts,
+                 args.events, args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits,
+                 args.miss_counts, args.interval_counts, mc.region_voxels);
+    }
+    if (threadIdx.x == 0)
+    {
+      fetchNextChunk();  // overlaps with the other waves finishing their loop
+    }
+    __syncthreads();
+    if (stamp && chunk_index < kTraceChunks)
+    {
+      args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 24] = wall_clock64();  // epilogue start
+    }
 
-  unsigned long long clk_end_loop = 0;
-  if (args.dbg_counters && lane == 0)
-  {
-    clk_end_loop = wall_clock64();
-    if (chunk_index < kTraceChunks)
+    if (lds_resolve)
     {
-      unsigned long long *rec = args.dbg_counters + 16 + size_t(chunk_index) * kTraceWords;
-      if (wave < 15)
+      for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
       {
-        rec[2 + wave] = clk_end_loop;
-      }
-      if (wave == 0)
-      {
-        rec[0] = n_seg | ((unsigned long long)((chunk.hash_index >> 31) & 1u) << 32);
-        rec[1] = clk_loop;
-        rec[18] = clk_start;
-        rec[17] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
-                  ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_ID | XCC_ID
-      }
-    }
-    if (args.dbg & 128u)
-    {
-      atomicAdd(&args.dbg_counters[0], (unsigned long long)dbg_iters);
-      atomicAdd(&args.dbg_counters[1], (unsigned long long)dbg_active);
-      atomicAdd(&args.dbg_counters[2], (unsigned long long)dbg_refills);
-      atomicAdd(&args.dbg_counters[3], (unsigned long long)dbg_fm);
-    }
-  }
-  // Final queue flush.
-  if (qcount)
-  {
-    flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals, l_counts,
-               args.events, args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits,
-               args.miss_counts, args.interval_counts, mc.region_voxels);
-  }
-  if (threadIdx.x == 0)
-  {
-    fetchNextChunk();  // overlaps with the other waves finishing their loop
-  }
-  __syncthreads();
-  if (stamp && chunk_index < kTraceChunks)
-  {
-    args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 24] = wall_clock64();  // epilogue start
-  }
-
-  if (lds_resolve)
-  {
-    for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
-    {
-      const uint32_t c = (l_intervals[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
-      if (c)
-      {
-        atomicAdd(&args.interval_counts[hb + i], c);
-      }
-    }
-  }
-  uint32_t *g_counts = args.miss_counts + size_t(chunk.slot) * size_t(mc.region_voxels);
-  if (args.occupancy && (chunk.hash_index & 0x80000000u))
-  {
-    // This chunk holds ALL of the region's segments for the batch: apply the miss counts to the log-odds layer
-    // straight from LDS (no count round trip through HBM).  Voxels which also receive samples keep their count for
-    // the ordered replay (occupancy: k_apply_hits; NDT: their visits are events, the tile entry is not used).
-    float *g_occ = args.occupancy + size_t(chunk.slot) * size_t(mc.region_voxels);
-    // Two passes so the loads of all the voxels a thread updates are in flight together (a load -> update -> store
-    // loop would pay the memory latency once per touched word, and nothing else runs on this CU to hide it).
-    constexpr uint32_t kWordsPerThread = (1u << kHitVoxelBits) / 2u / kWalkThreads;
-    uint32_t words[kWordsPerThread];
-    float2 values[kWordsPerThread];
-    const bool even_voxels = (mc.region_voxels & 1) == 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kWordsPerThread; ++j)
-    {
-      const uint32_t i = threadIdx.x + j * kWalkThreads;
-      uint32_t w = (i < count_words) ? l_counts[i] : 0u;
-      // Keep only the entries applied here: unflagged voxels with a count.
-      w = (w & kTileFlag) ? (w & 0xffff0000u) : w;
-      w = (w & (kTileFlag << 16)) ? (w & 0x0000ffffu) : w;
-      const uint32_t flagged_w = (i < count_words) ? l_counts[i] : 0u;
-      if (!defer_all)
-      {
-        // Voxels which also receive samples keep their count for the ordered replay (k_apply_hits).
-        if ((flagged_w & kTileFlag) && (flagged_w & kTileCountMask))
+        const uint32_t c = (l_intervals[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
+        if (c)
         {
-          atomicAdd(&g_counts[2 * i], flagged_w & kTileCountMask);
-        }
-        if ((flagged_w & (kTileFlag << 16)) && ((flagged_w >> 16) & kTileCountMask))
-        {
-          atomicAdd(&g_counts[2 * i + 1], (flagged_w >> 16) & kTileCountMask);
-        }
-      }
-      words[j] = w;
-      values[j] = make_float2(0.0f, 0.0f);
-      if (w)
-      {
-        if (even_voxels)
-        {
-          values[j] = *reinterpret_cast<const float2 *>(&g_occ[2 * i]);
-        }
-        else
-        {
-          values[j].x = g_occ[2 * i];
-          values[j].y = (2 * i + 1 < uint32_t(mc.region_voxels)) ? g_occ[2 * i + 1] : 0.0f;
+          atomicAdd(&args.interval_counts[hb + i], c);
         }
       }
     }
-#pragma unroll
-    for (uint32_t j = 0; j < kWordsPerThread; ++j)
+    uint32_t *g_counts = args.miss_counts + size_t(chunk.slot) * size_t(mc.region_voxels);
+    if (args.occupancy && (chunk.hash_index & 0x80000000u))
     {
-      const uint32_t i = threadIdx.x + j * kWalkThreads;
-      const uint32_t w = words[j];
-      if (w)
+      // This chunk holds ALL of the region's segments for the batch: apply the miss counts to the log-odds layer
+      // straight from LDS (no count round trip through HBM).  Voxels which also receive samples keep their count for
+      // the ordered replay (occupancy: k_apply_hits; NDT: their visits are events, the tile entry is not used).
+      float *g_occ = args.occupancy + size_t(chunk.slot) * size_t(mc.region_voxels);
+      // Two passes so the loads of all the voxels a thread updates are in flight together (a load -> update -> store
+      // loop would pay the memory latency once per touched word, and nothing else runs on this CU to hide it).
+      constexpr uint32_t kWordsPerThread = (1u << kHitVoxelBits) / 2u / kWalkThreads;
+      uint32_t words[kWordsPerThread];
+      float2 values[kWordsPerThread];
+      const bool even_voxels = (mc.region_voxels & 1) == 0;
+  #pragma unroll
+      for (uint32_t j = 0; j < kWordsPerThread; ++j)
       {
-        const uint32_t n0 = w & kTileCountMask;
-        const uint32_t n1 = (w >> 16) & kTileCountMask;
-        if (n0)
+        const uint32_t i = threadIdx.x + j * kWalkThreads;
+        uint32_t w = (i < count_words) ? l_counts[i] : 0u;
+        // Keep only the entries applied here: unflagged voxels with a count.
+        w = (w & kTileFlag) ? (w & 0xffff0000u) : w;
+        w = (w & (kTileFlag << 16)) ? (w & 0x0000ffffu) : w;
+        const uint32_t flagged_w = (i < count_words) ? l_counts[i] : 0u;
+        if (!defer_all)
         {
-          g_occ[2 * i] = occMissN(mc, args.ray_flags, values[j].x, n0);
+          // Voxels which also receive samples keep their count for the ordered replay (k_apply_hits).
+          if ((flagged_w & kTileFlag) && (flagged_w & kTileCountMask))
+          {
+            atomicAdd(&g_counts[2 * i], flagged_w & kTileCountMask);
+          }
+          if ((flagged_w & (kTileFlag << 16)) && ((flagged_w >> 16) & kTileCountMask))
+          {
+            atomicAdd(&g_counts[2 * i + 1], (flagged_w >> 16) & kTileCountMask);
+          }
         }
-        if (n1)
+        words[j] = w;
+        values[j] = make_float2(0.0f, 0.0f);
+        if (w)
         {
-          g_occ[2 * i + 1] = occMissN(mc, args.ray_flags, values[j].y, n1);
+          if (even_voxels)
+          {
+            values[j] = *reinterpret_cast<const float2 *>(&g_occ[2 * i]);
+          }
+          else
+          {
+            values[j].x = g_occ[2 * i];
+            values[j].y = (2 * i + 1 < uint32_t(mc.region_voxels)) ? g_occ[2 * i + 1] : 0.0f;
+          }
+        }
+      }
+  #pragma unroll
+      for (uint32_t j = 0; j < kWordsPerThread; ++j)
+      {
+        const uint32_t i = threadIdx.x + j * kWalkThreads;
+        const uint32_t w = words[j];
+        if (w)
+        {
+          const uint32_t n0 = w & kTileCountMask;
+          const uint32_t n1 = (w >> 16) & kTileCountMask;
+          if (n0)
+          {
+            g_occ[2 * i] = occMissN(mc, args.ray_flags, values[j].x, n0);
+          }
+          if (n1)
+          {
+            g_occ[2 * i + 1] = occMissN(mc, args.ray_flags, values[j].y, n1);
+          }
+        }
+      }
+      if (stamp && chunk_index < kTraceChunks)
+      {
+        args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
+      }
+      __syncthreads();
+      chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
+      continue;
+    }
+    // Flush the tile: integer adds, so the merge across chunks of one region is order independent.  (NDT / TSDF:
+    // entries of masked voxels are skipped -- their visits travel as events.)
+    for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
+    {
+      const uint32_t w = l_counts[i];
+      if (w & (kTileCountMask | (kTileCountMask << 16)))
+      {
+  #pragma unroll
+        for (uint32_t half = 0; half < 2; ++half)
+        {
+          const uint32_t entry = (w >> (16u * half)) & 0xffffu;
+          const uint32_t n = entry & kTileCountMask;
+          if (n && !(defer_all && (entry & kTileFlag)))
+          {
+            atomicAdd(&g_counts[2 * i + half], n);
+          }
         }
       }
     }
@@ -1878,36 +1905,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     {
       args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
     }
+    // The tile is reused by the next trip: everyone must be done reading it.
     __syncthreads();
     chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
-    continue;
-  }
-  // Flush the tile: integer adds, so the merge across chunks of one region is order independent.  (NDT / TSDF:
-  // entries of masked voxels are skipped -- their visits travel as events.)
-  for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
-  {
-    const uint32_t w = l_counts[i];
-    if (w & (kTileCountMask | (kTileCountMask << 16)))
-    {
-#pragma unroll
-      for (uint32_t half = 0; half < 2; ++half)
-      {
-        const uint32_t entry = (w >> (16u * half)) & 0xffffu;
-        const uint32_t n = entry & kTileCountMask;
-        if (n && !(defer_all && (entry & kTileFlag)))
-        {
-          atomicAdd(&g_counts[2 * i + half], n);
-        }
-      }
-    }
-  }
-  if (stamp && chunk_index < kTraceChunks)
-  {
-    args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
-  }
-  // The tile is reused by the next trip: everyone must be done reading it.
-  __syncthreads();
-  chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
   }  // chunk loop
 }
 

@@ -112,7 +112,10 @@ struct ohmhip_map_s
   uint32_t event_demand = 0;
   double segments_per_ray = 10.0;            ///< running estimate (previous batch) used to size the next batch's chunks
   uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= kMaxChunkSegments (15-bit LDS counters)
-  unsigned debug_flags = 0;  ///< OHMHIP_DEBUG_FLAGS: timing experiments only (breaks results)
+  /// OHMHIP_DEBUG_FLAGS (development only): 16 = walk kernel refills lanes but does not walk (timing experiments,
+  /// breaks results); 64 = per-chunk timing trace of the walk kernel (OHMHIP_DEBUG_TRACE=<file>, scripts/
+  /// analyse_trace.py); 128 = iteration / visit / refill counters (hot-address atomics: distorts timing).
+  unsigned debug_flags = 0;
   int refill_min_idle = kRefillMinIdle;      ///< tunable (OHMHIP_REFILL_MIN_IDLE)  ///< events the previous batch produced (sizes the next batch's list)
   void *h_stage = nullptr;  ///< pinned staging for host rays / region copies
   size_t h_stage_bytes = 0;
@@ -585,7 +588,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       if (info.n_hit_regions)
       {
         hipLaunchKernelGGL(k_sort_region_hits, dim3(info.n_hit_regions), dim3(kSortThreads), 0, s, regionTable(m),
-                           batchScratch(m), keys_a, keys_b, m->mc.region_voxels, int(m->debug_flags >> 8));
+                           batchScratch(m), keys_a, keys_b, m->mc.region_voxels);
       }
     }
     else if (occupancy_mode)
