@@ -234,6 +234,19 @@ int ohmhip_map_clear(ohmhip_map_t map);
 int ohmhip_map_line_keys(ohmhip_map_t map, const double *lines, size_t line_count, uint32_t max_keys_per_line,
                          void *keys_out, uint32_t *counts_out);
 
+/* GpuTransformSamples::transform (ohmgpu/GpuTransformSamples.h:75-79, .cpp:97-210; kernel transformTimestampedPoints,
+ * ohmgpu/gpu/TransformSamples.cl:94-228): sensor-frame samples with time stamps + a timestamped trajectory (translations
+ * xyz, rotations as quaternions x,y,z,w) -> world-frame ray pairs (sensor origin, sample), 6 doubles per valid sample,
+ * compacted in input order into `output` (resized), ready for ohmhip_map_integrate_rays_device().  Same rules as the
+ * reference: samples with a NaN component or dot(s, s) > max_range are skipped; pose = lerp of the bracketing
+ * translations and rot[from] * slerp(rot[from], rot[to], f); fp64 throughout (the reference kernel is fp32).  Host
+ * pointers in; *ray_elements = 2 x valid samples (the reference's return value).  Synchronous on `stream` (NULL: the
+ * default stream). */
+int ohmhip_transform_samples(const double *transform_times, const double *transform_translations,
+                             const double *transform_rotations_xyzw, uint32_t transform_count,
+                             const double *sample_times, const double *local_samples, uint32_t point_count,
+                             double max_range, ohmhip_stream_t stream, ohmhip_buffer_t output, uint32_t *ray_elements);
+
 /* Multi-GPU merge support (no reference equivalent -- ohm is single device).  The resident layer of a
  * map is one allocation of region_stride_bytes per slot: ohm_amd/distributed.py wraps it as a device tensor and runs
  * the RCCL all-reduce of touched-region occupancy deltas on it.  ensure_regions makes regions resident (cleared)

@@ -398,6 +398,49 @@ class GpuTsdfMap(GpuMap):
         (cfg.tsdf_max_weight, cfg.tsdf_trunc, cfg.tsdf_dropoff, cfg.tsdf_sparsity) = self.tsdf_options
 
 
+class GpuTransformSamples:
+    """ohm::GpuTransformSamples (ohmgpu/GpuTransformSamples.h:30-83): local sensor samples + a timestamped trajectory ->
+    world-frame ray pairs in a device buffer that integrateRaysDevice() consumes directly."""
+
+    def __init__(self):
+        self._buffer = L._vp()
+        L.check(L.lib.ohmhip_buffer_create(C.byref(self._buffer), 48, 3), "buffer_create")
+
+    def close(self):
+        if self._buffer:
+            L.lib.ohmhip_buffer_destroy(self._buffer)
+            self._buffer = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transform(self, transform_times, transform_translations, transform_rotations_xyzw, sample_times, local_samples,
+                  max_range=float("inf")):
+        """Returns (device pointer, element_count): element_count = 2 x valid samples, as the reference returns."""
+        times = np.ascontiguousarray(transform_times, dtype=np.float64)
+        tr = np.ascontiguousarray(transform_translations, dtype=np.float64).reshape(-1, 3)
+        rot = np.ascontiguousarray(transform_rotations_xyzw, dtype=np.float64).reshape(-1, 4)
+        st = np.ascontiguousarray(sample_times, dtype=np.float64)
+        pts = np.ascontiguousarray(local_samples, dtype=np.float64).reshape(-1, 3)
+        count = C.c_uint32(0)
+        L.check(L.lib.ohmhip_transform_samples(times.ctypes.data, tr.ctypes.data, rot.ctypes.data, times.shape[0],
+                                               st.ctypes.data, pts.ctypes.data, pts.shape[0], float(max_range), None,
+                                               self._buffer, C.byref(count)), "transform_samples")
+        ptr = L._vp()
+        L.check(L.lib.ohmhip_buffer_ptr(self._buffer, C.byref(ptr)), "buffer_ptr")
+        return ptr, int(count.value)
+
+    def read(self, element_count):
+        """Copy the transformed rays back to the host ((element_count, 3) float64)."""
+        out = np.zeros((element_count, 3), dtype=np.float64)
+        if element_count:
+            L.check(L.lib.ohmhip_buffer_read(self._buffer, out.ctypes.data, out.nbytes, 0, None, None, None), "buffer_read")
+        return out
+
+
 def device_count():
     n = C.c_int(0)
     status = L.lib.ohmhip_device_count(C.byref(n))

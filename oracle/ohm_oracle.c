@@ -1509,3 +1509,148 @@ size_t oracle_integrate_tsdf(OracleMap *m, const double *rays, size_t element_co
   }
   return element_count / 2;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* GpuTransformSamples (sensor frame -> world frame), fp64 restatement of the reference kernel's arithmetic.            */
+/* ------------------------------------------------------------------------------------------------------------------ */
+typedef struct
+{
+  double x, y, z, w;
+} OQuat;
+
+/* ohmgpu/gpu/TransformSamples.cl:13-54 */
+static OQuat o_slerp(OQuat from, OQuat to, double f)
+{
+  if (from.x == to.x && from.y == to.y && from.z == to.z && from.w == to.w)
+  {
+    return from;
+  }
+  double cos_angle = ((from.x * to.x + from.y * to.y) + from.z * to.z) + from.w * to.w;
+  OQuat temp = to;
+  if (!(cos_angle >= 0))
+  {
+    temp.x = -1.0 * to.x;
+    temp.y = -1.0 * to.y;
+    temp.z = -1.0 * to.z;
+    temp.w = -1.0 * to.w;
+    cos_angle = -1.0 * cos_angle;
+  }
+  double coeff0, coeff1;
+  if (1.0 - cos_angle > 1e-12)
+  {
+    const double angle = acos(cos_angle);
+    const double inv_sin = 1.0 / sin(angle);
+    coeff0 = sin((1.0 - f) * angle) * inv_sin;
+    coeff1 = sin(f * angle) * inv_sin;
+  }
+  else
+  {
+    coeff0 = 1.0 - f;
+    coeff1 = f;
+  }
+  OQuat r;
+  r.x = coeff0 * from.x + coeff1 * temp.x;
+  r.y = coeff0 * from.y + coeff1 * temp.y;
+  r.z = coeff0 * from.z + coeff1 * temp.z;
+  r.w = coeff0 * from.w + coeff1 * temp.w;
+  return r;
+}
+
+/* ohmgpu/gpu/TransformSamples.cl:57-65 */
+static OQuat o_quat_mul(OQuat a, OQuat b)
+{
+  OQuat q;
+  q.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  q.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  q.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  q.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  return q;
+}
+
+unsigned oracle_transform_samples(const double *times, const double *translations, const double *rotations_xyzw,
+                                  unsigned transform_count, const double *sample_times, const double *local_samples,
+                                  unsigned point_count, double max_range, double *out)
+{
+  unsigned valid = 0;
+  if (point_count == 0 || transform_count == 0)
+  {
+    return 0;
+  }
+  for (unsigned i = 0; i < point_count; ++i)
+  {
+    const double vx = local_samples[3 * (size_t)i], vy = local_samples[3 * (size_t)i + 1];
+    const double vz = local_samples[3 * (size_t)i + 2];
+    /* goodSample, GpuTransformSamples.cpp:47-60: squared length against max_range itself */
+    if (vx != vx || vy != vy || vz != vz || ((vx * vx + vy * vy) + vz * vz) > max_range)
+    {
+      continue;
+    }
+    double sample_time = sample_times[i];
+    unsigned from = 0, to = transform_count - 1;
+    if (transform_count > 2)
+    {
+      if (times[0] <= sample_time && sample_time <= times[transform_count - 1])
+      {
+        unsigned iterations = 0;
+        while (from <= to && iterations < 100000u)
+        {
+          ++iterations;
+          const unsigned mid_low = (from + to) / 2;
+          const unsigned mid_high = (mid_low + 1 < transform_count - 1) ? mid_low + 1 : transform_count - 1;
+          if (sample_time >= times[mid_low] && sample_time <= times[mid_high])
+          {
+            from = mid_low;
+            to = mid_high;
+            break;
+          }
+          else if (sample_time <= times[mid_low])
+          {
+            to = mid_low - 1;
+          }
+          else
+          {
+            from = mid_low + 1;
+          }
+        }
+      }
+      else if (sample_time < times[0])
+      {
+        sample_time = times[0];
+        from = to = 0;
+      }
+      else
+      {
+        sample_time = times[transform_count - 1];
+        from = to = transform_count - 1;
+      }
+    }
+    const double span = times[to] - times[from];
+    const double f = (span != 0) ? (sample_time - times[from]) / span : 0.0;
+    double position[3];
+    for (int a = 0; a < 3; ++a)
+    {
+      position[a] = translations[3 * (size_t)from + a] + f * (translations[3 * (size_t)to + a] - translations[3 * (size_t)from + a]);
+    }
+    OQuat qf = { rotations_xyzw[4 * (size_t)from], rotations_xyzw[4 * (size_t)from + 1], rotations_xyzw[4 * (size_t)from + 2],
+                 rotations_xyzw[4 * (size_t)from + 3] };
+    OQuat qt = { rotations_xyzw[4 * (size_t)to], rotations_xyzw[4 * (size_t)to + 1], rotations_xyzw[4 * (size_t)to + 2],
+                 rotations_xyzw[4 * (size_t)to + 3] };
+    const OQuat q = o_quat_mul(qf, o_slerp(qf, qt, f));
+    /* ohmgpu/gpu/TransformSamples.cl:68-91 */
+    const double xx = q.x * q.x, xy = q.x * q.y, xz = q.x * q.z, xw = q.x * q.w;
+    const double yy = q.y * q.y, yz = q.y * q.z, yw = q.y * q.w;
+    const double zz = q.z * q.z, zw = q.z * q.w;
+    const double rx = (1 - 2 * (yy + zz)) * vx + (2 * (xy - zw)) * vy + (2 * (xz + yw)) * vz;
+    const double ry = (2 * (xy + zw)) * vx + (1 - 2 * (xx + zz)) * vy + (2 * (yz - xw)) * vz;
+    const double rz = (2 * (xz - yw)) * vx + (2 * (yz + xw)) * vy + (1 - 2 * (xx + yy)) * vz;
+    double *o = out + 6 * (size_t)valid;
+    o[0] = position[0];
+    o[1] = position[1];
+    o[2] = position[2];
+    o[3] = position[0] + rx;
+    o[4] = position[1] + ry;
+    o[5] = position[2] + rz;
+    ++valid;
+  }
+  return 2 * valid;
+}

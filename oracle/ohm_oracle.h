@@ -163,6 +163,12 @@ int oracle_calculate_hit_with_covariance(float cov[6], float *value, const doubl
 void oracle_calculate_miss_ndt(const float cov[6], float *value, int *is_miss, const double sensor[3],
                                const double sample[3], const double mean[3], unsigned point_count, float uninit,
                                float miss_value, float adaptation_rate, float sensor_noise, unsigned sample_threshold);
+/* GpuTransformSamples semantics in fp64 (ohmgpu/GpuTransformSamples.cpp:47-60, 131-142 sample filter + compaction;
+ * ohmgpu/gpu/TransformSamples.cl:13-228 bracketing search, lerp, rot[from] * slerp(rot[from], rot[to], f), rotate +
+ * translate).  out: 6 doubles per valid sample (sensor origin, sample).  Returns 2 x valid samples. */
+unsigned oracle_transform_samples(const double *transform_times, const double *translations, const double *rotations_xyzw,
+                                  unsigned transform_count, const double *sample_times, const double *local_samples,
+                                  unsigned point_count, double max_range, double *out);
 float oracle_probability_to_value(float p);
 float oracle_value_to_probability(float v);
 

@@ -87,6 +87,8 @@ lib.oracle_sub_voxel_coord.argtypes = [_dp, C.c_double]
 lib.oracle_sub_voxel_to_local.argtypes = [C.c_uint, C.c_double, _dp]
 lib.oracle_sub_voxel_update.restype = C.c_uint
 lib.oracle_sub_voxel_update.argtypes = [C.c_uint, C.c_uint, _dp, C.c_double]
+lib.oracle_transform_samples.restype = C.c_uint
+lib.oracle_transform_samples.argtypes = [_dp, _dp, _dp, C.c_uint, _dp, _dp, C.c_uint, C.c_double, _dp]
 lib.oracle_calculate_tsdf.restype = C.c_int
 lib.oracle_calculate_tsdf.argtypes = [_dp, _dp, _dp, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp]
 lib.oracle_calculate_hit_with_covariance.restype = C.c_int
@@ -207,3 +209,17 @@ class OracleMap:
     def chunks(self, names=None):
         names = names or self.layers
         return {tuple(int(v) for v in k): {n: self.region_layer(k, n) for n in names} for k in self.region_keys()}
+
+
+def transform_samples(times, translations, rotations_xyzw, sample_times, local_samples, max_range=float("inf")):
+    """GpuTransformSamples semantics on the CPU (fp64).  Returns the (2 * valid, 3) ray array."""
+    times = np.ascontiguousarray(times, dtype=np.float64)
+    tr = np.ascontiguousarray(translations, dtype=np.float64).reshape(-1, 3)
+    rot = np.ascontiguousarray(rotations_xyzw, dtype=np.float64).reshape(-1, 4)
+    st = np.ascontiguousarray(sample_times, dtype=np.float64)
+    pts = np.ascontiguousarray(local_samples, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((2 * pts.shape[0], 3), dtype=np.float64)
+    as_dp = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
+    n = lib.oracle_transform_samples(as_dp(times), as_dp(tr), as_dp(rot), times.shape[0], as_dp(st), as_dp(pts),
+                                     pts.shape[0], max_range, as_dp(out))
+    return out[:n]

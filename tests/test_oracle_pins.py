@@ -400,3 +400,42 @@ def test_voxel_mean_round_trip():
         O.lib.oracle_sub_voxel_to_local(pat, res, out)
         assert pat & (1 << 31)
         assert np.all(np.abs(np.array(out) - np.array(off)) <= res / 1023 + 1e-12)
+
+
+def test_transform_samples_round_trip():
+    # tests/ohmtestgpu/GpuTests.cpp:32-228 (the CPU half of the reference's own test): samples moved into a moving
+    # sensor frame with pose = lerp(translation), rot[from] * slerp(rot[from], rot[to], f) and transformed back by the
+    # function under test must land on the original points to 1e-7.
+    from ohm_amd import synth
+    n = 5000
+    idx = np.arange(n)
+    global_pts = np.stack([(synth.uniform01(9, idx, s) - 0.5) * 30.0 for s in range(3)], axis=1)
+    count = 10
+    base, dt = 1.7e9, 1e-3
+    times = base + (n * dt + 1.5 * dt) * np.arange(count) / (count - 1)
+    translations = np.array([-0.42] * 3) + (np.arange(count) / (count - 1))[:, None] * 10.42
+    angles = np.pi * np.arange(count) / (count - 1)
+    rotations = np.stack([np.zeros(count), np.zeros(count), np.sin(angles / 2), np.cos(angles / 2)], axis=1)
+    sample_times = base + 0.67 * dt + dt * idx
+    local = np.zeros_like(global_pts)
+    tidx = 0
+    for i in range(n):
+        while times[tidx + 1] < sample_times[i]:
+            tidx += 1
+        f = (sample_times[i] - times[tidx]) / (times[tidx + 1] - times[tidx])
+        pos = translations[tidx] + f * (translations[tidx + 1] - translations[tidx])
+        ang = angles[tidx] + (angles[tidx] + f * (angles[tidx + 1] - angles[tidx]))
+        c, s = np.cos(-ang), np.sin(-ang)
+        d = global_pts[i] - pos
+        local[i] = [c * d[0] - s * d[1], s * d[0] + c * d[1], d[2]]
+    rays = O.transform_samples(times, translations, rotations, sample_times, local)
+    assert rays.shape == (2 * n, 3)
+    assert np.max(np.linalg.norm(rays[1::2] - global_pts, axis=1)) < 1e-7
+    # rejected samples are skipped, order kept (GpuTransformSamples.cpp:131-142)
+    local[3, 0] = np.nan
+    local[7] = [100.0, 0.0, 0.0]
+    rays2 = O.transform_samples(times, translations, rotations, sample_times, local, max_range=50.0 * 50.0)
+    assert rays2.shape == (2 * (n - 2), 3)
+    keep = np.ones(n, dtype=bool)
+    keep[[3, 7]] = False
+    assert np.array_equal(rays2[1::2], rays[1::2][keep])
