@@ -1322,6 +1322,7 @@ struct WalkArgs
   unsigned ray_flags;
   unsigned long long *dbg_counters;
   float *traversal;  ///< kTraversal instantiations: per-visit ray length accumulation (global float atomics)
+  float *tsdf;       ///< non-null (TSDF mode): single-chunk regions are applied straight from LDS
   uint32_t *chunk_cursor;  ///< device-wide next-chunk cursor (zeroed before the launch)
   uint32_t n_chunks;
 };
@@ -1397,7 +1398,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
     constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
     uint32_t lens[kSegPerThread];
-  #pragma unroll
+#pragma unroll
     for (int j = 0; j < kSegPerThread; ++j)
     {
       const uint32_t i = min(threadIdx.x + uint32_t(j) * kWalkThreads, n_seg - 1u);
@@ -1412,7 +1413,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     unsigned long long my_hits[kHitsPerThread];
     if (lds_resolve && n_region_hits)
     {
-  #pragma unroll
+#pragma unroll
       for (int j = 0; j < kHitsPerThread; ++j)
       {
         my_hits[j] = args.sorted_hits[hb + min(threadIdx.x + uint32_t(j) * kWalkThreads, n_region_hits - 1u)];
@@ -1436,11 +1437,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     for (uint32_t w = threadIdx.x; w < mask_words; w += kWalkThreads)
     {
       const uint32_t mword = (w == threadIdx.x) ? my_mask : g_mask[w];
-  #pragma unroll
+#pragma unroll
       for (uint32_t q = 0; q < 4; ++q)
       {
         uint32_t v[4];
-  #pragma unroll
+#pragma unroll
         for (uint32_t r = 0; r < 4; ++r)
         {
           const uint32_t two = (mword >> ((q * 4u + r) * 2u)) & 3u;
@@ -1474,7 +1475,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // Longest segments first (counting sort on the voxel count, indices in LDS): lanes refilled together get segments
     // of similar length and so retire together, and the workgroup drains on its SHORTEST segments instead of waiting
     // for a few long stragglers.  The order inside a length class is arbitrary; integer counting does not care.
-  #pragma unroll
+#pragma unroll
     for (int j = 0; j < kSegPerThread; ++j)
     {
       if (threadIdx.x + uint32_t(j) * kWalkThreads < n_seg)
@@ -1484,7 +1485,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     }
     if (lds_resolve && n_region_hits)
     {
-  #pragma unroll
+#pragma unroll
       for (int j = 0; j < kHitsPerThread; ++j)
       {
         const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
@@ -1510,7 +1511,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       const uint32_t a = l_hist[hi_class];
       const uint32_t b = l_hist[hi_class - 1u];
       uint32_t incl = a + b;
-  #pragma unroll
+#pragma unroll
       for (int d = 1; d < 64; d <<= 1)
       {
         const uint32_t up = __shfl_up(incl, d);
@@ -1521,7 +1522,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       l_hist[hi_class - 1u] = excl + a;
     }
     __syncthreads();
-  #pragma unroll
+#pragma unroll
     for (int j = 0; j < kSegPerThread; ++j)
     {
       const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
@@ -1819,7 +1820,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       uint32_t words[kWordsPerThread];
       float2 values[kWordsPerThread];
       const bool even_voxels = (mc.region_voxels & 1) == 0;
-  #pragma unroll
+#pragma unroll
       for (uint32_t j = 0; j < kWordsPerThread; ++j)
       {
         const uint32_t i = threadIdx.x + j * kWalkThreads;
@@ -1855,7 +1856,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           }
         }
       }
-  #pragma unroll
+#pragma unroll
       for (uint32_t j = 0; j < kWordsPerThread; ++j)
       {
         const uint32_t i = threadIdx.x + j * kWalkThreads;
@@ -1882,6 +1883,62 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
       continue;
     }
+    if (args.tsdf && (chunk.hash_index & 0x80000000u))
+    {
+      // TSDF, region held by this one chunk: voxels that only saw free-space visits (count n, not flagged) end at
+      // weight = min(weight + n, max_weight), distance = truncation distance (see k_apply_counts_tsdf) -- applied here
+      // straight from LDS; flagged voxels are replayed from their events.
+      float2 *g_tsdf = reinterpret_cast<float2 *>(args.tsdf) + size_t(chunk.slot) * size_t(mc.region_voxels);
+      constexpr uint32_t kTsdfBatch = 4;
+      for (uint32_t first = threadIdx.x; first < count_words; first += kTsdfBatch * kWalkThreads)
+      {
+        uint32_t words[kTsdfBatch];
+        float2 values[2 * kTsdfBatch];
+#pragma unroll
+        for (uint32_t j = 0; j < kTsdfBatch; ++j)
+        {
+          const uint32_t i = first + j * kWalkThreads;
+          uint32_t w = (i < count_words) ? l_counts[i] : 0u;
+          w = (w & kTileFlag) ? (w & 0xffff0000u) : w;
+          w = (w & (kTileFlag << 16)) ? (w & 0x0000ffffu) : w;
+          words[j] = w;
+          values[2 * j] = make_float2(0.0f, 0.0f);
+          values[2 * j + 1] = make_float2(0.0f, 0.0f);
+          if (w & kTileCountMask)
+          {
+            values[2 * j] = g_tsdf[2 * i];
+          }
+          if ((w >> 16) & kTileCountMask)
+          {
+            values[2 * j + 1] = g_tsdf[2 * i + 1];
+          }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kTsdfBatch; ++j)
+        {
+          const uint32_t i = first + j * kWalkThreads;
+          const uint32_t n0 = words[j] & kTileCountMask;
+          const uint32_t n1 = (words[j] >> 16) & kTileCountMask;
+          if (n0)
+          {
+            const float wn = values[2 * j].x + float(n0);
+            g_tsdf[2 * i] = make_float2((mc.tsdf_max_weight < wn) ? mc.tsdf_max_weight : wn, mc.tsdf_trunc);
+          }
+          if (n1)
+          {
+            const float wn = values[2 * j + 1].x + float(n1);
+            g_tsdf[2 * i + 1] = make_float2((mc.tsdf_max_weight < wn) ? mc.tsdf_max_weight : wn, mc.tsdf_trunc);
+          }
+        }
+      }
+      if (stamp && chunk_index < kTraceChunks)
+      {
+        args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
+      }
+      __syncthreads();
+      chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
+      continue;
+    }
     // Flush the tile: integer adds, so the merge across chunks of one region is order independent.  (NDT / TSDF:
     // entries of masked voxels are skipped -- their visits travel as events.)
     for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
@@ -1889,7 +1946,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       const uint32_t w = l_counts[i];
       if (w & (kTileCountMask | (kTileCountMask << 16)))
       {
-  #pragma unroll
+#pragma unroll
         for (uint32_t half = 0; half < 2; ++half)
         {
           const uint32_t entry = (w >> (16u * half)) & 0xffffu;

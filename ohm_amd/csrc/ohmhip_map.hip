@@ -606,7 +606,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     float *direct_occ = (occupancy_mode || mode == OHMHIP_MODE_NDT_OM) ?
                           static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]) :
                           nullptr;
-    const uint32_t direct_segments = direct_occ ? batch_chunk_segments : 0u;
+    const uint32_t direct_segments = (direct_occ || tsdf_mode) ? batch_chunk_segments : 0u;
     uint32_t n_events = 0;
     if (info.n_chunks)
     {
@@ -631,6 +631,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.ray_shift = ray_shift;
         wa.defer_all = occupancy_mode ? 0 : 1;
         wa.occupancy = direct_occ;
+        wa.tsdf = tsdf_mode ? static_cast<float *>(m->layers[OHMHIP_LID_TSDF]) : nullptr;
         wa.ray_flags = ray_flags;
         wa.dbg_counters = (m->debug_flags & 64u) ? m->d_dbg : nullptr;
         wa.traversal = sec.traversal;
@@ -767,7 +768,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         {
           hipLaunchKernelGGL(k_apply_counts_tsdf, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
                              batchScratch(m), m->d_miss_counts, m->d_hit_mask,
-                             static_cast<float *>(m->layers[OHMHIP_LID_TSDF]));
+                             static_cast<float *>(m->layers[OHMHIP_LID_TSDF]), direct_segments);
         }
       }
     }

@@ -278,13 +278,17 @@ __global__ void __launch_bounds__(128)
 /// distance -- the fixed point of calculateTsdf for sdf >= truncation distance.
 __global__ void __launch_bounds__(256)
   k_apply_counts_tsdf(MapConst mc, RegionTable rt, BatchScratch bs, uint32_t *__restrict__ miss_counts,
-                      const uint32_t *__restrict__ hit_mask, float *__restrict__ tsdf_layer)
+                      const uint32_t *__restrict__ hit_mask, float *__restrict__ tsdf_layer,
+                      uint32_t direct_chunk_segments)
 {
   const uint32_t h = bs.touched[blockIdx.x];
   const uint32_t slot = rt.vals[h];
   const size_t base = size_t(slot) * size_t(mc.region_voxels);
   const uint32_t *mask = hit_mask + size_t(slot) * (uint32_t(mc.region_voxels + 31) >> 5);
-  for (uint32_t vi = threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
+  // Regions with a single chunk were applied by the walk kernel itself (direct_chunk_segments != 0): only the
+  // bookkeeping below is left.
+  const bool applied_by_walk = direct_chunk_segments && bs.seg_count[h] > 0 && bs.seg_count[h] <= direct_chunk_segments;
+  for (uint32_t vi = threadIdx.x; !applied_by_walk && vi < uint32_t(mc.region_voxels); vi += blockDim.x)
   {
     uint32_t n = miss_counts[base + vi];
     if (n && ((mask[vi >> 5] >> (vi & 31)) & 1u))
@@ -302,6 +306,7 @@ __global__ void __launch_bounds__(256)
       miss_counts[base + vi] = 0;
     }
   }
+  __syncthreads();  // every thread has read seg_count
   if (threadIdx.x == 0)
   {
     bs.seg_count[h] = 0;
