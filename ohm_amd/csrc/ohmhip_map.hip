@@ -637,9 +637,11 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.traversal = sec.traversal;
         wa.chunk_cursor = m->d_event_count + 1;
         wa.n_chunks = info.n_chunks;
-        // The lean instantiation applies unless some ray's end voxel is part of its walk or origins are excluded.
-        const bool special = (ray_flags & (OHMHIP_RF_END_POINT_AS_FREE | OHMHIP_RF_EXCLUDE_ORIGIN)) ||
-                             m->mc.filter_mode == OHMHIP_FILTER_CLIP;
+        // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited) or the
+        // traversal layer needs the exit range of an end voxel that is part of the walk.  (An end voxel that is walked --
+        // kRfEndPointAsFree, clipped rays, TSDF -- is simply one more voxel of the ray's last segment.)
+        const bool end_walked = (ray_flags & OHMHIP_RF_END_POINT_AS_FREE) || m->mc.filter_mode == OHMHIP_FILTER_CLIP;
+        const bool special = (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) || (sec.traversal && end_walked);
         const dim3 wgrid(std::min<uint32_t>(info.n_chunks, m->walk_workgroups)), wblock(kWalkThreads);
         const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments);
         if (special && sec.traversal)
