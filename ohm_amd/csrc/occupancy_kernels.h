@@ -1299,6 +1299,31 @@ __device__ inline void flushQueue(const uint2 *queue, uint32_t qcount, unsigned 
   }
 }
 
+// Explicit lane-mask selects for the walk step (see k_region_walk): `mask` is a wave-wide 64-bit lane mask in SGPRs.
+constexpr int kFcmpOlt = 4;   ///< llvm::CmpInst::FCMP_OLT
+constexpr int kIcmpSlt = 40;  ///< llvm::CmpInst::ICMP_SLT
+
+__device__ inline int selectI(unsigned long long mask, int if_set, int if_clear)
+{
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return r;
+}
+
+__device__ inline double selectD(unsigned long long mask, double if_set, double if_clear)
+{
+  const int lo = selectI(mask, __double2loint(if_set), __double2loint(if_clear));
+  const int hi = selectI(mask, __double2hiint(if_set), __double2hiint(if_clear));
+  return __hiloint2double(hi, lo);
+}
+
+/// value + (lane's mask bit): one add-with-carry-in.
+__device__ inline int addMask(int value, unsigned long long mask)
+{
+  asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(value) : "s"(mask) : "vcc");
+  return value;
+}
+
 /// Kernel parameters of k_region_walk (one struct keeps the template instantiations readable).
 struct WalkArgs
 {
@@ -1697,23 +1722,28 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       // ---- segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the
       // ---- higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
       {
-        const bool c01 = t0 < t1;
-        const double t01 = c01 ? t0 : t1;
-        const bool c2 = t01 < t2;
-        const bool a0 = c2 && c01;
-        const bool a1 = c2 && !c01;
-        const bool a2 = !c2;
-        k0 += int(a0);
-        k1 += int(a1);
-        k2 += int(a2);
-        const double n0 = (k0 < tot0) ? i0 + e0 * double(k0) : inf;
-        const double n1 = (k1 < tot1) ? i1 + e1 * double(k1) : inf;
-        const double n2 = (k2 < tot2) ? i2 + e2 * double(k2) : inf;
-        t0 = a0 ? n0 : t0;
-        t1 = a1 ? n1 : t1;
-        t2 = a2 ? n2 : t2;
-        int stride = a0 ? sx : sy;
-        stride = a2 ? sz : stride;
+        // Lane masks and selects are spelled out (compare builtins + v_cndmask / v_addc on the 64-bit masks): left to
+        // itself the compiler evaluates each fp64 compare twice (a < b and !(a < b) are different predicates under
+        // NaN rules) and turns every `k += predicate` into a select plus an add.
+        const unsigned long long m01 = __builtin_amdgcn_fcmp(t0, t1, kFcmpOlt);
+        const double t01 = selectD(m01, t0, t1);
+        const unsigned long long m2 = __builtin_amdgcn_fcmp(t01, t2, kFcmpOlt);
+        const unsigned long long a0 = m2 & m01;
+        const unsigned long long a1 = m2 & ~m01;
+        const unsigned long long a2 = ~m2;
+        k0 = addMask(k0, a0);
+        k1 = addMask(k1, a1);
+        k2 = addMask(k2, a2);
+        const unsigned long long f0 = __builtin_amdgcn_sicmp(k0, tot0, kIcmpSlt);
+        const unsigned long long f1 = __builtin_amdgcn_sicmp(k1, tot1, kIcmpSlt);
+        const unsigned long long f2 = __builtin_amdgcn_sicmp(k2, tot2, kIcmpSlt);
+        const double n0 = selectD(f0, i0 + e0 * double(k0), inf);
+        const double n1 = selectD(f1, i1 + e1 * double(k1), inf);
+        const double n2 = selectD(f2, i2 + e2 * double(k2), inf);
+        t0 = selectD(a0, n0, t0);
+        t1 = selectD(a1, n1, t1);
+        t2 = selectD(a2, n2, t2);
+        const int stride = selectI(a2, sz, selectI(a0, sx, sy));
         vi += uint32_t(stride);
         left -= 1;
       }
