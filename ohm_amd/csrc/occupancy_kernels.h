@@ -783,12 +783,13 @@ __global__ void __launch_bounds__(1024)
   }
   __syncthreads();
   const uint32_t n_big = min(s_big_n, kBigQueue);
-  for (uint32_t q = 0; q < n_big; ++q)
+  // One wave per queued region, one lane per chunk.
+  for (uint32_t q = tid >> 6; q < n_big; q += 16)
   {
     const uint32_t cnt = s_big[q][3];
     const uint32_t nchk = (cnt + chunk_segments - 1) / chunk_segments;
     const uint32_t per = (cnt + nchk - 1) / nchk;
-    for (uint32_t c = tid; c < nchk; c += 1024)
+    for (uint32_t c = tid & 63u; c < nchk; c += 64)
     {
       emit(s_big[q][0], s_big[q][1], s_big[q][2], cnt, nchk, per, c);
     }
