@@ -841,7 +841,11 @@ __global__ void __launch_bounds__(kBinThreads)
     }
     if (bucket_hits && wr.hits)
     {
-      tab.count[wr.entry] = atomicAdd(&bs.hit_end[rt.vals[wr.hash]], wr.hits);
+      const uint32_t slot = rt.vals[wr.hash];
+      if (slot < rt.slot_capacity)  // (a speculatively launched pass may see a batch whose slots ran out)
+      {
+        tab.count[wr.entry] = atomicAdd(&bs.hit_end[slot], wr.hits);
+      }
     }
   }
   __syncthreads();
@@ -1039,17 +1043,21 @@ __global__ void __launch_bounds__(kSortThreads)
                      unsigned long long *__restrict__ sorted, int region_voxels)
 {
   __shared__ unsigned long long l_keys[kSortRegionHits + kSortRegionHits / 32];
-  const uint32_t h = bs.sort_list[blockIdx.x];
+  // Grid-stride over the list (its length lives on the device: the launch may be issued before the host knows it).
+  const uint32_t n_regions = bs.info->n_hit_regions;
+  for (uint32_t list_index = blockIdx.x; list_index < n_regions; list_index += gridDim.x)
+  {
+  const uint32_t h = bs.sort_list[list_index];
   const uint32_t slot = rt.vals[h];
   if (slot >= rt.slot_capacity)
   {
-    return;
+    continue;
   }
   const uint32_t begin = bs.hit_begin[slot];
   const uint32_t n = bs.hit_end[slot] - begin;
   if (n == 0 || n > kSortRegionHits)
   {
-    return;
+    continue;
   }
   uint32_t padded = 64;
   while (padded < n)
@@ -1103,6 +1111,26 @@ __global__ void __launch_bounds__(kSortThreads)
       const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
       bs.voxel_first_hit[size_t(slot) * size_t(region_voxels) + vi] = begin + i;
     }
+  }
+  __syncthreads();  // l_keys is reused by the next region
+  }  // regions
+}
+
+/// Undo the cursor movement of a k_ray_bin pass over the touched regions (segment cursors back to zero, sample cursors
+/// back to the start of the region's range) so the pass can be repeated with other launch parameters.
+__global__ void __launch_bounds__(256) k_reset_cursors(RegionTable rt, BatchScratch bs)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs.info->n_touched)
+  {
+    return;
+  }
+  const uint32_t h = bs.touched[i];
+  bs.seg_cursor[h] = 0;
+  const uint32_t slot = rt.vals[h];
+  if (slot < rt.slot_capacity)
+  {
+    bs.hit_end[slot] = bs.hit_begin[slot];
   }
 }
 

@@ -110,6 +110,7 @@ struct ohmhip_map_s
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
   uint32_t event_demand = 0;
+  bool spec_bucket_ok = false;  ///< the previous occupancy batch used the per-region sample sort: bin speculatively
   double segments_per_ray = 10.0;            ///< running estimate (previous batch) used to size the next batch's chunks
   uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= kMaxChunkSegments (15-bit LDS counters)
   /// OHMHIP_DEBUG_FLAGS (development only): 16 = walk kernel refills lanes but does not walk (timing experiments,
@@ -521,13 +522,39 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
                        m->chunk_capacity, batch_chunk_segments);
     OHMHIP_CHECK(hipMemcpyAsync(m->h_info, m->d_info, sizeof(BatchInfo), hipMemcpyDeviceToHost, s));
-    OHMHIP_CHECK(hipStreamSynchronize(s));
+    OHMHIP_CHECK(hipEventRecord(m->ev[7], s));
+    // The host needs the batch summary (segment count, sample distribution, pool state) before it can size and launch
+    // the rest -- a round trip during which the device would idle.  In steady state (occupancy, previous batch sorted
+    // its samples per region) the binning and the sample sort are launched right away with the buffers of the previous
+    // batch; the summary then only confirms the guess, and a wrong guess costs a repeat of the two passes.
+    auto launchBin = [&](bool bucket, uint32_t seg_capacity, unsigned long long *hit_keys) {
+      hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m),
+                         static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
+                         seg_capacity, hit_keys, m->d_hit_mask, ray_shift, bucket ? 1 : 0, bin_rays_per_block);
+    };
+    auto launchRegionSort = [&]() {
+      hipLaunchKernelGGL(k_sort_region_hits, dim3(4 * m->walk_workgroups), dim3(kSortThreads), 0, s, regionTable(m),
+                         batchScratch(m), static_cast<const unsigned long long *>(m->hit_keys_a.ptr),
+                         static_cast<unsigned long long *>(m->hit_keys_b.ptr), m->mc.region_voxels);
+    };
+    const uint32_t spec_seg_cap = uint32_t(std::min<size_t>(m->segments.bytes / sizeof(Segment), 0xffffffffu));
+    bool speculated = occupancy_mode && m->spec_bucket_ok && attempt == 0 && spec_seg_cap > 0;
+    if (speculated)
+    {
+      launchBin(true, spec_seg_cap, static_cast<unsigned long long *>(m->hit_keys_a.ptr));
+      OHMHIP_CHECK(hipEventRecord(tev[1], s));
+      launchRegionSort();
+      OHMHIP_CHECK(hipEventRecord(tev[2], s));
+    }
+    OHMHIP_CHECK(hipEventSynchronize(m->ev[7]));
     OHMHIP_CHECK(hipGetLastError());
     const BatchInfo info = *m->h_info;
     if ((info.error & (kErrSlotsFull | kErrHashFull)) || info.n_slots > m->slot_capacity ||
         info.n_chunks > m->chunk_capacity)
     {
       // Pool exhausted: forget what this batch inserted, grow, retry.
+      OHMHIP_CHECK(hipStreamSynchronize(s));
+      m->spec_bucket_ok = false;
       const int err = rollbackAndGrow(m, std::max(info.n_slots, m->slot_capacity * 2u));
       if (err)
       {
@@ -537,6 +564,18 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     }
 
     m->slots_committed = info.n_slots;
+    if (speculated && (info.n_segments > spec_seg_cap || info.max_region_hits > kSortRegionHits))
+    {
+      // Wrong guess (segment buffer too small, or a region too dense for the per-region sort): wait for the two
+      // passes, put their cursors back and fall through to the regular launches.
+      OHMHIP_CHECK(hipStreamSynchronize(s));
+      if (info.n_touched)
+      {
+        hipLaunchKernelGGL(k_reset_cursors, dim3((info.n_touched + 255) / 256), dim3(256), 0, s, regionTable(m),
+                           batchScratch(m));
+      }
+      speculated = false;
+    }
     OHMHIP_CHECK(m->segments.ensure(sizeof(Segment) * size_t(std::max<uint32_t>(info.n_segments, 1u)), false, s));
     const uint32_t seg_cap = uint32_t(std::min<size_t>(m->segments.bytes / sizeof(Segment), 0xffffffffu));
 
@@ -573,34 +612,36 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     // Occupancy: sample keys are bucketed per region and ordered by one workgroup per region in LDS, unless some
     // region holds more samples than that kernel's LDS takes (then: ray-order keys + device-wide radix sort).
     const bool bucket_hits = occupancy_mode && info.max_region_hits <= kSortRegionHits;
-    hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m),
-                       static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
-                       seg_cap, keys_a, m->d_hit_mask, ray_shift, bucket_hits ? 1 : 0, bin_rays_per_block);
-    if (tsdf_mode)
-    {
-      hipLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
-                         static_cast<const RayWalk *>(m->walks.ptr), d_rays, n_rays, m->d_hit_mask);
-    }
-    OHMHIP_CHECK(hipEventRecord(tev[1], s));
+    m->spec_bucket_ok = bucket_hits;
     const unsigned long long *sorted = keys_b;
-    if (bucket_hits)
+    if (!speculated)
     {
-      if (info.n_hit_regions)
+      launchBin(bucket_hits, seg_cap, keys_a);
+      if (tsdf_mode)
       {
-        hipLaunchKernelGGL(k_sort_region_hits, dim3(info.n_hit_regions), dim3(kSortThreads), 0, s, regionTable(m),
-                           batchScratch(m), keys_a, keys_b, m->mc.region_voxels);
+        hipLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
+                           static_cast<const RayWalk *>(m->walks.ptr), d_rays, n_rays, m->d_hit_mask);
       }
+      OHMHIP_CHECK(hipEventRecord(tev[1], s));
+      if (bucket_hits)
+      {
+        if (info.n_hit_regions)
+        {
+          launchRegionSort();
+        }
+      }
+      else if (occupancy_mode)
+      {
+        size_t temp_bytes = m->sort_temp.bytes;
+        // Sample keys are emitted in ray order and the radix sort is stable: sorting on the (slot, voxel) bits alone
+        // leaves each voxel's samples in ray order.
+        OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays),
+                                                          kHitRayBits, sortEndBit(m), s));
+        hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m),
+                           m->mc.region_voxels);
+      }
+      OHMHIP_CHECK(hipEventRecord(tev[2], s));
     }
-    else if (occupancy_mode)
-    {
-      size_t temp_bytes = m->sort_temp.bytes;
-      // Sample keys are emitted in ray order and the radix sort is stable: sorting on the (slot, voxel) bits alone
-      // leaves each voxel's samples in ray order.
-      OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays), kHitRayBits,
-                                            sortEndBit(m), s));
-      hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m), m->mc.region_voxels);
-    }
-    OHMHIP_CHECK(hipEventRecord(tev[2], s));
 
     // Single-chunk regions are applied by the walk kernel straight from LDS (plain log-odds misses only).
     float *direct_occ = (occupancy_mode || mode == OHMHIP_MODE_NDT_OM) ?

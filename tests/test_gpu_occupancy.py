@@ -136,3 +136,28 @@ def test_dense_region_samples_fall_back_to_device_sort(gpu):
     stats, gm, om, total = run_case(rays, layers=("occupancy", "mean"))
     assert total == 4 * n
     assert_parity(stats)
+
+
+def test_speculative_binning_recovers_from_wrong_guesses(gpu):
+    # In steady state the binning / sample-sort passes of a batch are launched before the host has read the batch
+    # summary, with the previous batch's buffers and sorting mode.  Batches that break the guess -- many more
+    # ray-region segments than the segment buffer holds, then a region too dense for the per-region sort, then small
+    # again -- must give the same bit-exact result.
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    small = synth.random_rays(1500, extent=4.0, seed=21)
+    large = synth.rays_c1(n=120000, max_range=20.0)
+    n = 11000
+    i = np.arange(n)
+    ends = np.stack([2.0 + 0.9 * synth.uniform01(78, i, 1), 0.9 * synth.uniform01(78, i, 2) - 0.45,
+                     0.9 * synth.uniform01(78, i, 3) - 0.45], axis=1)
+    dense = np.empty((2 * n, 3), dtype=np.float64)
+    dense[0::2] = 0.0
+    dense[1::2] = ends
+    for batch in (small, small, large, large, dense, small, large):
+        gm.integrateRays(batch)
+        om.integrate_occupancy(batch)
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
+    assert_parity(stats)
