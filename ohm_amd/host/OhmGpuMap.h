@@ -227,6 +227,24 @@ public:
     return integrateRays(reinterpret_cast<const dvec3 *>(rays), element_count, intensities, timestamps,
                          ray_update_flags);
   }
+  /// Rays already resident in device memory (e.g. the output buffer of GpuTransformSamples::transform): the same
+  /// integration without the host-to-device staging.
+  size_t integrateRays(const gputil::Buffer &device_rays, size_t element_count, unsigned ray_update_flags = kRfDefault)
+  {
+    if (!gpuOk() || !device_rays.isValid() || element_count < 2)
+    {
+      return 0;
+    }
+    void *ptr = nullptr;
+    size_t integrated = 0;
+    last_status_ = ohmhip_buffer_ptr(device_rays.handle(), &ptr);
+    if (last_status_ == OHMHIP_OK)
+    {
+      last_status_ = ohmhip_map_integrate_rays_device(handle_, static_cast<const double *>(ptr), element_count, nullptr,
+                                                      nullptr, ray_update_flags, &integrated);
+    }
+    return (last_status_ == OHMHIP_OK) ? integrated : 0;
+  }
   int lastStatus() const { return last_status_; }
 
   /// ohmgpu/GpuMap.cpp:308-324 -> GpuLayerCache::syncToMainMemory: fence, then copy regions modified on the device
@@ -453,6 +471,45 @@ private:
     cfg.tsdf_sparsity = o.sparsity_compensation_factor;
   }
   TsdfOptions options_;
+};
+
+/// Quaternion in (x, y, z, w) member order (glm::dquat exposes the same members; its memory order depends on the glm
+/// version, ohmgpu/GpuTransformSamples.cpp:169-174).
+struct dquat
+{
+  double x, y, z, w;
+};
+
+/// ohm::GpuTransformSamples (ohmgpu/GpuTransformSamples.h:30-83): sensor-frame samples + timestamped trajectory ->
+/// world-frame ray pairs in a device buffer.  fp64 on the device (the reference kernel is fp32).
+class GpuTransformSamples
+{
+public:
+  explicit GpuTransformSamples(gputil::Device &) {}
+  GpuTransformSamples() = default;
+
+  /// @return 2 x the number of valid samples written to @p output_buffer (as the reference), 0 on failure.
+  unsigned transform(const double *transform_times, const dvec3 *transform_translations, const dquat *transform_rotations,
+                     unsigned transform_count, const double *sample_times, const dvec3 *local_samples,
+                     unsigned point_count, gputil::Queue &gpu_queue, gputil::Buffer &output_buffer,
+                     double max_range = INFINITY)
+  {
+    if (!output_buffer.isValid())
+    {
+      output_buffer.create(sizeof(double) * 6 * (point_count ? point_count : 1u));
+    }
+    uint32_t elements = 0;
+    last_status_ = ohmhip_transform_samples(
+      transform_times, reinterpret_cast<const double *>(transform_translations),
+      reinterpret_cast<const double *>(transform_rotations), transform_count, sample_times,
+      reinterpret_cast<const double *>(local_samples), point_count, max_range, gpu_queue.handle(),
+      output_buffer.handle(), &elements);
+    return (last_status_ == OHMHIP_OK) ? elements : 0u;
+  }
+  int lastStatus() const { return last_status_; }
+
+private:
+  int last_status_ = OHMHIP_OK;
 };
 
 /// ohm::configureGpu / gpuDevice (ohmgpu/OhmGpu.h:40-66): select the process-wide device.

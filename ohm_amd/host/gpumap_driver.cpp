@@ -3,7 +3,9 @@
 // (tests/ohmtestgpu/GpuMapTest.cpp:68-205), syncs, and dumps every region layer for the Python parity test to check
 // against the CPU oracle.  Links libohmhip.so only; built with plain g++ (no hipcc, no glm).
 //
-//   gpumap_driver <mode: occ|occmean|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>
+//   gpumap_driver <mode: occ|occmean|occdev|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>
+//   occdev: the sample points (odd entries) go through ohm::GpuTransformSamples with a static identity trajectory and
+//   are integrated straight from the device buffer (all rays then start at the origin).
 //   rays.bin: u64 n_points, then n_points * 3 doubles.  out.bin: u64 regions, per region i16[3] key, then per enabled
 //   layer (ascending id): u32 layer id, u64 bytes, payload.
 #include "OhmGpuMap.h"
@@ -49,7 +51,7 @@ int main(int argc, char **argv)
 
     ohm::OccupancyMap map(resolution);
     std::unique_ptr<ohm::GpuMap> gpu_map;
-    if (mode == "occ" || mode == "occmean")
+    if (mode == "occ" || mode == "occmean" || mode == "occdev")
     {
       if (mode == "occmean")
       {
@@ -75,10 +77,39 @@ int main(int argc, char **argv)
     }
     const size_t batch_points = batch_rays ? batch_rays * 2 : size_t(n_points);
     size_t total = 0;
-    for (size_t i = 0; i < n_points; i += batch_points)
+    if (mode == "occdev")
     {
-      const size_t count = std::min<size_t>(batch_points, n_points - i);
-      total += gpu_map->integrateRays(rays.data() + i, count, nullptr, nullptr, ohm::kRfDefault);
+      gputil::Device device;
+      gputil::Queue queue = device.defaultQueue();
+      ohm::GpuTransformSamples transform(device);
+      gputil::Buffer device_rays;
+      const double times[2] = { 0.0, 1.0 };
+      const ohm::dvec3 translations[2] = { { 0, 0, 0 }, { 0, 0, 0 } };
+      const ohm::dquat rotations[2] = { { 0, 0, 0, 1 }, { 0, 0, 0, 1 } };
+      std::vector<ohm::dvec3> samples;
+      std::vector<double> sample_times;
+      for (size_t i = 0; i < n_points; i += batch_points)
+      {
+        const size_t count = std::min<size_t>(batch_points, n_points - i);
+        samples.clear();
+        sample_times.clear();
+        for (size_t k = 1; k < count; k += 2)
+        {
+          samples.push_back(rays[i + k]);
+          sample_times.push_back(0.25 + 0.5 * double(k) / double(count));
+        }
+        const unsigned elements = transform.transform(times, translations, rotations, 2, sample_times.data(),
+                                                      samples.data(), unsigned(samples.size()), queue, device_rays);
+        total += gpu_map->integrateRays(device_rays, elements, ohm::kRfDefault);
+      }
+    }
+    else
+    {
+      for (size_t i = 0; i < n_points; i += batch_points)
+      {
+        const size_t count = std::min<size_t>(batch_points, n_points - i);
+        total += gpu_map->integrateRays(rays.data() + i, count, nullptr, nullptr, ohm::kRfDefault);
+      }
     }
     gpu_map->syncVoxels();
     std::printf("integrated %zu of %llu points, %zu regions\n", total, (unsigned long long)n_points, map.regionCount());

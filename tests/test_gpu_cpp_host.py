@@ -71,3 +71,17 @@ def test_cpp_host_mirror_matches_oracle(gpu, mode, layers, res):
             om.integrate_occupancy(chunk)
     stats = compare_maps(om.chunks(), gpu_chunks, list(layers), rel=1e-5, exact_float=(mode != "ndt"))
     assert_parity(stats)
+
+
+def test_cpp_transform_samples_feeds_device_integration(gpu):
+    # ohm::GpuTransformSamples -> device buffer -> GpuMap::integrateRays(Buffer): with a static identity trajectory the
+    # result must equal integrating rays from the origin to the same sample points.
+    rays = synth.rays_c2(n=8000)
+    gpu_chunks = run_driver("occdev", 0.1, 4096, rays, 1)
+    from_origin = rays.copy()
+    from_origin[0::2] = 0.0
+    om = OracleMap(0.1, layers=("occupancy",))
+    for i in range(0, rays.shape[0], 2 * 4096):
+        om.integrate_occupancy(from_origin[i:i + 2 * 4096])
+    stats = compare_maps(om.chunks(), gpu_chunks, ["occupancy"], exact_float=True)
+    assert_parity(stats)
