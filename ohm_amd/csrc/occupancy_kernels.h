@@ -1451,16 +1451,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // ---- the loads share one basic block, and consumed afterwards.
     constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
     constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
-    uint32_t lens[kSegPerThread];
-#pragma unroll
-    for (int j = 0; j < kSegPerThread; ++j)
-    {
-      const uint32_t i = min(threadIdx.x + uint32_t(j) * kWalkThreads, n_seg - 1u);
-      const uint2 w = *reinterpret_cast<const uint2 *>(&chunk_segments[i].s1);
-      lens[j] = min((w.x >> 24) | ((w.y >> 24) << 8), kLengthClasses - 1u);
-    }
-    const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
-    const uint32_t my_mask = g_mask[min(threadIdx.x, mask_words - 1u)];
+    // (The conditional sample loads come first: the segment words are consumed right below, and a wait for them placed
+    // ahead of the sample loads would serialise two memory round trips.)
     // Stage the region's sorted sample keys so deferred misses can be ordered against them at LDS latency.
     const uint32_t n_region_hits = he - hb;
     const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(kLdsHits);
@@ -1472,6 +1464,16 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       {
         my_hits[j] = args.sorted_hits[hb + min(threadIdx.x + uint32_t(j) * kWalkThreads, n_region_hits - 1u)];
       }
+    }
+    const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
+    const uint32_t my_mask = g_mask[min(threadIdx.x, mask_words - 1u)];
+    uint32_t lens[kSegPerThread];
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j)
+    {
+      const uint32_t i = min(threadIdx.x + uint32_t(j) * kWalkThreads, n_seg - 1u);
+      const uint2 w = *reinterpret_cast<const uint2 *>(&chunk_segments[i].s1);
+      lens[j] = min((w.x >> 24) | ((w.y >> 24) << 8), kLengthClasses - 1u);
     }
     if (threadIdx.x < kLengthClasses)
     {
