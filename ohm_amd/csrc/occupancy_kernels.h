@@ -278,9 +278,11 @@ struct LdsRegionTable
 };
 
 /// Find or insert `key`; returns the entry index or kLtabSize when the table is full (caller falls back to global).
-__device__ inline uint32_t ltabFindOrInsert(LdsRegionTable &tab, uint64_t key)
+/// `mask` = entries in use - 1 (a power of two <= kLtabSize: small workgroups use a small table so clearing and scanning
+/// it does not dominate their run time).
+__device__ inline uint32_t ltabFindOrInsert(LdsRegionTable &tab, uint64_t key, uint32_t mask)
 {
-  uint32_t idx = hashRegionKey(key, kLtabSize - 1);
+  uint32_t idx = hashRegionKey(key, mask);
   for (uint32_t probe = 0; probe < 64; ++probe)
   {
     unsigned long long prev = tab.keys[idx];
@@ -292,14 +294,14 @@ __device__ inline uint32_t ltabFindOrInsert(LdsRegionTable &tab, uint64_t key)
     {
       return idx;
     }
-    idx = (idx + 1) & (kLtabSize - 1);
+    idx = (idx + 1) & mask;
   }
   return kLtabSize;
 }
 
-__device__ inline uint32_t ltabFind(const LdsRegionTable &tab, uint64_t key)
+__device__ inline uint32_t ltabFind(const LdsRegionTable &tab, uint64_t key, uint32_t mask)
 {
-  uint32_t idx = hashRegionKey(key, kLtabSize - 1);
+  uint32_t idx = hashRegionKey(key, mask);
   for (uint32_t probe = 0; probe < 64; ++probe)
   {
     const unsigned long long k = tab.keys[idx];
@@ -311,7 +313,7 @@ __device__ inline uint32_t ltabFind(const LdsRegionTable &tab, uint64_t key)
     {
       break;
     }
-    idx = (idx + 1) & (kLtabSize - 1);
+    idx = (idx + 1) & mask;
   }
   return kLtabSize;
 }
@@ -420,13 +422,13 @@ __device__ inline void markTouched(const BatchScratch &bs, uint32_t h)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBinThreads)
   k_ray_setup(MapConst mc, RegionTable rt, BatchScratch bs, const double *__restrict__ rays, uint32_t n_rays,
-              unsigned ray_flags, RayWalk *__restrict__ walks, uint32_t rays_per_block)
+              unsigned ray_flags, RayWalk *__restrict__ walks, uint32_t rays_per_block, uint32_t tab_mask)
 {
   __shared__ LdsRegionTable tab;
   __shared__ unsigned long long s_visits;
   __shared__ uint32_t s_rays_ok;
   __shared__ uint32_t s_list_n;
-  for (uint32_t i = threadIdx.x; i < kLtabSize; i += blockDim.x)
+  for (uint32_t i = threadIdx.x; i <= tab_mask; i += blockDim.x)
   {
     tab.keys[i] = 0;
     tab.count[i] = 0;
@@ -472,7 +474,7 @@ __global__ void __launch_bounds__(kBinThreads)
     my_visits += (rw.flags & kRwApplySample) ? 1u : 0u;
 
     forEachSegment(mc, rw, false, [&](uint64_t key, uint32_t, uint32_t, uint32_t) {
-      const uint32_t e = ltabFindOrInsert(tab, key);
+      const uint32_t e = ltabFindOrInsert(tab, key, tab_mask);
       if (e < kLtabSize)
       {
         atomicAdd(&tab.count[e], 1u);
@@ -491,7 +493,7 @@ __global__ void __launch_bounds__(kBinThreads)
       uint64_t key;
       uint32_t vi;
       sampleVoxel(mc, rw, key, vi);
-      const uint32_t e = ltabFindOrInsert(tab, key);
+      const uint32_t e = ltabFindOrInsert(tab, key, tab_mask);
       if (e < kLtabSize)
       {
         atomicAdd(&tab.cursor[e], 1u);
@@ -513,7 +515,7 @@ __global__ void __launch_bounds__(kBinThreads)
     atomicAdd(&bs.info->rays_ok, (unsigned long long)s_rays_ok);
   }
   // One global insert + one counter atomic per (workgroup, region).
-  for (uint32_t e = threadIdx.x; e < kLtabSize; e += blockDim.x)
+  for (uint32_t e = threadIdx.x; e <= tab_mask; e += blockDim.x)
   {
     const unsigned long long key = tab.keys[e];
     if (key)
@@ -813,10 +815,11 @@ __global__ void __launch_bounds__(1024)
 __global__ void __launch_bounds__(kBinThreads)
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
-            uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits, uint32_t rays_per_block)
+            uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits, uint32_t rays_per_block,
+            uint32_t tab_mask)
 {
   __shared__ LdsRegionTable tab;
-  for (uint32_t i = threadIdx.x; i < kLtabSize; i += blockDim.x)
+  for (uint32_t i = threadIdx.x; i <= tab_mask; i += blockDim.x)
   {
     tab.keys[i] = 0;
     tab.count[i] = 0;
@@ -861,7 +864,7 @@ __global__ void __launch_bounds__(kBinThreads)
       uint64_t key;
       uint32_t vi;
       sampleVoxel(mc, rw, key, vi);
-      const uint32_t e = bucket_hits ? ltabFind(tab, key) : kLtabSize;
+      const uint32_t e = bucket_hits ? ltabFind(tab, key, tab_mask) : kLtabSize;
       uint32_t slot;
       if (e < kLtabSize)
       {
@@ -897,7 +900,7 @@ __global__ void __launch_bounds__(kBinThreads)
   {
     const RayWalk rw = walks[ray];
     forEachSegment(mc, rw, true, [&](uint64_t key, uint32_t rs0, uint32_t rs1, uint32_t rs2) {
-      const uint32_t e = ltabFind(tab, key);
+      const uint32_t e = ltabFind(tab, key, tab_mask);
       uint32_t pos;
       if (e < kLtabSize)
       {

@@ -468,6 +468,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   }
   bin_threads = std::min<uint32_t>(bin_threads, bin_rays_per_block);
   const uint32_t bin_blocks = (n_rays + bin_rays_per_block - 1) / bin_rays_per_block;
+  // LDS region table of the binning workgroups: two entries per ray of the workgroup, at most kLtabSize.
+  const uint32_t bin_tab_mask = std::min<uint32_t>(kLtabSize, std::max<uint32_t>(256u, 2u * bin_rays_per_block)) - 1u;
   // Chunk size of this batch: small batches get smaller chunks so the walk still has a few chunks per CU (estimated
   // from the previous batch's segments per ray; results do not depend on it).
   const uint64_t expected_segments = uint64_t(double(n_rays) * m->segments_per_ray);
@@ -518,7 +520,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, sizeof(BatchInfo), s));
     OHMHIP_CHECK(hipEventRecord(tev[0], s));
     hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
-                       n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr), bin_rays_per_block);
+                       n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr), bin_rays_per_block, bin_tab_mask);
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
                        m->chunk_capacity, batch_chunk_segments);
     OHMHIP_CHECK(hipMemcpyAsync(m->h_info, m->d_info, sizeof(BatchInfo), hipMemcpyDeviceToHost, s));
@@ -530,7 +532,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     auto launchBin = [&](bool bucket, uint32_t seg_capacity, unsigned long long *hit_keys) {
       hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m),
                          static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
-                         seg_capacity, hit_keys, m->d_hit_mask, ray_shift, bucket ? 1 : 0, bin_rays_per_block);
+                         seg_capacity, hit_keys, m->d_hit_mask, ray_shift, bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
     };
     auto launchRegionSort = [&]() {
       hipLaunchKernelGGL(k_sort_region_hits, dim3(4 * m->walk_workgroups), dim3(kSortThreads), 0, s, regionTable(m),
