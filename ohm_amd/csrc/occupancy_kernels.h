@@ -1,16 +1,19 @@
 // occupancy_kernels.h -- the gfx950 kernels of the occupancy ray-integration path.
 //
 // Pipeline per ray batch (all on one HIP stream; see DESIGN.md for the full picture):
-//   k_ray_setup     1 lane / ray     filter, keys, fp64 line-walk set-up; enumerate the regions the ray crosses and
-//                                    count ray-region segments per region (wave-aggregated atomics)
-//   k_plan          1 block          slots for new regions, exclusive scan of segment counts, chunk work list
-//   k_ray_bin       1 lane / ray     scatter segments into per-region buckets; emit hit keys; set hit bitmask
-//   (radix sort of hit keys by region slot, voxel, ray index)
-//   k_hit_bounds    1 lane / hit     per-region [begin, end) into the sorted hit list
-//   k_region_walk   1 block / chunk  THE hot kernel: region miss-count tile in LDS, 1 lane / segment resumes the
-//                                    fp64 DDA inside the region; LDS atomics; flush tile to the region count layer
-//   k_apply_hits    1 lane / hit     ordered replay (misses-before-hit counts, hit, mean) for voxels that got samples
-//   k_apply_counts  1 block / region apply remaining miss counts to the occupancy layer, clear scratch
+//   k_ray_setup         1 lane / ray       filter, keys, fp64 line-walk set-up; enumerate the regions the ray crosses;
+//                                          segment and sample counts per region in a workgroup-level LDS table
+//   k_plan              1 workgroup        scans over the touched regions: segment / sample offsets, equal-size chunks
+//                                          (largest first), sample-sort order
+//   k_ray_bin           1 lane / ray       scatter segment records (resume state + voxel count) and sample keys into
+//                                          the per-region ranges; set the sample bitmask
+//   k_sort_region_hits  1 workgroup/region order a region's sample keys by (voxel, ray) in LDS
+//                                          (fallback for very dense regions: device-wide radix sort + k_hit_bounds)
+//   k_region_walk       persistent, 1 workgroup / CU   THE hot kernel: chunks from a device-wide cursor; region
+//                                          miss-count tile in LDS, 1 lane / segment resumes the fp64 walk inside the
+//                                          region; LDS atomics; single-chunk regions applied straight from LDS
+//   k_apply_hits        1 lane / sample    ordered replay (misses-before-hit counts, hit, mean) for voxels with samples
+//   k_apply_counts      1 workgroup/region remaining miss counts of multi-chunk regions, clear scratch
 //
 // Ordering argument (why integer counting reproduces the sequential CPU result exactly): every miss applies the
 // same function m(x) and every hit the same h(x) to a voxel's value.  The CPU result for a voxel is the composition
