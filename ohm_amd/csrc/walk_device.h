@@ -16,10 +16,18 @@ __device__ inline double dInf()
   return __longlong_as_double(0x7ff0000000000000ll);
 }
 
+/// double -> int the way the host the reference runs on does it (x86 cvttsd2si): values outside the int range and
+/// NaN give INT_MIN, where the device conversion would saturate.  Only matters for absurd inputs (points 10^5 km from
+/// the map origin), but those still have to produce the same keys as the CPU mapper.
+__device__ inline int hostInt(double v)
+{
+  return (v >= -2147483648.0 && v < 2147483648.0) ? int(v) : int(0x80000000u);
+}
+
 /// ohm/MapCoord.h:85-93
 __device__ inline int pointToRegionCoord(double coord, double resolution)
 {
-  return int(floor(coord / resolution + 0.5));
+  return hostInt(floor(coord / resolution + 0.5));
 }
 
 /// ohm/MapCoord.h:45-80
@@ -34,10 +42,11 @@ __device__ inline int pointToRegionVoxel(double coord, double voxel_resolution, 
   {
     coord -= epsilon;
   }
-  return int(floor(coord / voxel_resolution));
+  return hostInt(floor(coord / voxel_resolution));
 }
 
-/// ohm/OccupancyMap.cpp:859-886 -> ohm/MapRegion.cpp:32-69.  Returns false for a null key.
+/// ohm/OccupancyMap.cpp:859-886 -> ohm/MapRegion.cpp:32-69.  Returns false when the point is not addressable (the
+/// reference then hands out Key::kNull).  See keyIsNull() for the one addressable key that still reads as null.
 /// @param[out] region Region coordinate per axis.
 /// @param[out] local Local voxel coordinate per axis.
 __device__ inline bool voxelKey(const MapConst &mc, const double p[3], int region[3], int local[3])
@@ -47,8 +56,9 @@ __device__ inline bool voxelKey(const MapConst &mc, const double p[3], int regio
   for (int a = 0; a < 3; ++a)
   {
     const int coord = pointToRegionCoord(p[a] - mc.origin[a], mc.region_dim[a]);
-    // The reference stores the region coordinate in an int16; anything outside is not addressable.
-    ok = ok && coord > -32768 && coord <= 32767;
+    // The reference stores the region coordinate in an int16: anything outside wraps to a far-away region, whose local
+    // coordinate is then out of range, i.e. the key is null (ohm/MapRegion.cpp:32-69).
+    ok = ok && coord >= -32768 && coord <= 32767;
     const double centre = coord * mc.region_dim[a];
     const double region_min = centre - 0.5 * mc.region_dim[a];
     const double pl = p[a] - mc.origin[a] - region_min;
@@ -58,6 +68,13 @@ __device__ inline bool voxelKey(const MapConst &mc, const double p[3], int regio
     local[a] = q;
   }
   return ok;
+}
+
+/// Key::isNull() is "all three region coordinates == int16 lowest" (ohm/Key.h:206): that one corner region reads as
+/// null -- for the line walk -- even when the point is addressable.
+__device__ inline bool keyIsNull(bool addressable, const int region[3])
+{
+  return !addressable || (region[0] == -32768 && region[1] == -32768 && region[2] == -32768);
 }
 
 /// ohm/OccupancyMap.h:757-778 (one axis).
@@ -218,11 +235,28 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
   }
 
   int r0[3], l0[3], r1[3], l1[3];
-  const bool ok0 = voxelKey(mc, start, r0, l0);
-  const bool ok1 = voxelKey(mc, end, r1, l1);
+  const bool addressable0 = voxelKey(mc, start, r0, l0);
+  const bool addressable1 = voxelKey(mc, end, r1, l1);
+  const bool ok0 = !keyIsNull(addressable0, r0);
+  const bool ok1 = !keyIsNull(addressable1, r1);
   if (!ok0 || !ok1)
   {
-    return;  // walkSegmentKeys returns 0 for null keys (ohm/LineWalk.h:119-122).
+    // walkSegmentKeys returns 0 for null keys (ohm/LineWalk.h:119-122): no voxel of the ray is visited.  The mappers
+    // still apply the SAMPLE update afterwards with voxelKey(end) and no null check (ohm/RayMapperOccupancy.cpp:234-239,
+    // ohm/RayMapperNdt.cpp:280-286): an addressable end point gets its hit although the start was not addressable, and an
+    // unaddressable end point lands on Key::kNull -- region (-32768)^3, voxel 0 (an end point in that corner region IS
+    // addressable and keeps its voxel; only the walk treats its key as null).  Mirrored here so the maps stay identical: a ray with no walk whose "start voxel" is the voxel the sample goes to.
+    const bool include_end = clipped_end || (ray_flags & OHMHIP_RF_END_POINT_AS_FREE);
+    if (!include_end && !(ray_flags & OHMHIP_RF_EXCLUDE_SAMPLE))
+    {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+      {
+        rw.g0[a] = addressable1 ? (r1[a] * mc.dim[a] + l1[a]) : (-32768 * mc.dim[a]);
+      }
+      rw.flags = kRwValid | kRwApplySample;
+    }
+    return;
   }
 
   // walkInitRay

@@ -51,6 +51,19 @@ def test_ndt_random_rays_small_voxels(gpu):
     assert_parity(stats)
 
 
+def test_ndt_unaddressable_points(gpu):
+    # ohm/RayMapperNdt.cpp:277-286: no voxel is walked when either key is null, the sample is still applied (to the end
+    # voxel when it is addressable, to Key::kNull's voxel otherwise) -- same rule as the occupancy mapper.
+    good = synth.random_rays(300, extent=6.0, seed=41)
+    res = 0.2
+    edge = 32768 * 32 * res  # first coordinate beyond the int16 region range
+    bad = np.array([[0, 0, 0], [2 * edge, 0, 0], [-3 * edge, 1, 1], [1, 1, 1], [edge - 3.0, 0, 0], [edge + 1.0, 0, 0],
+                    [-(edge - 3.0), 0, 0], [-(edge - 0.3), 0, 0]], dtype=np.float64)
+    rays = np.concatenate([good[:300], bad, good[300:]])
+    stats, gm, om = run_ndt(rays, resolution=res)
+    assert_parity(stats)
+
+
 def test_ndt_tm(gpu):
     rays = np.concatenate([synth.rays_c2(n=15000, seed=200 + k) for k in range(3)])
     ints = (synth.uniform01(5, np.arange(rays.shape[0] // 2, dtype=np.uint64), 0) * 100).astype(np.float32)

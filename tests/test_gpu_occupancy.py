@@ -161,3 +161,29 @@ def test_speculative_binning_recovers_from_wrong_guesses(gpu):
     gm.syncVoxels()
     stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
     assert_parity(stats)
+
+
+def test_out_of_range_coordinates_and_degenerate_batches(gpu):
+    # Points whose region coordinate does not fit the int16 key are null keys: the CPU walk visits nothing for such rays
+    # (ohm/LineWalk.h:119-122) but the mapper still applies the sample update -- to the end voxel when that is
+    # addressable, to Key::kNull's voxel otherwise (ohm/RayMapperOccupancy.cpp:234-239).  Mixed with valid rays, empty
+    # batches and a one-ray batch.
+    good = synth.random_rays(500, extent=5.0, seed=33)
+    bad = np.array([[0, 0, 0], [2.0e5, 0, 0],            # end far outside the addressable range
+                    [-3.0e5, 1, 1], [1, 1, 1],           # start outside
+                    [1.0e6, 1.0e6, 1.0e6], [1.0e6 + 1, 1.0e6, 1.0e6],
+                    [104850.0, 0, 0], [104857.0, 0, 0],      # end region 32768: not addressable (wraps)
+                    [-104850.0, 0, 0], [-104857.0, 0, 0],    # end region -32768: the lowest addressable one
+                    [-104857.0, -104857.0, -104850.0], [-104857.0, -104857.0, -104857.0]],  # end = the kNull corner
+                   dtype=np.float64)
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    for batch in (good[:200], bad[:6], np.zeros((0, 3)), good[200:202], bad, good[202:]):
+        if batch.shape[0]:
+            gm.integrateRays(batch)
+            om.integrate_occupancy(batch)
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
+    assert_parity(stats)
+    assert (-32768, -32768, -32768) in map_.chunks
