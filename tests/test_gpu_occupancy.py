@@ -187,3 +187,53 @@ def test_out_of_range_coordinates_and_degenerate_batches(gpu):
     stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
     assert_parity(stats)
     assert (-32768, -32768, -32768) in map_.chunks
+
+
+@pytest.mark.parametrize("origin", [(0.0, 0.0, 0.0), (0.05, 0.05, 0.05)])
+def test_rays_through_voxel_and_region_corners(gpu, origin):
+    # Exact ties between the axes' step times at every step (diagonals through voxel corners) and at region corners,
+    # axis-aligned rays running along voxel faces, rays starting / ending exactly on boundaries: the resume state at
+    # region entries is computed in closed form (stepsBefore) and must break ties like the sequential CPU walk.
+    pts = []
+    dirs = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1), (-1, 1, 1), (1, -1, 1),
+            (1, 1, -1), (-1, -1, 1), (-1, -1, -1), (2, 1, 0), (1, 2, 3), (-3, 2, 1)]
+    for d in dirs:
+        for length in (3.2, 6.4, 9.6, 12.8, 7.3):
+            for start in ((0.0, 0.0, 0.0), (3.2, 3.2, 3.2), (0.1, 0.2, 0.3), (-3.2, 0.0, 6.4), (1.6, 1.6, 1.6)):
+                s = np.array(start)
+                pts += [s, s + np.array(d, dtype=np.float64) * length]
+    rays = np.array(pts, dtype=np.float64)
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+    map_.setOrigin(origin)
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    for flags in (0, int(RayFlag.kRfEndPointAsFree)):
+        gm.integrateRays(rays, ray_update_flags=flags)
+        om.integrate_occupancy(rays, flags=flags)
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
+    assert_parity(stats)
+    assert gm.stats()["voxel_visits"] > 0
+
+
+def test_ray_flag_combinations(gpu):
+    # Every subset of the value-dependent / geometry flags, each on a map that already holds free, occupied and
+    # unobserved voxels (a first default pass), so kRfExcludeFree / kRfExcludeOccupied / kRfExcludeUnobserved bite.
+    base = synth.random_rays(1500, extent=4.0, seed=51, origin_spread=0.5)
+    probe = synth.random_rays(1500, extent=4.0, seed=52, origin_spread=0.5)
+    bits = [RayFlag.kRfEndPointAsFree, RayFlag.kRfExcludeOrigin, RayFlag.kRfExcludeSample, RayFlag.kRfExcludeUnobserved,
+            RayFlag.kRfExcludeFree, RayFlag.kRfExcludeOccupied]
+    for subset in range(1, 1 << len(bits), 3):  # every third subset keeps the run short; all bits appear many times
+        flags = 0
+        for k, b in enumerate(bits):
+            flags |= int(b) if (subset >> k) & 1 else 0
+        map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+        gm = GpuMap(map_)
+        om = make_oracle(map_)
+        gm.integrateRays(base)
+        om.integrate_occupancy(base)
+        gm.integrateRays(probe, ray_update_flags=flags)
+        om.integrate_occupancy(probe, flags=flags)
+        gm.syncVoxels()
+        stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
+        assert not {k: v for k, v in stats.items() if (k.startswith("diff_") or k.endswith("_on_gpu")) and v}, (flags, stats)
