@@ -12,6 +12,12 @@ def make_oracle(map_):
     om.set_origin(map_.origin)
     mode, rng = map_.ray_filter if map_.ray_filter else ("none", 0.0)
     om.set_ray_filter(mode, rng)
+    # non-default probabilities / clamps / saturation travel too
+    from oracle.oracle import lib as _olib
+    _olib.oracle_map_set_hit_value(om.handle, float(map_.hit_value))
+    _olib.oracle_map_set_miss_value(om.handle, float(map_.miss_value))
+    _olib.oracle_map_set_min_max(om.handle, float(map_.min_voxel_value), float(map_.max_voxel_value))
+    _olib.oracle_map_set_saturation(om.handle, int(map_.saturate_at_min_value), int(map_.saturate_at_max_value))
     return om
 
 

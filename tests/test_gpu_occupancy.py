@@ -237,3 +237,39 @@ def test_ray_flag_combinations(gpu):
         gm.syncVoxels()
         stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
         assert not {k: v for k, v in stats.items() if (k.startswith("diff_") or k.endswith("_on_gpu")) and v}, (flags, stats)
+
+
+def test_very_long_rays_overflow_the_workgroup_region_table(gpu):
+    # A ray crossing more regions than the binning workgroup's LDS region table holds (2048 entries) takes the global
+    # counting / cursor fallback; mixed with ordinary rays in the same workgroup.
+    short = synth.random_rays(400, extent=5.0, seed=61)
+    long_rays = np.array([[0.05, 0.05, 0.05], [9000.0, 13.0, -7.0],
+                          [0.05, 0.05, 0.05], [-3000.0, 8000.0, 40.0],
+                          [1.0, 2.0, 3.0], [1.0, 2.0, 7500.0]], dtype=np.float64)
+    rays = np.concatenate([short[:400], long_rays, short[400:]])
+    stats, gm, om, total = run_case(rays, layers=("occupancy",), region_capacity=16384)
+    assert total == rays.shape[0]
+    assert_parity(stats)
+    assert gm.stats()["voxel_visits"] == stats["visits_cpu"]
+
+
+@pytest.mark.parametrize("sat_min,sat_max", [(False, False), (True, False), (False, True), (True, True)])
+def test_non_default_probabilities_clamps_and_saturation(gpu, sat_min, sat_max):
+    # ohm/VoxelOccupancyCompute.h:44-54, 110-120: saturation freezes a voxel once it reaches min / max; tight clamps make
+    # that happen quickly.  Several passes over the same rays so the frozen states matter.
+    rays = synth.rays_c1(n=20000, max_range=8.0)
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+    map_.setHitProbability(0.8)
+    map_.setMissProbability(0.35)
+    map_.min_voxel_value = np.float32(-1.1)
+    map_.max_voxel_value = np.float32(2.3)
+    map_.saturate_at_min_value = sat_min
+    map_.saturate_at_max_value = sat_max
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    for _ in range(4):
+        gm.integrateRays(rays)
+        om.integrate_occupancy(rays)
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
+    assert_parity(stats)
