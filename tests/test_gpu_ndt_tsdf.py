@@ -64,6 +64,28 @@ def test_ndt_unaddressable_points(gpu):
     assert_parity(stats)
 
 
+def test_ndt_ray_flags_and_clip_filter(gpu):
+    # RayMapperNdt honours kRfEndPointAsFree / kRfExcludeOrigin / kRfExcludeRay (ohm/RayMapperNdt.cpp:238-262); the
+    # clip filter shortens long rays and turns their end voxel into a walked voxel.
+    rays = np.concatenate([synth.rays_c2(n=8000, seed=300 + k) for k in range(2)])
+    for flags in (ohm_amd.RayFlag.kRfEndPointAsFree, ohm_amd.RayFlag.kRfExcludeOrigin, ohm_amd.RayFlag.kRfExcludeRay,
+                  ohm_amd.RayFlag.kRfEndPointAsFree | ohm_amd.RayFlag.kRfExcludeOrigin):
+        stats, gm, om = run_ndt(rays, batch=4000, flags=flags)
+        assert_parity(stats)
+    map_ = OccupancyMap(0.2, (32, 32, 32), layers=("occupancy",))
+    map_.ray_filter = ("clip", 12.0)
+    gm = GpuNdtMap(map_)
+    om = make_oracle(map_)
+    om.set_ndt(sensor_noise=gm.sensor_noise, sample_threshold=gm.sample_threshold, adaptation_rate=gm.adaptation_rate,
+               reinit_threshold=gm.reinitialise_covariance_threshold,
+               reinit_count=gm.reinitialise_covariance_point_count)
+    for i in range(0, rays.shape[0], 8000):
+        gm.integrateRays(rays[i:i + 8000])
+        om.integrate_ndt(rays[i:i + 8000])
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(map_.layers), rel=1e-5))
+
+
 def test_ndt_tm(gpu):
     rays = np.concatenate([synth.rays_c2(n=15000, seed=200 + k) for k in range(3)])
     ints = (synth.uniform01(5, np.arange(rays.shape[0] // 2, dtype=np.uint64), 0) * 100).astype(np.float32)
