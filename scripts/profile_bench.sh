@@ -9,7 +9,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu --no-extra"
+CMD="python bench.py --steps 20 --warmup 5 --no-cpu --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.log 2>&1
 if [ "$MODE" = "pmc" ]; then
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_ANY --output-format csv -d $OUT/pmc1 -o pmc1 -- $CMD > $OUT/bench_pmc1.log 2>&1
