@@ -156,7 +156,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64 line walk + f32 log-odds",
+        "dtype": "f64",  # line walk in fp64 (as the CPU mapper); the log-odds layer itself is f32
         "data": "synthetic",
         "config": {"workload": workload, "rays_per_step_per_gpu": n_rays, "voxel_visits_per_step": visits,
                    "regions": int(st["regions_resident"]), "ray_region_segments": int(st["ray_region_segments"])},
