@@ -92,6 +92,13 @@ __device__ inline double voxelCentreAxis(const MapConst &mc, int a, int region, 
 /// floor division / modulo for global voxel coordinate -> (region, local).
 __device__ inline void splitGlobal(int g, int dim, int &region, int &local)
 {
+  if ((dim & (dim - 1)) == 0)
+  {
+    // power-of-two region edge (the default 32): arithmetic shift == floor division, mask == floor modulo
+    region = g >> (__ffs(dim) - 1);
+    local = g & (dim - 1);
+    return;
+  }
   int q = g / dim;
   int r = g - q * dim;
   if (r < 0)
