@@ -421,6 +421,80 @@ __device__ inline void markTouched(const BatchScratch &bs, uint32_t h)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Ray order inside a binning workgroup.  A lane enumerates its ray's region crossings one after the other, so a wave
+// runs as long as its longest ray: with rays in arrival order (a lidar's beams have unrelated ranges) a third of the
+// lane slots idle.  The workgroup therefore visits its rays by descending extent (counting sort on the ray's Manhattan
+// extent in regions, 64 bins, positions in LDS): the rays of one wave then cross about the same number of regions.
+// The order is irrelevant to the result -- segment records and sample keys carry the ray index.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kRayOrderBins = 64;
+
+struct RayOrder
+{
+  uint32_t bins[kRayOrderBins];
+  uint16_t perm[kBinRaysPerBlock];
+};
+
+__device__ inline uint32_t rayExtentBin(const MapConst &mc, unsigned flags, const int total[3])
+{
+  if (!(flags & kRwValid) || !(flags & kRwWalk))
+  {
+    return 0;
+  }
+  const int max_dim = max(mc.dim[0], max(mc.dim[1], mc.dim[2]));
+  const uint32_t manhattan = uint32_t(total[0] + total[1] + total[2]);
+  return min(manhattan >> (31 - __clz(max_dim)), kRayOrderBins - 1u);
+}
+
+/// Build the order of the workgroup's `n_local` rays from their extent bins (bin_of(k) = bin of the thread's k-th ray,
+/// local index threadIdx.x + k * blockDim.x; at most 8 rays per thread).  Ends with a barrier.
+template <typename BinOf>
+__device__ inline void buildRayOrder(RayOrder &order, uint32_t n_local, BinOf bin_of)
+{
+  if (threadIdx.x < kRayOrderBins)
+  {
+    order.bins[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  uint32_t my_bins[8];
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k)
+  {
+    const uint32_t idx = threadIdx.x + k * blockDim.x;
+    my_bins[k] = 0;
+    if (idx < n_local)
+    {
+      my_bins[k] = kRayOrderBins - 1u - bin_of(k, idx);  // descending extent
+      atomicAdd(&order.bins[my_bins[k]], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kRayOrderBins)
+  {
+    const uint32_t count = order.bins[threadIdx.x];
+    uint32_t incl = count;
+#pragma unroll
+    for (int d = 1; d < int(kRayOrderBins); d <<= 1)
+    {
+      const uint32_t up = __shfl_up(incl, d);
+      incl += (int(threadIdx.x) >= d) ? up : 0u;
+    }
+    order.bins[threadIdx.x] = incl - count;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k)
+  {
+    const uint32_t idx = threadIdx.x + k * blockDim.x;
+    if (idx < n_local)
+    {
+      order.perm[atomicAdd(&order.bins[my_bins[k]], 1u)] = uint16_t(idx);
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_ray_setup: per-ray line-walk set-up + per-region segment counts.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBinThreads)
@@ -898,9 +972,17 @@ __global__ void __launch_bounds__(kBinThreads)
       hit_keys[pos] = hk;
     }
   }
-  // Step 3: scatter.
-  for (uint32_t ray = first + threadIdx.x; ray < last; ray += blockDim.x)
+  // Step 3: scatter, rays visited by descending extent (see RayOrder).
+  __shared__ RayOrder order;
+  const uint32_t n_local = last - first;
+  buildRayOrder(order, n_local, [&](uint32_t, uint32_t idx) {
+    const RayWalk *w = walks + first + idx;
+    const int total[3] = { w->total[0], w->total[1], w->total[2] };
+    return rayExtentBin(mc, w->flags, total);
+  });
+  for (uint32_t idx = threadIdx.x; idx < n_local; idx += blockDim.x)
   {
+    const uint32_t ray = first + order.perm[idx];
     const RayWalk rw = walks[ray];
     forEachSegment(mc, rw, true, [&](uint64_t key, uint32_t rs0, uint32_t rs1, uint32_t rs2) {
       const uint32_t e = ltabFind(tab, key, tab_mask);
