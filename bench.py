@@ -224,6 +224,28 @@ def main():
                                        "integrate_ms": (t2 - t1) * 1e3, "sync_voxels_ms": (t3 - t2) * 1e3,
                                        "note": "host-pointer rays (48 B/ray over PCIe) + all modified regions copied back"}
         g4.close()
+        # (iii) exact multi-GPU mode ("owner computes"): what ONE rank of an 8-way region partition spends
+        # on the full C1 stream -- the per-ray front half is repeated on every rank, the line walk is partitioned.
+        per_rank = []
+        for r in (0, 3):
+            m5 = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+            g5 = ohm_amd.GpuMap(m5, gpu_mem_size=8 << 30)
+            g5.setRegionOwnership(8, r, 0)
+            g5.integrateRaysDevice(dptr, rays.shape[0])
+            g5.wait()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                g5.integrateRaysDevice(dptr, rays.shape[0])
+            g5.wait()
+            dt = (time.perf_counter() - t1) / 5
+            st5 = g5.stats()
+            per_rank.append({"rank": r, "ms_per_step": dt * 1e3, "walk_ms": float(st5["ms_walk"]),
+                             "segments": int(st5["ray_region_segments"])})
+            g5.close()
+        extra["C1_owner_computes_8way_one_rank"] = {
+            "per_rank": per_rank, "all_segments": int(st["ray_region_segments"]),
+            "note": "same 1M-ray stream on every rank; projected 8-GPU rate = rays / max rank step, excluding the "
+                    "48 B/ray all-gather"}
         out["other_configs"] = extra
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(rays, resolution, min(args.cpu_sample, n_rays))

@@ -256,6 +256,18 @@ int ohmhip_map_region_slot(ohmhip_map_t map, const int16_t key_xyz[3], uint32_t 
 int ohmhip_map_ensure_regions(ohmhip_map_t map, const int16_t *keys_xyz, size_t count, uint32_t *slots);
 int ohmhip_map_mark_dirty(ohmhip_map_t map, const uint32_t *slots, size_t count);
 
+/* Exact multi-GPU integration, "owner computes" (SURVEY 8e mode 2: map partitioned by region; no reference equivalent).
+ * With world_size > 1 the map integrates only what falls in regions ohmhip_region_owner() assigns to `rank`: the ray
+ * segments crossing those regions and the samples landing in them.  Every voxel's update sequence depends only on the
+ * rays that reach it, in order, so when each of world_size maps is given the SAME ray stream the union of their
+ * regions is bit-identical to one map integrating that stream (tests/test_gpu_owner_computes.py); what the ranks
+ * exchange is rays (an all-gather), never voxels.  Regions are dealt to ranks by a hash of their block of
+ * 2^block_shift regions per axis.  Set before the first integrate call; world_size <= 1 turns the filter off.
+ * ohmhip_batch_stats::visits keeps counting the voxels of the presented rays, owned or not. */
+int ohmhip_map_set_region_ownership(ohmhip_map_t map, uint32_t world_size, uint32_t rank, int block_shift);
+int ohmhip_region_owner(const int16_t *keys_xyz, size_t count, int block_shift, uint32_t world_size,
+                        uint32_t *owners);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,10 +324,18 @@ __device__ inline uint32_t ltabFind(const LdsRegionTable &tab, uint64_t key, uin
 /// Walk the regions a ray crosses and call f(region key, s0, s1, s2) for every ray-region segment which produces at
 /// least one voxel visit.  With `with_resume_state` the three words are the packed Segment fields (see Segment): the
 /// per-axis step counts at the moment the region is entered, the first / end flags and the number of voxels visited in
-/// the region; otherwise they are zero (the counting passes only need the keys).
+/// the region; otherwise they are zero (the counting passes only need the keys).  Segments in regions another replica
+/// owns (MapConst::owner_world > 1) are skipped: every segment carries its own resume state, so dropping some of a
+/// ray's segments does not change what the others do.
 template <typename F>
-__device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, bool with_resume_state, F f)
+__device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, bool with_resume_state, F emit)
 {
+  auto f = [&](uint64_t key, uint32_t w0, uint32_t w1, uint32_t w2) {
+    if (ownsRegion(mc, key))
+    {
+      emit(key, w0, w1, w2);
+    }
+  };
   if (!(rw.flags & kRwValid) || !(rw.flags & kRwWalk))
   {
     return;
@@ -534,6 +542,14 @@ __global__ void __launch_bounds__(kBinThreads)
       end[a] = rays[size_t(ray) * 6 + 3 + a];
     }
     setupRay(mc, start, end, ray_flags, rw);
+    if (mc.owner_world > 1u && (rw.flags & kRwApplySample))
+    {
+      // A sample in a region another replica owns is that replica's to apply.
+      uint64_t sample_key;
+      uint32_t sample_vi;
+      sampleVoxel(mc, rw, sample_key, sample_vi);
+      rw.flags &= ownsRegion(mc, sample_key) ? ~0u : ~unsigned(kRwApplySample);
+    }
     walks[ray] = rw;
     if (!(rw.flags & kRwValid))
     {

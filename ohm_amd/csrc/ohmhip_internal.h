@@ -65,6 +65,11 @@ struct MapConst
   float initial_intensity_cov;
   // TSDF
   float tsdf_max_weight, tsdf_trunc, tsdf_dropoff, tsdf_sparsity;
+  // Region ownership (multi-GPU "owner computes"): with owner_world > 1 the map only integrates the
+  // ray segments and samples which fall in regions regionOwner() assigns to owner_rank.
+  unsigned owner_world;
+  unsigned owner_rank;
+  int owner_shift;
 };
 
 /// Per-ray line-walk parameters: everything ohm/LineWalkCompute.h:260-280 derives once per ray, in fp64, plus the
@@ -151,6 +156,30 @@ __host__ __device__ inline void unpackRegionKey(uint64_t key, int16_t out[3])
   out[0] = int16_t(uint16_t(key & 0xffffu));
   out[1] = int16_t(uint16_t((key >> 16) & 0xffffu));
   out[2] = int16_t(uint16_t((key >> 32) & 0xffffu));
+}
+
+/// Owner of region (rx, ry, rz) among `world` region-partitioned replicas: a hash of the region's block of
+/// 2^shift regions per axis (blocks keep a rank's regions spatially clustered), the same on host and device.
+__host__ __device__ inline uint32_t regionOwner(int rx, int ry, int rz, int shift, uint32_t world)
+{
+  uint32_t h = uint32_t(rx >> shift) * 0x9E3779B1u;
+  h = (h ^ uint32_t(ry >> shift)) * 0x85EBCA77u;
+  h = (h ^ uint32_t(rz >> shift)) * 0xC2B2AE3Du;
+  h ^= h >> 15;
+  h *= 0x27D4EB2Fu;
+  h ^= h >> 13;
+  return h % world;
+}
+
+__host__ __device__ inline bool ownsRegion(const MapConst &mc, uint64_t key)
+{
+  if (mc.owner_world <= 1u)
+  {
+    return true;
+  }
+  int16_t r[3];
+  unpackRegionKey(key, r);
+  return regionOwner(r[0], r[1], r[2], mc.owner_shift, mc.owner_world) == mc.owner_rank;
 }
 
 __host__ __device__ inline uint32_t hashRegionKey(uint64_t key, uint32_t mask)

@@ -1747,6 +1747,38 @@ int ohmhip_map_mark_dirty(ohmhip_map_t m, const uint32_t *slots, size_t count)
   return OHMHIP_OK;
 }
 
+int ohmhip_map_set_region_ownership(ohmhip_map_t m, uint32_t world_size, uint32_t rank, int block_shift)
+{
+  if (!m || (world_size > 1 && rank >= world_size) || block_shift < 0 || block_shift > 15)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  ohmhip_map_sync(m);
+  if (m->slots_committed != 0)
+  {
+    return OHMHIP_ERR_INVALID_ARG;  // regions integrated under another partition would be left behind
+  }
+  m->mc.owner_world = (world_size > 1) ? world_size : 0u;
+  m->mc.owner_rank = (world_size > 1) ? rank : 0u;
+  m->mc.owner_shift = block_shift;
+  return OHMHIP_OK;
+}
+
+int ohmhip_region_owner(const int16_t *keys_xyz, size_t count, int block_shift, uint32_t world_size, uint32_t *owners)
+{
+  if ((count && (!keys_xyz || !owners)) || block_shift < 0 || block_shift > 15)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  for (size_t i = 0; i < count; ++i)
+  {
+    owners[i] = (world_size > 1) ? regionOwner(keys_xyz[i * 3], keys_xyz[i * 3 + 1], keys_xyz[i * 3 + 2], block_shift,
+                                               world_size)
+                                 : 0u;
+  }
+  return OHMHIP_OK;
+}
+
 int ohmhip_map_line_keys(ohmhip_map_t m, const double *lines, size_t line_count, uint32_t max_keys_per_line,
                          void *keys_out, uint32_t *counts_out)
 {

@@ -15,6 +15,13 @@ shards exactly when no min/max clamp engages between the shards' updates of a vo
 they saturate).  Where clamps interact the merged value is the order-free sum, which is the standard map-merge
 semantic, not the sequential one.  NDT / TSDF layers are not additive: replicas only.
 
+Exact alternative, all map types -- "owner computes" (`region_owner`, `gather_rays`, `OwnerComputesIntegrator`): regions
+are dealt to ranks by a block hash, every rank sees the same ray stream (an all-gather of the ranks' batches, 48 B per
+ray) and integrates only the ray segments and samples inside its own regions (`GpuMap.setRegionOwnership`).  No voxel
+ever crosses a link and the union of the ranks' regions is bit-identical to one map integrating the gathered stream,
+because a voxel's update sequence depends only on the rays that reach it, in order.  The line-walk work (the dominant
+kernel) is partitioned, the per-ray front half (set-up and binning) is repeated on every rank.
+
 The functions below are backend agnostic (any torch device / process group) so the protocol itself is covered by
 world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py).
 """
@@ -80,6 +87,67 @@ def merge_occupancy_deltas(base_tiles, local_tiles, min_value, max_value, group=
     merged = torch.clamp(base0 + payload[0], min=min_value, max=max_value)
     observed = payload[1] > 0
     return torch.where(observed, merged, torch.full_like(merged, inf))
+
+
+def region_owner(keys, world_size, block_shift=0):
+    """Owner rank of each int16 (n, 3) region key: the library's own rule (ohmhip_region_owner), so host code, tests
+    and kernels cannot disagree."""
+    import ctypes as C
+    from . import _lib as L
+    keys = np.ascontiguousarray(keys, dtype=np.int16).reshape(-1, 3)
+    owners = np.zeros(len(keys), dtype=np.uint32)
+    L.check(L.lib.ohmhip_region_owner(keys.ctypes.data, len(keys), int(block_shift), int(world_size),
+                                      owners.ctypes.data), "region_owner")
+    return owners
+
+
+def gather_rays(local_rays, group=None):
+    """All-gather the ranks' ray batches into ONE stream ordered by rank (then by ray): torch tensor (2N_r, 3) float64 on
+    any device -> (sum_r 2N_r, 3) on the same device.  Ranks may hold different counts (padded to the maximum for the
+    collective).  RCCL all_gather_into_tensor for device tensors, gloo on CPU."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    local = local_rays.reshape(-1, 3).contiguous()
+    counts = torch.zeros(world, dtype=torch.int64, device=local.device)
+    counts[dist.get_rank(group)] = local.shape[0]
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    counts = [int(c) for c in counts.tolist()]
+    longest = max(counts)
+    if longest == 0:
+        return local
+    padded = torch.zeros((longest, 3), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    out = torch.empty((world * longest, 3), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    if all(c == longest for c in counts):
+        return out
+    return torch.cat([out[r * longest:r * longest + counts[r]] for r in range(world)])
+
+
+class OwnerComputesIntegrator:
+    """Exact multi-rank integration: usage on every rank
+        integ = OwnerComputesIntegrator(gpu_map); integ.integrateRays(local_rays_tensor, flags)
+    `gpu_map` (GpuMap / GpuNdtMap / GpuTsdfMap) must be empty; it ends up holding this rank's regions of the map a
+    single device would have built from the rank-ordered stream of all ranks' batches."""
+
+    def __init__(self, gpu_map, group=None, block_shift=0):
+        import torch.distributed as dist
+        self.gpu_map = gpu_map
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        gpu_map.setRegionOwnership(self.world, self.rank, block_shift)
+
+    def integrateRays(self, local_rays, ray_update_flags=0):
+        import torch
+        stream = gather_rays(local_rays, self.group)
+        if stream.is_cuda:
+            torch.cuda.current_stream().synchronize()  # the map integrates on its own HIP stream
+            self.gpu_map.wait()                        # the previous gathered batch may still be being read
+            self._inflight = stream                    # keep the device memory alive while the batch runs
+            return self.gpu_map.integrateRaysDevice(stream.data_ptr(), stream.shape[0], ray_update_flags)
+        return self.gpu_map.integrateRays(stream.numpy(), ray_update_flags=ray_update_flags)
 
 
 class _DeviceArray:

@@ -316,6 +316,13 @@ class GpuMap(RayMapper):
         L.check(L.lib.ohmhip_map_clear_dirty(self._handle), "clear_dirty")
         self.wait()
 
+    def setRegionOwnership(self, world_size, rank, block_shift=0):
+        """Owner-computes multi-GPU mode (include/ohmhip.h: ohmhip_map_set_region_ownership): integrate only what falls
+        in the regions `rank` owns among `world_size` region-partitioned maps.  Call before the first integrateRays."""
+        L.check(L.lib.ohmhip_map_set_region_ownership(self._handle, int(world_size), int(rank), int(block_shift)),
+                "setRegionOwnership")
+        self._ownership = (int(world_size), int(rank), int(block_shift))
+
     def lineKeys(self, lines, max_keys_per_line=1024):
         """LineKeysQueryGpu equivalent: voxel keys along each query line (start/end pairs, (2N, 3) float64).
         Returns (keys, counts): keys is (N, max_keys, 10) uint8 viewed as int16 region[3] + uint8 voxel[4]."""

@@ -288,6 +288,13 @@ public:
     ohmhip_map_last_stats(handle_, &st);
     return st;
   }
+  /// Not in the reference (single device): owner-computes multi-GPU mode, see ohmhip_map_set_region_ownership.  The
+  /// map integrates only what falls in the regions @p rank owns among @p world_size maps fed the same ray stream.
+  void setRegionOwnership(unsigned world_size, unsigned rank, int block_shift = 0)
+  {
+    OHMHIP_GPUAPICHECK(ohmhip_map_set_region_ownership(handle_, world_size, rank, block_shift));
+  }
+
   ohmhip_map_t handle() const { return handle_; }
 
 protected:

@@ -48,6 +48,20 @@ def main():
             fin = np.isfinite(exp)
             assert np.allclose(got[fin], exp[fin], rtol=1e-6, atol=1e-6)
             checked += int(fin.sum())
+        # Owner-computes integrator on device tensors: RCCL all-gather of the ray batch, then the map reads the gathered
+        # stream straight from the torch allocation (world 1 here: the filter is off, the plumbing is what runs).
+        map2 = OccupancyMap(0.1)
+        gm2 = GpuMap(map2)
+        integ = D.OwnerComputesIntegrator(gm2)
+        d_rays = torch.from_numpy(rays).to("cuda")
+        assert integ.integrateRays(d_rays) == rays.shape[0]
+        assert integ.integrateRays(d_rays[:4000]) == 4000
+        gm2.syncVoxels()
+        om2 = OracleMap(0.1)
+        om2.integrate_occupancy(rays)
+        om2.integrate_occupancy(rays[:4000])
+        for key, layers in om2.chunks().items():
+            assert np.array_equal(map2.chunks[key]["occupancy"].view(np.uint32), layers["occupancy"].view(np.uint32))
         print("MERGE_OK", n, checked)
     finally:
         dist.destroy_process_group()

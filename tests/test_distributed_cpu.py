@@ -106,3 +106,89 @@ def test_two_rank_gloo_merge_matches_additive_rule_and_sequential_where_unclampe
         assert np.allclose(m0[i][safe], st[safe], rtol=1e-5, atol=1e-5)
         unclamped_checked += int(miss_only.sum())
     assert unclamped_checked > 100
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Owner-computes (exact) mode: region ownership rule, ray all-gather, partition == single map.
+# ---------------------------------------------------------------------------------------------------------------------
+def _owner_formula(keys, world, shift):
+    """numpy restatement of regionOwner() (ohm_amd/csrc/ohmhip_internal.h) to pin the exported C function."""
+    k = np.asarray(keys, dtype=np.int64) >> shift
+    m32 = np.uint64(0xFFFFFFFF)
+    x, y, z = [(k[:, a].astype(np.int64) & 0xFFFFFFFF).astype(np.uint64) for a in range(3)]
+    h = (x * np.uint64(0x9E3779B1)) & m32
+    h = ((h ^ y) * np.uint64(0x85EBCA77)) & m32
+    h = ((h ^ z) * np.uint64(0xC2B2AE3D)) & m32
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x27D4EB2F)) & m32
+    h ^= h >> np.uint64(13)
+    return (h % np.uint64(world)).astype(np.uint32)
+
+
+def test_region_owner_rule():
+    rng = np.random.default_rng(5)
+    keys = rng.integers(-32768, 32768, size=(5000, 3)).astype(np.int16)
+    keys[:6] = [[0, 0, 0], [-1, -1, -1], [32767, -32768, 5], [1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    for world in (2, 3, 8):
+        for shift in (0, 1, 3):
+            owners = D.region_owner(keys, world, shift)
+            assert owners.max() < world
+            assert np.array_equal(owners, _owner_formula(keys, world, shift))
+            assert len(np.unique(owners)) == world
+    assert np.all(D.region_owner(keys, 1, 0) == 0)
+    # blocks of 2^shift regions share an owner
+    base = np.array([[4, -6, 2]], dtype=np.int16)
+    block = base + np.array([[dx, dy, dz] for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)], dtype=np.int16)
+    assert len(np.unique(D.region_owner(block, 8, 1))) == 1
+
+
+def _owner_worker(rank, world, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import OracleMap
+        # ranks hold different numbers of rays; two rounds
+        chunks = {}
+        om = OracleMap(0.1)
+        for rnd in range(2):
+            n = 1500 + 700 * rank + 100 * rnd
+            local = synth.rays_c0(n=n, origin=(0.05 + 4.0 * rank, 0.05, 0.05), length=5.0, seed=950 + 10 * rnd + rank)
+            stream = D.gather_rays(torch.from_numpy(local)).numpy()
+            np.save(os.path.join(result_dir, f"stream_{rnd}_{rank}.npy"), stream)
+            np.save(os.path.join(result_dir, f"local_{rnd}_{rank}.npy"), local)
+            om.integrate_occupancy(stream)
+        # the CPU stand-in for a map with the ownership filter: integrate the stream, keep the regions this rank owns
+        all_chunks = om.chunks()
+        keys = np.array(sorted(all_chunks.keys()), dtype=np.int16).reshape(-1, 3)
+        mine = D.region_owner(keys, world, 0) == rank
+        np.save(os.path.join(result_dir, f"keys_{rank}.npy"), keys[mine])
+        np.save(os.path.join(result_dir, f"occ_{rank}.npy"),
+                np.stack([all_chunks[tuple(int(v) for v in k)]["occupancy"] for k in keys[mine]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_owner_computes_stream_and_partition(tmp_path):
+    world = 2
+    mp.spawn(_owner_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from oracle.oracle import OracleMap
+    seq = OracleMap(0.1)
+    for rnd in range(2):
+        streams = [np.load(tmp_path / f"stream_{rnd}_{r}.npy") for r in range(world)]
+        locals_ = [np.load(tmp_path / f"local_{rnd}_{r}.npy") for r in range(world)]
+        expect = np.concatenate(locals_)  # rank order, then ray order; ragged counts
+        for s in streams:
+            assert np.array_equal(s, expect)
+        seq.integrate_occupancy(expect)
+    seq_chunks = seq.chunks()
+    seen = set()
+    for r in range(world):
+        keys, occ = np.load(tmp_path / f"keys_{r}.npy"), np.load(tmp_path / f"occ_{r}.npy")
+        assert len(keys) > 0
+        for k, tile in zip(keys, occ):
+            key = tuple(int(v) for v in k)
+            assert key not in seen
+            seen.add(key)
+            assert np.array_equal(tile.view(np.uint32), seq_chunks[key]["occupancy"].view(np.uint32))
+    assert seen == set(seq_chunks.keys())
