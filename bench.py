@@ -213,17 +213,42 @@ def main():
         m4 = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
         g4 = ohm_amd.GpuMap(m4, gpu_mem_size=8 << 30)
         g4.integrateRays(rays)
+        g4.integrateRays(rays)  # both staging slots allocated
         g4.syncVoxels()
         t1 = time.perf_counter()
         g4.integrateRays(rays)
         t2 = time.perf_counter()
         g4.syncVoxels()
         t3 = time.perf_counter()
+        n_host = 6
+        for _ in range(n_host):  # steady state: batch N+1 staged and uploaded while batch N runs
+            g4.integrateRays(rays)
+        g4.wait()
+        t4 = time.perf_counter()
         extra["C1_host_end_to_end"] = {"rays_per_s_integrate": n_rays / (t2 - t1),
                                        "rays_per_s_with_sync_voxels": n_rays / (t3 - t1),
+                                       "rays_per_s_back_to_back": n_host * n_rays / (t4 - t3),
                                        "integrate_ms": (t2 - t1) * 1e3, "sync_voxels_ms": (t3 - t2) * 1e3,
                                        "note": "host-pointer rays (48 B/ray over PCIe) + all modified regions copied back"}
         g4.close()
+        # the reference tools' pattern: 4096-ray host batches, as presented and with batch coalescing
+        host_small = {}
+        for label, min_rays in (("as_presented", 0), ("coalesced_64k", 1 << 16)):
+            m6 = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+            g6 = ohm_amd.GpuMap(m6, gpu_mem_size=8 << 30)
+            g6.integrateRays(rays)
+            g6.integrateRays(rays)
+            g6.wait()
+            g6.setBatchCoalescing(min_rays)
+            n_calls = 128
+            t1 = time.perf_counter()
+            for b in range(n_calls):
+                g6.integrateRays(rays[b * 2 * small:(b + 1) * 2 * small])
+            g6.wait()
+            dt = time.perf_counter() - t1
+            host_small[label] = {"rays_per_s": n_calls * small / dt, "ms_per_call": dt * 1e3 / n_calls}
+            g6.close()
+        extra["C1_4096_ray_host_batches"] = host_small
         # (iii) exact multi-GPU mode ("owner computes"): what ONE rank of an 8-way region partition spends
         # on the full C1 stream -- the per-ray front half is repeated on every rank, the line walk is partitioned.
         per_rank = []

@@ -191,10 +191,20 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config); /* Gp
 int ohmhip_map_destroy(ohmhip_map_t map);
 
 /* GpuMap::integrateRays (ohmgpu/GpuMap.cpp:416, 540-875): rays = element_count dvec3 (origin, sample pairs).
- * Host-pointer form stages through pinned memory with hipMemcpyAsync; returns after enqueue (like the reference the
- * call is asynchronous; ohmhip_map_sync / any read is the fence).  *integrated = points accepted (2 per ray). */
+ * Host-pointer form stages through one of two pinned blocks and uploads on a side stream, so batch N+1 is copied while
+ * batch N runs; returns after enqueue (like the reference the call is asynchronous; ohmhip_map_sync / any read is
+ * the fence).  *integrated = points accepted (2 per ray). */
 int ohmhip_map_integrate_rays(ohmhip_map_t map, const double *rays, size_t element_count, const float *intensities,
                               const double *timestamps, unsigned ray_flags, size_t *integrated);
+/* Small host batches (the reference tools present 4096 rays per call, ohmapp/OhmAppGpu.cpp:187-207) cost a full
+ * pipeline pass each.  With min_rays > 0, consecutive host-pointer batches with the same flags and the same optional
+ * arrays are collected in the pinned staging block and run as ONE device batch once min_rays have accumulated -- or as
+ * soon as anything observes the map (sync, stats, region reads, a device-pointer batch ...).  The result is the one
+ * the separate calls give: the CPU mappers integrate ray by ray, so call boundaries carry no meaning, except for the
+ * traversal layer (its exit range is carried within a call): maps with that layer never merge batches.  A deferred
+ * call reports *integrated = element_count; what the ray filter rejected shows in ohmhip_map_last_stats once the batch
+ * has run.  0 (the default) launches every call's batch in that call. */
+int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
 /* Same with rays (and optional intensities/timestamps) already resident in device memory. */
 int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, size_t element_count,
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,

@@ -646,7 +646,8 @@ __global__ void __launch_bounds__(kBinThreads)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
   k_plan(RegionTable rt, BatchScratch bs, Chunk *__restrict__ chunks, uint32_t chunk_capacity,
-         uint32_t chunk_segments)
+         uint32_t chunk_segments, BatchInfo *__restrict__ host_info, BatchInfo *__restrict__ next_info,
+         uint32_t *__restrict__ event_count)
 {
   constexpr uint32_t kSizeClasses = 32;  // chunk size classes for the largest-first order (class = 32 * size / max)
   constexpr int kRounds = 4;             // touched regions held in registers between the two passes: 4 x 1024
@@ -891,12 +892,21 @@ __global__ void __launch_bounds__(1024)
   }
   if (tid == 0)
   {
-    bs.info->n_segments = s_seg_base;
-    bs.info->n_chunks = s_chk_base;
-    bs.info->n_slots = *rt.n_slots;
-    bs.info->n_hits = s_hit_base;
-    bs.info->max_region_hits = s_hit_max;
-    bs.info->n_hit_regions = s_hclass[32];
+    BatchInfo out = *bs.info;  // visits, rays, touched regions, errors: accumulated by k_ray_setup
+    out.n_segments = s_seg_base;
+    out.n_chunks = s_chk_base;
+    out.n_slots = *rt.n_slots;
+    out.n_hits = s_hit_base;
+    out.max_region_hits = s_hit_max;
+    out.n_hit_regions = s_hclass[32];
+    *bs.info = out;
+    // Housekeeping that would otherwise be separate copy / fill launches on the batch's critical path: the host's copy
+    // of the summary goes straight to pinned memory, the next batch's summary and the walk's counters start at zero.
+    *host_info = out;
+    *next_info = BatchInfo{};
+    event_count[0] = 0;  // deferred events
+    event_count[1] = 0;  // walk chunk cursor
+    __threadfence_system();
   }
 }
 
@@ -2137,8 +2147,13 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 __global__ void __launch_bounds__(256)
   k_flagged_events(BatchScratch bs, const unsigned long long *__restrict__ events, uint32_t event_capacity,
                    const uint32_t *__restrict__ event_count, const unsigned long long *__restrict__ sorted_hits,
-                   uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts, int region_voxels)
+                   uint32_t *__restrict__ miss_counts, uint32_t *__restrict__ interval_counts, int region_voxels,
+                   uint32_t *__restrict__ host_event_count)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    *host_event_count = *event_count;  // pinned: sizes the next batch's event list
+  }
   const uint32_t n = min(*event_count, event_capacity);
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)

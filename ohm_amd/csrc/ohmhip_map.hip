@@ -96,14 +96,17 @@ struct ohmhip_map_s
   uint32_t *d_seg_count = nullptr, *d_seg_cursor = nullptr, *d_seg_offset = nullptr, *d_touched_flag = nullptr,
            *d_touched = nullptr;
   uint32_t *d_voxel_first_hit = nullptr, *d_hit_begin = nullptr, *d_hit_end = nullptr, *d_dirty = nullptr;
-  BatchInfo *d_info = nullptr;
-  BatchInfo *h_info = nullptr;  ///< pinned
+  BatchInfo *d_info = nullptr;   ///< two summaries used alternately: k_plan of one batch zeroes the next batch's
+  BatchInfo *h_info = nullptr;   ///< pinned, device visible: [0] batch summary (written by k_plan), [1] event count
+  BatchInfo *h_info_dev = nullptr;  ///< device address of h_info
+  uint32_t info_index = 0;
+  bool info_clean = false;       ///< d_info[info_index ^ 1] was zeroed by the previous batch's k_plan
   uint32_t *d_miss_counts = nullptr;
   uint32_t *d_hit_mask = nullptr;
   Chunk *d_chunks = nullptr;
   uint32_t chunk_capacity = 0;
 
-  DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, rays_dev, intens_dev, times_dev, events;
+  DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, events;
   DevBuf wg_regions, wg_region_count, group_heads;
   uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
@@ -112,14 +115,34 @@ struct ohmhip_map_s
   uint32_t event_demand = 0;
   bool spec_bucket_ok = false;  ///< the previous occupancy batch used the per-region sample sort: bin speculatively
   double segments_per_ray = 10.0;            ///< running estimate (previous batch) used to size the next batch's chunks
+  uint32_t min_chunk_segments = 2048;  ///< tunable (OHMHIP_MIN_CHUNK_SEGMENTS): floor of the small-batch chunk size (two rounds of the walk workgroup's 1024 lanes)
   uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= kMaxChunkSegments (15-bit LDS counters)
   /// OHMHIP_DEBUG_FLAGS (development only): 16 = walk kernel refills lanes but does not walk (timing experiments,
   /// breaks results); 64 = per-chunk timing trace of the walk kernel (OHMHIP_DEBUG_TRACE=<file>, scripts/
   /// analyse_trace.py); 128 = iteration / visit / refill counters (hot-address atomics: distorts timing).
   unsigned debug_flags = 0;
   int refill_min_idle = kRefillMinIdle;      ///< tunable (OHMHIP_REFILL_MIN_IDLE)  ///< events the previous batch produced (sizes the next batch's list)
-  void *h_stage = nullptr;  ///< pinned staging for host rays / region copies
+  void *h_stage = nullptr;  ///< pinned staging for region copies
   size_t h_stage_bytes = 0;
+
+  /// Host-pointer ray batches go through one of two staging slots (pinned host block + device copies), so the host
+  /// copy and the H2D transfer of batch N+1 overlap the device work of batch N.  With coalescing on, consecutive small
+  /// batches with the same flags accumulate in the filling slot and run as one device batch.
+  struct RaySlot
+  {
+    char *h = nullptr;            ///< pinned: capacity x 48 B rays, then capacity x 8 B timestamps, then x 4 B intensities
+    size_t capacity = 0;          ///< rays
+    DevBuf d_rays, d_times, d_intens;
+    hipEvent_t uploaded = nullptr;  ///< H2D copies done (copy stream)
+    hipEvent_t done = nullptr;      ///< the batch reading the device copies has finished (compute stream)
+    bool in_flight = false;
+  } ray_slots[2];
+  int fill_slot = 0;
+  size_t pending_rays = 0;
+  size_t pending_calls = 0;
+  unsigned pending_flags = 0;
+  bool pending_intens = false, pending_times = false;
+  size_t coalesce_min_rays = 0;  ///< 0: every host batch is launched by the call that presents it
 
   // host mirror of the region table
   std::unordered_map<uint64_t, uint32_t> region_slots;
@@ -157,7 +180,7 @@ BatchScratch batchScratch(ohmhip_map_t m)
   bs.hit_begin = m->d_hit_begin;
   bs.hit_end = m->d_hit_end;
   bs.dirty = m->d_dirty;
-  bs.info = m->d_info;
+  bs.info = m->d_info + m->info_index;
   bs.wg_regions = static_cast<WgRegion *>(m->wg_regions.ptr);
   bs.wg_region_count = static_cast<uint32_t *>(m->wg_region_count.ptr);
   return bs;
@@ -457,6 +480,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
 {
   hipStream_t s = m->stream;
   hipEvent_t *tev = m->tev[m->batch_seq % kTimingRing];
+  // This batch's summary block: the other one of the pair, zeroed by the previous batch's k_plan if that ran.
+  m->info_index ^= 1u;
+  const bool info_clean = m->info_clean;
+  m->info_clean = false;
   const uint32_t ray_blocks = (n_rays + 255) / 256;
   // Binning launch shape: 1024 rays per 512-thread workgroup for large batches; small batches use smaller workgroups
   // with as many rays as threads so they still cover the CUs.
@@ -474,7 +501,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   // from the previous batch's segments per ray; results do not depend on it).
   const uint64_t expected_segments = uint64_t(double(n_rays) * m->segments_per_ray);
   uint32_t batch_chunk_segments = m->chunk_segments;
-  while (batch_chunk_segments > 512 && expected_segments / batch_chunk_segments < 3ull * m->walk_workgroups)
+  while (batch_chunk_segments > m->min_chunk_segments &&
+         expected_segments / batch_chunk_segments < 3ull * m->walk_workgroups)
   {
     batch_chunk_segments /= 2;
   }
@@ -517,13 +545,17 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
 
   for (int attempt = 0; attempt < 8; ++attempt)
   {
-    OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, sizeof(BatchInfo), s));
+    if (attempt > 0 || !info_clean)
+    {
+      OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), s));
+    }
     OHMHIP_CHECK(hipEventRecord(tev[0], s));
     hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
                        n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr), bin_rays_per_block, bin_tab_mask);
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
-                       m->chunk_capacity, batch_chunk_segments);
-    OHMHIP_CHECK(hipMemcpyAsync(m->h_info, m->d_info, sizeof(BatchInfo), hipMemcpyDeviceToHost, s));
+                       m->chunk_capacity, batch_chunk_segments, m->h_info_dev, m->d_info + (m->info_index ^ 1u),
+                       m->d_event_count);
+    m->info_clean = true;
     OHMHIP_CHECK(hipEventRecord(m->ev[7], s));
     // The host needs the batch summary (segment count, sample distribution, pool state) before it can size and launch
     // the rest -- a round trip during which the device would idle.  In steady state (occupancy, previous batch sorted
@@ -655,7 +687,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     {
       for (int walk_attempt = 0; walk_attempt < 4; ++walk_attempt)
       {
-        OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, 2 * sizeof(uint32_t), s));
+        if (walk_attempt > 0)
+        {
+          OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, 2 * sizeof(uint32_t), s));  // (k_plan zeroed them for the first)
+        }
         WalkArgs wa;
         wa.mc = m->mc;
         wa.bs = batchScratch(m);
@@ -708,8 +743,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         {
           hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m), events, event_capacity,
                              m->d_event_count, sorted, m->d_miss_counts,
-                             static_cast<uint32_t *>(m->interval_counts.ptr), m->mc.region_voxels);
-          OHMHIP_CHECK(hipMemcpyAsync(&m->h_info[1], m->d_event_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                             static_cast<uint32_t *>(m->interval_counts.ptr), m->mc.region_voxels,
+                             reinterpret_cast<uint32_t *>(m->h_info_dev + 1));
           break;
         }
         // NDT / TSDF: the host needs the event count to size the sort; an overflowing list is re-walked.
@@ -733,7 +768,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         events = keys_a + n_rays;
         event_capacity = uint32_t(std::min<size_t>(total - n_rays, 0xfffffff0u - n_rays));
         // k_ray_bin also fills the segment buckets: only the sample keys are rewritten here (cursors already reset).
-        OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, sizeof(BatchInfo), s));
+        OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), s));
         hipLaunchKernelGGL(k_rekey_samples, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
                            static_cast<const RayWalk *>(m->walks.ptr), n_rays, keys_a, ray_shift);
         if (walk_attempt == 3)
@@ -834,6 +869,112 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   }
   return OHMHIP_ERR_CAPACITY;
 }
+
+/// memcpy split over a few host threads for large blocks (a single core copies ~10 GB/s, PCIe Gen5 moves ~55).
+void parallelCopy(void *dst, const void *src, size_t bytes)
+{
+  constexpr size_t kPerThread = size_t(4) << 20;
+  const unsigned n = unsigned(std::min<size_t>(4, bytes / kPerThread));
+  if (n <= 1)
+  {
+    std::memcpy(dst, src, bytes);
+    return;
+  }
+  std::vector<std::thread> workers;
+  const size_t part = (bytes / n + 63) & ~size_t(63);
+  for (unsigned t = 1; t < n; ++t)
+  {
+    const size_t off = std::min(bytes, t * part);
+    const size_t len = std::min(bytes - off, part);
+    workers.emplace_back([=] { std::memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len); });
+  }
+  std::memcpy(dst, src, std::min(bytes, part));
+  for (auto &w : workers)
+  {
+    w.join();
+  }
+}
+
+inline char *slotRays(ohmhip_map_s::RaySlot &sl) { return sl.h; }
+inline char *slotTimes(ohmhip_map_s::RaySlot &sl) { return sl.h + sl.capacity * 48; }
+inline char *slotIntens(ohmhip_map_s::RaySlot &sl) { return sl.h + sl.capacity * 56; }
+
+/// Make room for `rays` rays in the filling slot, keeping what is pending in it.
+int growRaySlot(ohmhip_map_t m, ohmhip_map_s::RaySlot &sl, size_t rays)
+{
+  if (rays <= sl.capacity)
+  {
+    return OHMHIP_OK;
+  }
+  ohmhip_map_s::RaySlot grown;
+  grown.capacity = std::max<size_t>(rays + rays / 4, 4096);
+  void *block = nullptr;
+  OHMHIP_CHECK(hipHostMalloc(&block, grown.capacity * 60, hipHostMallocDefault));
+  grown.h = static_cast<char *>(block);
+  if (m->pending_rays)
+  {
+    std::memcpy(slotRays(grown), slotRays(sl), m->pending_rays * 48);
+    std::memcpy(slotTimes(grown), slotTimes(sl), m->pending_rays * 8);
+    std::memcpy(slotIntens(grown), slotIntens(sl), m->pending_rays * 4);
+  }
+  if (sl.h)
+  {
+    OHMHIP_CHECK(hipHostFree(sl.h));
+  }
+  sl.h = grown.h;
+  sl.capacity = grown.capacity;
+  return OHMHIP_OK;
+}
+
+int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_count, const float *d_intensities,
+                        const double *d_timestamps, unsigned ray_flags, size_t *integrated);
+
+/// Launch what the filling slot holds: H2D on the copy stream, the batch on the compute stream behind it.
+int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
+{
+  const size_t n = m->pending_rays;
+  if (n == 0)
+  {
+    return OHMHIP_OK;
+  }
+  ohmhip_map_s::RaySlot &sl = m->ray_slots[m->fill_slot];
+  m->pending_rays = 0;
+  m->pending_calls = 0;
+  OHMHIP_CHECK(sl.d_rays.ensure(n * 48, false, m->stream));
+  OHMHIP_CHECK(hipMemcpyAsync(sl.d_rays.ptr, slotRays(sl), n * 48, hipMemcpyHostToDevice, m->copy_stream));
+  const double *d_ts = nullptr;
+  const float *d_int = nullptr;
+  if (m->pending_times)
+  {
+    OHMHIP_CHECK(sl.d_times.ensure(n * 8, false, m->stream));
+    OHMHIP_CHECK(hipMemcpyAsync(sl.d_times.ptr, slotTimes(sl), n * 8, hipMemcpyHostToDevice, m->copy_stream));
+    d_ts = static_cast<const double *>(sl.d_times.ptr);
+  }
+  if (m->pending_intens)
+  {
+    OHMHIP_CHECK(sl.d_intens.ensure(n * 4, false, m->stream));
+    OHMHIP_CHECK(hipMemcpyAsync(sl.d_intens.ptr, slotIntens(sl), n * 4, hipMemcpyHostToDevice, m->copy_stream));
+    d_int = static_cast<const float *>(sl.d_intens.ptr);
+  }
+  OHMHIP_CHECK(hipEventRecord(sl.uploaded, m->copy_stream));
+  OHMHIP_CHECK(hipStreamWaitEvent(m->stream, sl.uploaded, 0));
+  const int err = integrateRaysDevice(m, static_cast<const double *>(sl.d_rays.ptr), n * 2, d_int, d_ts,
+                                      m->pending_flags, integrated);
+  OHMHIP_CHECK(hipEventRecord(sl.done, m->stream));
+  sl.in_flight = true;
+  m->fill_slot ^= 1;
+  return err;
+}
+
+#define OHMHIP_SETTLE(m)                          \
+  if (m)                                          \
+  {                                               \
+    const int settle_err_ = flushPendingRays(m);  \
+    if (settle_err_ != OHMHIP_OK)                 \
+    {                                             \
+      return settle_err_;                         \
+    }                                             \
+  }
 }  // namespace
 
 extern "C" {
@@ -982,11 +1123,19 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
       }
     }
   }
+  for (auto &sl : m->ray_slots)
+  {
+    if ((err = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming)) != 0 ||
+        (err = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != 0)
+    {
+      return fail(err);
+    }
+  }
   if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_n_slots), sizeof(uint32_t))) != 0)
   {
     return fail(err);
   }
-  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_info), sizeof(BatchInfo))) != 0)
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_info), 2 * sizeof(BatchInfo))) != 0)
   {
     return fail(err);
   }
@@ -999,10 +1148,13 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
     return fail(err);
   }
   (void)hipMemset(m->d_dbg, 0, kDbgWords * sizeof(unsigned long long));
-  if ((err = hipHostMalloc(reinterpret_cast<void **>(&m->h_info), 2 * sizeof(BatchInfo), hipHostMallocDefault)) != 0)
+  if ((err = hipHostMalloc(reinterpret_cast<void **>(&m->h_info), 2 * sizeof(BatchInfo),
+                           hipHostMallocMapped | hipHostMallocCoherent)) != 0 ||
+      (err = hipHostGetDevicePointer(reinterpret_cast<void **>(&m->h_info_dev), m->h_info, 0)) != 0)
   {
     return fail(err);
   }
+  std::memset(m->h_info, 0, 2 * sizeof(BatchInfo));
 
   uint32_t capacity = m->config.region_capacity;
   if (capacity == 0)
@@ -1026,6 +1178,10 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   if (const char *env = std::getenv("OHMHIP_CHUNK_SEGMENTS"))
   {
     m->chunk_segments = uint32_t(std::max(64, std::min(int(kMaxChunkSegments), std::atoi(env))));
+  }
+  if (const char *env = std::getenv("OHMHIP_MIN_CHUNK_SEGMENTS"))
+  {
+    m->min_chunk_segments = uint32_t(std::max(64, std::min(int(kMaxChunkSegments), std::atoi(env))));
   }
   // The walk kernel keeps a region's count tile, the staged samples and the chunk's segment order in LDS (about
   // 150 KiB of the CU's 160 KiB for 32^3 regions): the chunk size gives way if the region tile is large.
@@ -1078,9 +1234,6 @@ int ohmhip_map_destroy(ohmhip_map_t m)
   m->interval_counts.release();
   m->segments.release();
   m->sort_temp.release();
-  m->rays_dev.release();
-  m->intens_dev.release();
-  m->times_dev.release();
   m->events.release();
   m->wg_regions.release();
   m->wg_region_count.release();
@@ -1104,6 +1257,24 @@ int ohmhip_map_destroy(ohmhip_map_t m)
   if (m->h_stage)
   {
     (void)hipHostFree(m->h_stage);
+  }
+  for (auto &sl : m->ray_slots)
+  {
+    sl.d_rays.release();
+    sl.d_times.release();
+    sl.d_intens.release();
+    if (sl.h)
+    {
+      (void)hipHostFree(sl.h);
+    }
+    if (sl.uploaded)
+    {
+      (void)hipEventDestroy(sl.uploaded);
+    }
+    if (sl.done)
+    {
+      (void)hipEventDestroy(sl.done);
+    }
   }
   for (auto &e : m->ev)
   {
@@ -1134,9 +1305,12 @@ int ohmhip_map_destroy(ohmhip_map_t m)
   return OHMHIP_OK;
 }
 
-int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_t element_count,
-                                     const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
-                                     size_t *integrated)
+}  // extern "C"
+
+namespace
+{
+int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_count, const float *d_intensities,
+                        const double *d_timestamps, unsigned ray_flags, size_t *integrated)
 {
   if (integrated)
   {
@@ -1209,6 +1383,21 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
   }
   return err;
 }
+}  // namespace
+
+extern "C" {
+
+int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_t element_count,
+                                     const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
+                                     size_t *integrated)
+{
+  if (integrated)
+  {
+    *integrated = 0;
+  }
+  OHMHIP_SETTLE(m);  // batches presented earlier through the host entry point come first
+  return integrateRaysDevice(m, d_rays, element_count, d_intensities, d_timestamps, ray_flags, integrated);
+}
 
 int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
                               const double *timestamps, unsigned ray_flags, size_t *integrated)
@@ -1221,43 +1410,94 @@ int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
+  if (ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED)
+  {
+    return OHMHIP_ERR_UNSUPPORTED;
+  }
   const size_t n_rays = element_count / 2;
   if (n_rays == 0)
   {
     return OHMHIP_OK;
   }
-  hipStream_t s = m->stream;
-  const size_t ray_bytes = n_rays * 6 * sizeof(double);
-  OHMHIP_CHECK(m->rays_dev.ensure(ray_bytes, false, s));
-  // The previous batch may still be reading the staging buffer's device copy; the stream orders the copies.
-  int err = ensureStage(m, ray_bytes);
-  if (err)
+  if (n_rays >= (size_t(1) << (kHitRayBits - 1)))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  // Batches only share a device launch when they are integrated the same way; the traversal layer's exit range is
+  // carried from ray to ray WITHIN one call (secondary_device.h: lastExitRange), so its batches are never merged.
+  const bool coalesce = m->coalesce_min_rays > 0 && !m->layers[OHMHIP_LID_TRAVERSAL];
+  if (m->pending_rays &&
+      (!coalesce || m->pending_flags != ray_flags || m->pending_intens != (intensities != nullptr) ||
+       m->pending_times != (timestamps != nullptr) || m->pending_rays + n_rays >= (size_t(1) << (kHitRayBits - 1))))
+  {
+    const int err = flushPendingRays(m);
+    if (err != OHMHIP_OK)
+    {
+      return err;
+    }
+  }
+  ohmhip_map_s::RaySlot &sl = m->ray_slots[m->fill_slot];
+  if (m->pending_rays == 0 && sl.in_flight)
+  {
+    OHMHIP_CHECK(hipEventSynchronize(sl.done));  // the batch before last still owns this slot's buffers
+    sl.in_flight = false;
+  }
+  int err = growRaySlot(m, sl, m->pending_rays + n_rays);
+  if (err != OHMHIP_OK)
   {
     return err;
   }
-  OHMHIP_CHECK(hipStreamSynchronize(s));  // staging buffer reuse fence
-  std::memcpy(m->h_stage, rays, ray_bytes);
-  OHMHIP_CHECK(hipMemcpyAsync(m->rays_dev.ptr, m->h_stage, ray_bytes, hipMemcpyHostToDevice, s));
-  const float *d_int = nullptr;
-  const double *d_ts = nullptr;
-  if (intensities)
-  {
-    OHMHIP_CHECK(m->intens_dev.ensure(n_rays * sizeof(float), false, s));
-    OHMHIP_CHECK(hipMemcpyAsync(m->intens_dev.ptr, intensities, n_rays * sizeof(float), hipMemcpyHostToDevice, s));
-    d_int = static_cast<const float *>(m->intens_dev.ptr);
-  }
+  parallelCopy(slotRays(sl) + m->pending_rays * 48, rays, n_rays * 48);
   if (timestamps)
   {
-    OHMHIP_CHECK(m->times_dev.ensure(n_rays * sizeof(double), false, s));
-    OHMHIP_CHECK(hipMemcpyAsync(m->times_dev.ptr, timestamps, n_rays * sizeof(double), hipMemcpyHostToDevice, s));
-    d_ts = static_cast<const double *>(m->times_dev.ptr);
+    std::memcpy(slotTimes(sl) + m->pending_rays * 8, timestamps, n_rays * 8);
+    if (m->first_ray_time < 0)
+    {
+      m->first_ray_time = timestamps[0];  // OccupancyMap::updateFirstRayTime (ohm/OccupancyMap.cpp:343-347)
+    }
   }
-  return ohmhip_map_integrate_rays_device(m, static_cast<const double *>(m->rays_dev.ptr), element_count, d_int, d_ts,
-                                          ray_flags, integrated);
+  if (intensities)
+  {
+    std::memcpy(slotIntens(sl) + m->pending_rays * 4, intensities, n_rays * 4);
+  }
+  m->pending_flags = ray_flags;
+  m->pending_intens = intensities != nullptr;
+  m->pending_times = timestamps != nullptr;
+  m->pending_rays += n_rays;
+  m->pending_calls += 1;
+  if (coalesce && m->pending_rays < m->coalesce_min_rays)
+  {
+    // Deferred: which rays the filter rejects is only known once the batch runs (ohmhip_map_last_stats).
+    if (integrated)
+    {
+      *integrated = n_rays * 2;
+    }
+    return OHMHIP_OK;
+  }
+  const bool only_this_call = m->pending_calls == 1;
+  size_t batch_integrated = 0;
+  err = flushPendingRays(m, &batch_integrated);
+  if (err == OHMHIP_OK && integrated)
+  {
+    *integrated = only_this_call ? batch_integrated : n_rays * 2;
+  }
+  return err;
+}
+
+int ohmhip_map_set_batch_coalescing(ohmhip_map_t m, size_t min_rays)
+{
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);
+  m->coalesce_min_rays = min_rays;
+  return OHMHIP_OK;
 }
 
 int ohmhip_map_sync(ohmhip_map_t m)
 {
+  OHMHIP_SETTLE(m);
   if (!m)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1298,6 +1538,7 @@ int ohmhip_map_sync(ohmhip_map_t m)
 
 int ohmhip_map_batch_timings(ohmhip_map_t m, uint32_t batches_back, float ms[4])
 {
+  OHMHIP_SETTLE(m);
   if (!m || !ms)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1320,6 +1561,7 @@ int ohmhip_map_batch_timings(ohmhip_map_t m, uint32_t batches_back, float ms[4])
 
 int ohmhip_map_last_stats(ohmhip_map_t m, ohmhip_batch_stats *stats)
 {
+  OHMHIP_SETTLE(m);
   if (!m || !stats)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1342,6 +1584,7 @@ int ohmhip_map_last_stats(ohmhip_map_t m, ohmhip_batch_stats *stats)
 
 int ohmhip_map_region_count(ohmhip_map_t m, size_t *count)
 {
+  OHMHIP_SETTLE(m);
   if (!m || !count)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1352,6 +1595,7 @@ int ohmhip_map_region_count(ohmhip_map_t m, size_t *count)
 
 int ohmhip_map_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity, size_t *count)
 {
+  OHMHIP_SETTLE(m);
   if (!m || !count)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1372,6 +1616,7 @@ int ohmhip_map_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity, size_
 
 int ohmhip_map_dirty_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity, size_t *count)
 {
+  OHMHIP_SETTLE(m);
   if (!m || !count)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1405,6 +1650,7 @@ int ohmhip_map_dirty_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity,
 
 int ohmhip_map_clear_dirty(ohmhip_map_t m)
 {
+  OHMHIP_SETTLE(m);
   if (!m)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1415,6 +1661,7 @@ int ohmhip_map_clear_dirty(ohmhip_map_t m)
 
 int ohmhip_map_region_slot(ohmhip_map_t m, const int16_t key_xyz[3], uint32_t *slot)
 {
+  OHMHIP_SETTLE(m);
   if (!m || !key_xyz || !slot)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1436,6 +1683,7 @@ int ohmhip_map_region_slot(ohmhip_map_t m, const int16_t key_xyz[3], uint32_t *s
 
 int ohmhip_map_device_layer_ptr(ohmhip_map_t m, int layer_id, void **device_ptr, size_t *region_stride_bytes)
 {
+  OHMHIP_SETTLE(m);
   if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || !device_ptr)
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1454,6 +1702,7 @@ int ohmhip_map_device_layer_ptr(ohmhip_map_t m, int layer_id, void **device_ptr,
 
 int ohmhip_map_read_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, size_t count, void *const *dsts)
 {
+  OHMHIP_SETTLE(m);
   if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || (count && (!keys_xyz || !dsts)))
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1583,6 +1832,7 @@ int ohmhip_map_read_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xy
 int ohmhip_map_write_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, size_t count,
                              const void *const *srcs)
 {
+  OHMHIP_SETTLE(m);
   if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || (count && (!keys_xyz || !srcs)))
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1676,6 +1926,7 @@ int ohmhip_map_write_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_x
 
 int ohmhip_map_ensure_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, uint32_t *slots)
 {
+  OHMHIP_SETTLE(m);
   if (!m || (count && !keys_xyz))
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1730,6 +1981,7 @@ int ohmhip_map_ensure_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t co
 
 int ohmhip_map_mark_dirty(ohmhip_map_t m, const uint32_t *slots, size_t count)
 {
+  OHMHIP_SETTLE(m);
   if (!m || (count && !slots))
   {
     return OHMHIP_ERR_INVALID_ARG;
@@ -1829,6 +2081,7 @@ int ohmhip_map_line_keys(ohmhip_map_t m, const double *lines, size_t line_count,
 
 int ohmhip_map_clear(ohmhip_map_t m)
 {
+  OHMHIP_SETTLE(m);
   if (!m)
   {
     return OHMHIP_ERR_INVALID_ARG;

@@ -316,6 +316,11 @@ class GpuMap(RayMapper):
         L.check(L.lib.ohmhip_map_clear_dirty(self._handle), "clear_dirty")
         self.wait()
 
+    def setBatchCoalescing(self, min_rays):
+        """Collect consecutive small host batches and run them as one device batch of >= min_rays rays
+        (include/ohmhip.h: ohmhip_map_set_batch_coalescing).  0 turns it off."""
+        L.check(L.lib.ohmhip_map_set_batch_coalescing(self._handle, int(min_rays)), "setBatchCoalescing")
+
     def setRegionOwnership(self, world_size, rank, block_shift=0):
         """Owner-computes multi-GPU mode (include/ohmhip.h: ohmhip_map_set_region_ownership): integrate only what falls
         in the regions `rank` owns among `world_size` region-partitioned maps.  Call before the first integrateRays."""

@@ -288,6 +288,10 @@ public:
     ohmhip_map_last_stats(handle_, &st);
     return st;
   }
+  /// Not in the reference: run consecutive small integrateRays() batches as one device batch of at least @p min_rays
+  /// rays (see ohmhip_map_set_batch_coalescing); 0 turns it off.
+  void setBatchCoalescing(size_t min_rays) { OHMHIP_GPUAPICHECK(ohmhip_map_set_batch_coalescing(handle_, min_rays)); }
+
   /// Not in the reference (single device): owner-computes multi-GPU mode, see ohmhip_map_set_region_ownership.  The
   /// map integrates only what falls in the regions @p rank owns among @p world_size maps fed the same ray stream.
   void setRegionOwnership(unsigned world_size, unsigned rank, int block_shift = 0)

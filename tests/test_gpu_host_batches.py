@@ -1,0 +1,106 @@
+"""-m gpu: the host-pointer entry point (ohmhip_map_integrate_rays) -- double-buffered staging (batch N+1 is copied
+and uploaded while batch N runs; the caller's array may be reused the moment the call returns) and batch coalescing
+(ohmhip_map_set_batch_coalescing: consecutive small batches run as one device batch).  Everything is compared with
+the CPU oracle integrating the same calls one by one: bit exact."""
+import numpy as np
+import pytest
+
+from ohm_amd import GpuMap, GpuNdtMap, OccupancyMap, RayFlag, synth
+
+from parity import assert_parity, compare_maps, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_back_to_back_host_batches_reuse_the_callers_buffer(gpu):
+    layers = ("occupancy", "mean")
+    map_ = OccupancyMap(0.1, layers=layers)
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    scratch = np.empty((2 * 30000, 3), dtype=np.float64)
+    for k in range(7):
+        n = 30000 - 3500 * k  # shrinking and growing batches through both staging slots
+        rays = synth.rays_c1(n=n, max_range=12.0, seed=40 + k, first=1000 * k)
+        scratch[:2 * n] = rays
+        assert gm.integrateRays(scratch[:2 * n]) == 2 * n
+        scratch[:] = np.nan  # the library must have taken its copy already
+        om.integrate_occupancy(rays)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
+
+
+@pytest.mark.parametrize("min_rays", [1, 5000, 1 << 20])
+def test_coalesced_small_batches_equal_separate_calls(gpu, min_rays):
+    layers = ("occupancy", "mean", "touch_time")
+    map_ = OccupancyMap(0.1, layers=layers)
+    gm = GpuMap(map_)
+    gm.setBatchCoalescing(min_rays)
+    om = make_oracle(map_)
+    rays = synth.rays_c1(n=24000, max_range=10.0, seed=9)
+    ts = 50.0 + 0.002 * np.arange(rays.shape[0] // 2, dtype=np.float64)
+    small = 2 * 1000
+    for i in range(0, rays.shape[0], small):
+        chunk, tchunk = rays[i:i + small], ts[i // 2:(i + small) // 2]
+        # the flags change half way: batches on either side must not be merged
+        flags = int(RayFlag.kRfEndPointAsFree) if i >= rays.shape[0] // 2 else 0
+        assert gm.integrateRays(chunk, timestamps=tchunk, ray_update_flags=flags) == chunk.shape[0]
+        om.integrate_occupancy(chunk, timestamps=tchunk, flags=flags)
+    gm.syncVoxels()  # observing the map runs what is still pending
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
+    if min_rays == 1 << 20:
+        # two device batches in total: one per flag value
+        assert gm.stats()["rays_in"] == 12000
+
+
+def test_coalescing_keeps_order_with_device_batches_and_optional_arrays(gpu):
+    import ctypes as C
+    from ohm_amd import _lib as L
+    map_ = OccupancyMap(0.1, layers=("occupancy",))
+    gm = GpuMap(map_)
+    gm.setBatchCoalescing(1 << 20)
+    om = make_oracle(map_)
+    a = synth.rays_c0(n=3000, length=3.0, seed=1)
+    b = synth.rays_c0(n=3000, length=3.0, seed=2)
+    c = synth.rays_c0(n=3000, length=3.0, seed=3)
+    ts = np.linspace(1.0, 2.0, 3000)
+    gm.integrateRays(a)                  # deferred
+    buf = L._vp()
+    L.check(L.lib.ohmhip_buffer_create(C.byref(buf), b.nbytes, 3))
+    L.check(L.lib.ohmhip_buffer_write(buf, b.ctypes.data, b.nbytes, 0, None, None, None))
+    ptr = L._vp()
+    L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(ptr)))
+    gm.integrateRaysDevice(ptr, b.shape[0])  # must run after `a`
+    gm.integrateRays(c)                  # deferred
+    gm.integrateRays(a, timestamps=ts)   # different optional arrays: `c` is launched first
+    for r in (a, b, c, a):
+        om.integrate_occupancy(r)
+    gm.syncVoxels()
+    L.lib.ohmhip_buffer_destroy(buf)
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+
+
+def test_traversal_maps_never_merge_batches(gpu):
+    map_ = OccupancyMap(0.1, layers=("occupancy", "traversal"))
+    gm = GpuMap(map_)
+    gm.setBatchCoalescing(1 << 20)
+    rays = synth.rays_c0(n=2000, length=3.0, seed=4)
+    gm.integrateRays(rays[:2000])
+    gm.integrateRays(rays[2000:])
+    gm.wait()
+    assert gm.stats()["rays_in"] == 1000  # the second call's own batch
+
+
+def test_ndt_coalesced(gpu):
+    rays = synth.rays_c2(n=20000)
+    map_ = OccupancyMap(0.2, (32, 32, 32), layers=("occupancy",))
+    gm = GpuNdtMap(map_)
+    gm.setBatchCoalescing(8192)
+    om = make_oracle(map_)
+    om.set_ndt(sensor_noise=gm.sensor_noise, sample_threshold=gm.sample_threshold, adaptation_rate=gm.adaptation_rate,
+               reinit_threshold=gm.reinitialise_covariance_threshold,
+               reinit_count=gm.reinitialise_covariance_point_count, ndt_tm=False)
+    for i in range(0, rays.shape[0], 2 * 2048):
+        gm.integrateRays(rays[i:i + 2 * 2048])
+    om.integrate_ndt(rays)  # one CPU call == the sequence of calls (ray by ray either way)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(map_.layers), rel=1e-5))
