@@ -19,7 +19,7 @@ int main(int argc, char **argv)
 {
   if (argc < 6)
   {
-    std::fprintf(stderr, "usage: %s <occ|occmean|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <occ|occmean|occdev|occcoalesce|occowner|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>\n", argv[0]);
     return 2;
   }
   const std::string mode = argv[1];
@@ -51,13 +51,21 @@ int main(int argc, char **argv)
 
     ohm::OccupancyMap map(resolution);
     std::unique_ptr<ohm::GpuMap> gpu_map;
-    if (mode == "occ" || mode == "occmean" || mode == "occdev")
+    if (mode == "occ" || mode == "occmean" || mode == "occdev" || mode == "occcoalesce" || mode == "occowner")
     {
       if (mode == "occmean")
       {
         map.addLayer(OHMHIP_LID_MEAN);
       }
       gpu_map.reset(new ohm::GpuMap(&map, true, unsigned(batch_rays * 2)));
+      if (mode == "occcoalesce")
+      {
+        gpu_map->setBatchCoalescing(3 * batch_rays + 1);  // every fourth call launches a device batch
+      }
+      if (mode == "occowner")
+      {
+        gpu_map->setRegionOwnership(2, 1);  // this map is rank 1 of a two-way region partition
+      }
     }
     else if (mode == "ndt")
     {

@@ -85,3 +85,20 @@ def test_cpp_transform_samples_feeds_device_integration(gpu):
         om.integrate_occupancy(from_origin[i:i + 2 * 4096])
     stats = compare_maps(om.chunks(), gpu_chunks, ["occupancy"], exact_float=True)
     assert_parity(stats)
+
+
+def test_cpp_batch_coalescing_and_region_ownership(gpu):
+    from ohm_amd import distributed as D
+    rays = synth.rays_c1(n=20000, max_range=12.0)
+    om = OracleMap(0.1, layers=("occupancy",))
+    om.integrate_occupancy(rays)
+    expect = om.chunks()
+    # GpuMap::setBatchCoalescing: 1000-ray calls, a device batch every fourth call, the rest at syncVoxels()
+    merged = run_driver("occcoalesce", 0.1, 1000, rays, 1)
+    assert_parity(compare_maps(expect, merged, ["occupancy"], exact_float=True))
+    # GpuMap::setRegionOwnership(2, 1): exactly the regions rank 1 owns, with the values the whole map has there
+    owned = run_driver("occowner", 0.1, 4096, rays, 1)
+    keys = np.array(sorted(expect.keys()), dtype=np.int16).reshape(-1, 3)
+    mine = {tuple(int(v) for v in k) for k, o in zip(keys, D.region_owner(keys, 2, 0)) if o == 1}
+    assert set(owned.keys()) == mine and len(mine) > 0
+    assert_parity(compare_maps({k: expect[k] for k in mine}, owned, ["occupancy"], exact_float=True))
