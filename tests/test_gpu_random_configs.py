@@ -39,3 +39,50 @@ def test_random_geometry_parity(gpu, case):
     stats = compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True)
     assert_parity(stats)
     assert gm.stats()["voxel_visits"] > 0
+
+
+NDT_TSDF_CASES = [
+    # kind, resolution, region dims, origin, extent, rays, batches
+    ("ndt", 0.2, (5, 7, 9), (0.013, -0.4, 0.27), 6.0, 6000, 2),
+    ("ndt", 0.25, (31, 33, 32), (-1.0, 2.0, 0.5), 14.0, 9000, 3),
+    ("tsdf", 0.1, (6, 10, 4), (0.02, 0.02, 0.02), 4.0, 5000, 2),
+    ("tsdf", 0.15, (64, 16, 8), (0.0, 0.0, 0.0), 10.0, 8000, 2),
+]
+
+
+@pytest.mark.parametrize("case", range(len(NDT_TSDF_CASES)))
+def test_random_geometry_ndt_tsdf(gpu, case):
+    """Region shapes other than 32^3 through the NDT and TSDF pipelines (event sort keys, LDS tile sizes and the
+    replay kernels all depend on the region volume)."""
+    from ohm_amd import GpuNdtMap, GpuTsdfMap
+    kind, res, dims, origin, extent, n_rays, batches = NDT_TSDF_CASES[case]
+    rays = synth.random_rays(n_rays, extent=extent, seed=500 + case, origin_spread=0.2 * extent)
+    # cluster the samples so NDT voxels collect several samples each
+    rays[1::2] = np.round(rays[1::2] / (2.5 * res)) * (2.5 * res) + 0.013 * np.sin(np.arange(n_rays))[:, None]
+    layers = ("occupancy",) if kind == "ndt" else ("tsdf",)
+    map_ = OccupancyMap(res, dims, layers=layers)
+    map_.setOrigin(origin)
+    om = None
+    if kind == "ndt":
+        gm = GpuNdtMap(map_)
+        om = make_oracle(map_)
+        om.set_ndt(sensor_noise=gm.sensor_noise, sample_threshold=gm.sample_threshold,
+                   adaptation_rate=gm.adaptation_rate, reinit_threshold=gm.reinitialise_covariance_threshold,
+                   reinit_count=gm.reinitialise_covariance_point_count, ndt_tm=False)
+    else:
+        gm = GpuTsdfMap(map_, default_truncation_distance=2.0 * res)
+        om = make_oracle(map_)
+        opts = gm.tsdf_options
+        om.set_tsdf(max_weight=opts[0], trunc=opts[1], dropoff=opts[2], sparsity=opts[3])
+    step = 2 * ((n_rays + batches - 1) // batches)
+    for i in range(0, rays.shape[0], step):
+        assert gm.integrateRays(rays[i:i + step]) == rays[i:i + step].shape[0]
+        if kind == "ndt":
+            om.integrate_ndt(rays[i:i + step])
+        else:
+            om.integrate_tsdf(rays[i:i + step])
+    gm.syncVoxels()
+    if kind == "ndt":
+        assert_parity(compare_maps(om.chunks(), map_.chunks, list(map_.layers), rel=1e-5))
+    else:
+        assert_parity(compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True))
