@@ -104,3 +104,33 @@ def test_ndt_coalesced(gpu):
     om.integrate_ndt(rays)  # one CPU call == the sequence of calls (ray by ray either way)
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, list(map_.layers), rel=1e-5))
+
+
+def test_soak_mixed_batch_sizes_flags_and_coalescing(gpu):
+    """Sixty calls of wildly different sizes (1 ray ... 60 000 rays), changing flags and a coalescing threshold that is
+    switched on and off along the way: exercises the alternating batch-summary blocks, the speculative binning (which
+    keys on the previous batch), both staging slots and pool growth, against the CPU oracle fed the same calls."""
+    layers = ("occupancy", "mean")
+    map_ = OccupancyMap(0.1, layers=layers)
+    gm = GpuMap(map_, region_capacity=64)  # small pool: grows several times
+    om = make_oracle(map_)
+    rng = np.random.default_rng(2026)
+    sizes = [1, 7, 100, 5000, 60000, 300, 2, 20000]
+    flag_choices = [0, int(RayFlag.kRfEndPointAsFree), int(RayFlag.kRfExcludeOrigin), int(RayFlag.kRfExcludeSample)]
+    first = 0
+    for call in range(60):
+        n = sizes[int(rng.integers(len(sizes)))]
+        flags = flag_choices[int(rng.integers(len(flag_choices)))]
+        if call % 9 == 0:
+            gm.setBatchCoalescing([0, 4096, 1 << 20][int(rng.integers(3))])
+        if call % 2:
+            rays = synth.rays_c1(n=n, max_range=9.0, seed=7000 + call, first=first)
+        else:
+            rays = synth.random_rays(n, extent=6.0, seed=8000 + call, origin_spread=2.0)
+        first += n
+        assert gm.integrateRays(rays, ray_update_flags=flags) == rays.shape[0]
+        om.integrate_occupancy(rays, flags=flags)
+        if call % 13 == 5:
+            assert gm.stats()["rays_in"] > 0  # observing the map mid-stream flushes what is pending
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))

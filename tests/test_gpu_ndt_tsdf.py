@@ -145,3 +145,38 @@ def test_tsdf_dropoff_is_reported_unsupported(gpu):
     gm = GpuTsdfMap(map_, dropoff_epsilon=0.05)
     with pytest.raises(ohm_amd.OhmHipError):
         gm.integrateRays(synth.rays_c2(n=64))
+
+
+def test_ndt_and_tsdf_soak_mixed_batch_sizes(gpu):
+    """Many calls of very different sizes (1 ray ... 40 000 rays): the event-list sizing follows the previous batch's
+    demand, the sort scratch grows and shrinks, single-ray batches take the same kernels as large ones."""
+    rng = np.random.default_rng(77)
+    sizes = [1, 3, 50, 3000, 40000, 700, 12000]
+    calls = []
+    first = 0
+    for call in range(24):
+        n = sizes[int(rng.integers(len(sizes)))]
+        calls.append(synth.rays_c2(n=n, seed=900 + call, first=first))
+        first += n
+    # NDT
+    map_n = OccupancyMap(0.2, (32, 32, 32), layers=("occupancy",))
+    gn = GpuNdtMap(map_n)
+    on = make_oracle(map_n)
+    on.set_ndt(sensor_noise=gn.sensor_noise, sample_threshold=gn.sample_threshold, adaptation_rate=gn.adaptation_rate,
+               reinit_threshold=gn.reinitialise_covariance_threshold,
+               reinit_count=gn.reinitialise_covariance_point_count, ndt_tm=False)
+    # TSDF
+    map_t = OccupancyMap(0.1, (32, 32, 32), layers=("tsdf",))
+    gt = GpuTsdfMap(map_t, default_truncation_distance=0.2)
+    ot = make_oracle(map_t)
+    opts = gt.tsdf_options
+    ot.set_tsdf(max_weight=opts[0], trunc=opts[1], dropoff=opts[2], sparsity=opts[3])
+    for rays in calls:
+        assert gn.integrateRays(rays) == rays.shape[0]
+        assert gt.integrateRays(rays) == rays.shape[0]
+        on.integrate_ndt(rays)
+        ot.integrate_tsdf(rays)
+    gn.syncVoxels()
+    gt.syncVoxels()
+    assert_parity(compare_maps(on.chunks(), map_n.chunks, list(map_n.layers), rel=1e-5))
+    assert_parity(compare_maps(ot.chunks(), map_t.chunks, ["tsdf"], exact_float=True))
