@@ -69,3 +69,21 @@ def test_python_constants_match_host_libm():
     from oracle import oracle as O
     for p in (0.9, 0.45, 0.5, 0.2, 0.55, 0.7):
         assert ohm_amd.probability_to_value(p) == np.float32(O.lib.oracle_probability_to_value(p))
+
+
+def test_null_and_out_of_range_arguments_are_rejected():
+    """Entry points that need no device validate their arguments the same way with or without a GPU."""
+    import numpy as np
+    from ohm_amd import _lib as L
+    invalid = L.ERR_INVALID_ARG
+    assert L.lib.ohmhip_map_set_batch_coalescing(None, 4096) == invalid
+    assert L.lib.ohmhip_map_set_region_ownership(None, 2, 0, 0) == invalid
+    assert L.lib.ohmhip_map_integrate_rays(None, None, 0, None, None, 0, None) == invalid
+    assert L.lib.ohmhip_map_sync(None) == invalid
+    keys = np.zeros((4, 3), dtype=np.int16)
+    owners = np.zeros(4, dtype=np.uint32)
+    assert L.lib.ohmhip_region_owner(keys.ctypes.data, 4, -1, 2, owners.ctypes.data) == invalid
+    assert L.lib.ohmhip_region_owner(keys.ctypes.data, 4, 16, 2, owners.ctypes.data) == invalid
+    assert L.lib.ohmhip_region_owner(None, 4, 0, 2, owners.ctypes.data) == invalid
+    assert L.lib.ohmhip_region_owner(keys.ctypes.data, 4, 0, 2, owners.ctypes.data) == L.OK
+    assert L.lib.ohmhip_region_owner(None, 0, 0, 2, None) == L.OK
