@@ -196,6 +196,15 @@ int ohmhip_map_destroy(ohmhip_map_t map);
  * the fence).  *integrated = points accepted (2 per ray). */
 int ohmhip_map_integrate_rays(ohmhip_map_t map, const double *rays, size_t element_count, const float *intensities,
                               const double *timestamps, unsigned ray_flags, size_t *integrated);
+/* GpuMap::setRayFilter with an arbitrary RayFilterFunction (ohm/RayFilter.h:45, ohmgpu/GpuMap.cpp:348-369; applied
+ * per ray on the host at GpuMap.cpp:736-746).  The filter is host code, so the host mirror runs it and hands over what
+ * passed: `rays` holds the accepted (possibly moved) origin / sample pairs and filter_flags[ray] the RayFilterFlag bits
+ * the filter set (ohm/RayFilter.h:21-29: 1 invalid, 2 clipped start, 4 clipped end).  The map's built-in filter is not applied to
+ * such a batch; a clipped end makes the end voxel part of the ray and suppresses the sample, as in the CPU mappers
+ * (ohm/RayMapperOccupancy.cpp:209-223, ohm/RayMapperNdt.cpp:251-269). */
+int ohmhip_map_integrate_rays_filtered(ohmhip_map_t map, const double *rays, size_t element_count,
+                                       const float *intensities, const double *timestamps, unsigned ray_flags,
+                                       const unsigned char *filter_flags, size_t *integrated);
 /* Small host batches (the reference tools present 4096 rays per call, ohmapp/OhmAppGpu.cpp:187-207) cost a full
  * pipeline pass each.  With min_rays > 0, consecutive host-pointer batches with the same flags and the same optional
  * arrays are collected in the pinned staging block and run as ONE device batch once min_rays have accumulated -- or as

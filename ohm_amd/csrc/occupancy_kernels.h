@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(kBinThreads)
       start[a] = rays[size_t(ray) * 6 + a];
       end[a] = rays[size_t(ray) * 6 + 3 + a];
     }
-    setupRay(mc, start, end, ray_flags, rw);
+    setupRay(mc, start, end, ray_flags, rw, ray);
     if (mc.owner_world > 1u && (rw.flags & kRwApplySample))
     {
       // A sample in a region another replica owns is that replica's to apply.

@@ -70,6 +70,9 @@ struct MapConst
   unsigned owner_world;
   unsigned owner_rank;
   int owner_shift;
+  /// Per-ray RayFilterFlag bits of a batch the CALLER filtered (ohmhip_map_integrate_rays_filtered; null otherwise):
+  /// the device then applies no filter of its own and takes "end point was clipped" from kRffClippedEnd (bit 2).
+  const unsigned char *batch_filter_flags;
 };
 
 /// Per-ray line-walk parameters: everything ohm/LineWalkCompute.h:260-280 derives once per ray, in fp64, plus the

@@ -130,9 +130,9 @@ struct ohmhip_map_s
   /// batches with the same flags accumulate in the filling slot and run as one device batch.
   struct RaySlot
   {
-    char *h = nullptr;            ///< pinned: capacity x 48 B rays, then capacity x 8 B timestamps, then x 4 B intensities
+    char *h = nullptr;            ///< pinned: capacity x 48 B rays, x 8 B timestamps, x 4 B intensities, x 1 B filter flags
     size_t capacity = 0;          ///< rays
-    DevBuf d_rays, d_times, d_intens;
+    DevBuf d_rays, d_times, d_intens, d_fflags;
     hipEvent_t uploaded = nullptr;  ///< H2D copies done (copy stream)
     hipEvent_t done = nullptr;      ///< the batch reading the device copies has finished (compute stream)
     bool in_flight = false;
@@ -141,7 +141,7 @@ struct ohmhip_map_s
   size_t pending_rays = 0;
   size_t pending_calls = 0;
   unsigned pending_flags = 0;
-  bool pending_intens = false, pending_times = false;
+  bool pending_intens = false, pending_times = false, pending_fflags = false;
   size_t coalesce_min_rays = 0;  ///< 0: every host batch is launched by the call that presents it
 
   // host mirror of the region table
@@ -718,7 +718,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited) or the
         // traversal layer needs the exit range of an end voxel that is part of the walk.  (An end voxel that is walked --
         // kRfEndPointAsFree, clipped rays, TSDF -- is simply one more voxel of the ray's last segment.)
-        const bool end_walked = (ray_flags & OHMHIP_RF_END_POINT_AS_FREE) || m->mc.filter_mode == OHMHIP_FILTER_CLIP;
+        const bool end_walked = (ray_flags & OHMHIP_RF_END_POINT_AS_FREE) || m->mc.filter_mode == OHMHIP_FILTER_CLIP ||
+                                m->mc.batch_filter_flags != nullptr;
         const bool special = (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) || (sec.traversal && end_walked);
         const dim3 wgrid(std::min<uint32_t>(info.n_chunks, m->walk_workgroups)), wblock(kWalkThreads);
         const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments);
@@ -898,6 +899,7 @@ void parallelCopy(void *dst, const void *src, size_t bytes)
 inline char *slotRays(ohmhip_map_s::RaySlot &sl) { return sl.h; }
 inline char *slotTimes(ohmhip_map_s::RaySlot &sl) { return sl.h + sl.capacity * 48; }
 inline char *slotIntens(ohmhip_map_s::RaySlot &sl) { return sl.h + sl.capacity * 56; }
+inline char *slotFilterFlags(ohmhip_map_s::RaySlot &sl) { return sl.h + sl.capacity * 60; }
 
 /// Make room for `rays` rays in the filling slot, keeping what is pending in it.
 int growRaySlot(ohmhip_map_t m, ohmhip_map_s::RaySlot &sl, size_t rays)
@@ -909,13 +911,14 @@ int growRaySlot(ohmhip_map_t m, ohmhip_map_s::RaySlot &sl, size_t rays)
   ohmhip_map_s::RaySlot grown;
   grown.capacity = std::max<size_t>(rays + rays / 4, 4096);
   void *block = nullptr;
-  OHMHIP_CHECK(hipHostMalloc(&block, grown.capacity * 60, hipHostMallocDefault));
+  OHMHIP_CHECK(hipHostMalloc(&block, grown.capacity * 61, hipHostMallocDefault));
   grown.h = static_cast<char *>(block);
   if (m->pending_rays)
   {
     std::memcpy(slotRays(grown), slotRays(sl), m->pending_rays * 48);
     std::memcpy(slotTimes(grown), slotTimes(sl), m->pending_rays * 8);
     std::memcpy(slotIntens(grown), slotIntens(sl), m->pending_rays * 4);
+    std::memcpy(slotFilterFlags(grown), slotFilterFlags(sl), m->pending_rays);
   }
   if (sl.h)
   {
@@ -927,7 +930,8 @@ int growRaySlot(ohmhip_map_t m, ohmhip_map_s::RaySlot &sl, size_t rays)
 }
 
 int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_count, const float *d_intensities,
-                        const double *d_timestamps, unsigned ray_flags, size_t *integrated);
+                        const double *d_timestamps, unsigned ray_flags, size_t *integrated,
+                        const unsigned char *d_filter_flags = nullptr);
 
 /// Launch what the filling slot holds: H2D on the copy stream, the batch on the compute stream behind it.
 int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
@@ -956,10 +960,17 @@ int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
     OHMHIP_CHECK(hipMemcpyAsync(sl.d_intens.ptr, slotIntens(sl), n * 4, hipMemcpyHostToDevice, m->copy_stream));
     d_int = static_cast<const float *>(sl.d_intens.ptr);
   }
+  const unsigned char *d_ff = nullptr;
+  if (m->pending_fflags)
+  {
+    OHMHIP_CHECK(sl.d_fflags.ensure(n, false, m->stream));
+    OHMHIP_CHECK(hipMemcpyAsync(sl.d_fflags.ptr, slotFilterFlags(sl), n, hipMemcpyHostToDevice, m->copy_stream));
+    d_ff = static_cast<const unsigned char *>(sl.d_fflags.ptr);
+  }
   OHMHIP_CHECK(hipEventRecord(sl.uploaded, m->copy_stream));
   OHMHIP_CHECK(hipStreamWaitEvent(m->stream, sl.uploaded, 0));
   const int err = integrateRaysDevice(m, static_cast<const double *>(sl.d_rays.ptr), n * 2, d_int, d_ts,
-                                      m->pending_flags, integrated);
+                                      m->pending_flags, integrated, d_ff);
   OHMHIP_CHECK(hipEventRecord(sl.done, m->stream));
   sl.in_flight = true;
   m->fill_slot ^= 1;
@@ -1263,6 +1274,7 @@ int ohmhip_map_destroy(ohmhip_map_t m)
     sl.d_rays.release();
     sl.d_times.release();
     sl.d_intens.release();
+    sl.d_fflags.release();
     if (sl.h)
     {
       (void)hipHostFree(sl.h);
@@ -1310,8 +1322,25 @@ int ohmhip_map_destroy(ohmhip_map_t m)
 namespace
 {
 int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_count, const float *d_intensities,
-                        const double *d_timestamps, unsigned ray_flags, size_t *integrated)
+                        const double *d_timestamps, unsigned ray_flags, size_t *integrated,
+                        const unsigned char *d_filter_flags)
 {
+  // Kernels take MapConst by value at launch: the batch's filter-flag array rides in it for the calls below.
+  struct FlagScope
+  {
+    ohmhip_map_t m;
+    ~FlagScope()
+    {
+      if (m)
+      {
+        m->mc.batch_filter_flags = nullptr;
+      }
+    }
+  } flag_scope{ m };
+  if (m)
+  {
+    m->mc.batch_filter_flags = d_filter_flags;
+  }
   if (integrated)
   {
     *integrated = 0;
@@ -1399,8 +1428,13 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
   return integrateRaysDevice(m, d_rays, element_count, d_intensities, d_timestamps, ray_flags, integrated);
 }
 
-int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
-                              const double *timestamps, unsigned ray_flags, size_t *integrated)
+}  // extern "C"
+
+namespace
+{
+int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
+                      const double *timestamps, unsigned ray_flags, const unsigned char *filter_flags,
+                      size_t *integrated)
 {
   if (integrated)
   {
@@ -1428,7 +1462,8 @@ int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element
   const bool coalesce = m->coalesce_min_rays > 0 && !m->layers[OHMHIP_LID_TRAVERSAL];
   if (m->pending_rays &&
       (!coalesce || m->pending_flags != ray_flags || m->pending_intens != (intensities != nullptr) ||
-       m->pending_times != (timestamps != nullptr) || m->pending_rays + n_rays >= (size_t(1) << (kHitRayBits - 1))))
+       m->pending_times != (timestamps != nullptr) || m->pending_fflags != (filter_flags != nullptr) ||
+       m->pending_rays + n_rays >= (size_t(1) << (kHitRayBits - 1))))
   {
     const int err = flushPendingRays(m);
     if (err != OHMHIP_OK)
@@ -1460,7 +1495,12 @@ int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element
   {
     std::memcpy(slotIntens(sl) + m->pending_rays * 4, intensities, n_rays * 4);
   }
+  if (filter_flags)
+  {
+    std::memcpy(slotFilterFlags(sl) + m->pending_rays, filter_flags, n_rays);
+  }
   m->pending_flags = ray_flags;
+  m->pending_fflags = filter_flags != nullptr;
   m->pending_intens = intensities != nullptr;
   m->pending_times = timestamps != nullptr;
   m->pending_rays += n_rays;
@@ -1482,6 +1522,30 @@ int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element
     *integrated = only_this_call ? batch_integrated : n_rays * 2;
   }
   return err;
+}
+}  // namespace
+
+extern "C" {
+
+int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
+                              const double *timestamps, unsigned ray_flags, size_t *integrated)
+{
+  return integrateRaysHost(m, rays, element_count, intensities, timestamps, ray_flags, nullptr, integrated);
+}
+
+int ohmhip_map_integrate_rays_filtered(ohmhip_map_t m, const double *rays, size_t element_count,
+                                       const float *intensities, const double *timestamps, unsigned ray_flags,
+                                       const unsigned char *filter_flags, size_t *integrated)
+{
+  if (!filter_flags && element_count >= 2)
+  {
+    if (integrated)
+    {
+      *integrated = 0;
+    }
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  return integrateRaysHost(m, rays, element_count, intensities, timestamps, ray_flags, filter_flags, integrated);
 }
 
 int ohmhip_map_set_batch_coalescing(ohmhip_map_t m, size_t min_rays)

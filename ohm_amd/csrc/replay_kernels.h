@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(128)
       end[a] = rays[size_t(ray) * 6 + 3 + a];
     }
     bool clipped = false;
-    filterRay(mc, start, end, clipped);  // clip filter may move the end point used by the miss maths
+    filterRay(mc, start, end, clipped, ray);  // clip filter may move the end point used by the miss maths
     const D3 sensor = d3(start[0], start[1], start[2]);
     const D3 sample = d3(end[0], end[1], end[2]);
     const D3 mean = subVoxelToLocal(mcoord, mc.resolution) + centre;
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256)
   const D3 sensor = d3(start[0], start[1], start[2]);
   const D3 sample = d3(end[0], end[1], end[2]);
   bool clipped = false;
-  filterRay(mc, start, end, clipped);
+  filterRay(mc, start, end, clipped, ray);
   const double dx = end[0] - start[0], dy = end[1] - start[1], dz = end[2] - start[2];
   const double length = sqrt((dx * dx + dy * dy) + dz * dz);
   // Any voxel left before ray parameter t_star has its centre's projection at least margin * trunc short of the
@@ -487,8 +487,9 @@ __global__ void __launch_bounds__(256)
   }
   MapConst nofilter = mc;
   nofilter.filter_mode = OHMHIP_FILTER_NONE;
+  nofilter.batch_filter_flags = nullptr;
   RayWalk rw;
-  setupRay(nofilter, start, end, OHMHIP_RF_END_POINT_AS_FREE, rw);
+  setupRay(nofilter, start, end, OHMHIP_RF_END_POINT_AS_FREE, rw, line);
   if (!(rw.flags & kRwValid))
   {
     counts[line] = 0;

@@ -191,9 +191,17 @@ __device__ inline int stepsBefore(double init, double delta, double rdelta, int 
 
 /// Ray filter: ohm/RayFilter.cpp:12-58 (goodRayFilter / clipRayFilter).  May move `end` (clip).  Returns false for
 /// a rejected ray.
-__device__ inline bool filterRay(const MapConst &mc, const double start[3], double end[3], bool &clipped_end)
+__device__ inline bool filterRay(const MapConst &mc, const double start[3], double end[3], bool &clipped_end,
+                                 uint32_t ray)
 {
   clipped_end = false;
+  if (mc.batch_filter_flags)
+  {
+    // Filtered (and possibly moved) by the caller's RayFilterFunction: only the flag is consumed here -- kRffClippedEnd
+    // makes the end voxel part of the ray and suppresses the sample (ohm/RayMapperOccupancy.cpp:209-223).
+    clipped_end = (mc.batch_filter_flags[ray] & 4u) != 0;  // kRffClippedEnd, ohm/RayFilter.h:21-29
+    return true;
+  }
   if (mc.filter_mode == OHMHIP_FILTER_NONE)
   {
     return true;
@@ -223,7 +231,8 @@ __device__ inline bool filterRay(const MapConst &mc, const double start[3], doub
 ///   ohm/RayFilter.cpp:12-58 (goodRayFilter / clipRayFilter), ohm/LineWalk.h:112-129 (walkSegmentKeys),
 ///   ohm/LineWalkCompute.h:188-248 (walkInitRay) and :260-280 (walkCalculateSteps).
 /// `start`/`end` may be modified by the clip filter.
-__device__ inline void setupRay(const MapConst &mc, double start[3], double end[3], unsigned ray_flags, RayWalk &rw)
+__device__ inline void setupRay(const MapConst &mc, double start[3], double end[3], unsigned ray_flags, RayWalk &rw,
+                                uint32_t ray)
 {
   rw.flags = 0;
   rw.pad = 0;
@@ -236,7 +245,7 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
   }
 
   bool clipped_end = false;
-  if (!filterRay(mc, start, end, clipped_end))
+  if (!filterRay(mc, start, end, clipped_end, ray))
   {
     return;
   }

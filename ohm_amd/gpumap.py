@@ -240,6 +240,21 @@ class GpuMap(RayMapper):
     def raySegmentLength(self):
         return self._ray_segment_length
 
+    # GpuMap::setRayFilter / rayFilter / effectiveRayFilter / clearRayFilter (ohmgpu/GpuMap.cpp:348-369).  A filter is a
+    # callable of the vectorised form described in ohm_amd/rayfilter.py; without one the map's built-in filter
+    # (OccupancyMap.ray_filter) runs on the device.
+    def setRayFilter(self, ray_filter):
+        self._ray_filter = ray_filter
+
+    def rayFilter(self):
+        return getattr(self, "_ray_filter", None)
+
+    def effectiveRayFilter(self):
+        return self.rayFilter()
+
+    def clearRayFilter(self):
+        self._ray_filter = None
+
     def integrateRays(self, rays, intensities=None, timestamps=None, ray_update_flags=RayFlag.kRfDefault):
         """rays: (2N, 3) float64 origin/sample pairs.  Returns number of POINTS integrated (2 per ray), 0 on failure
         (ohmgpu/GpuMap.cpp:416, 548-551, 874)."""
@@ -252,6 +267,29 @@ class GpuMap(RayMapper):
         ints = None if intensities is None else np.ascontiguousarray(intensities, dtype=np.float32)
         ts = None if timestamps is None else np.ascontiguousarray(timestamps, dtype=np.float64)
         done = C.c_size_t(0)
+        if self.rayFilter() is not None:
+            # The reference runs the RayFilterFunction per ray on the host before upload (ohmgpu/GpuMap.cpp:736-746):
+            # rejected rays are dropped, the others go on with their (possibly moved) end points and filter flags.
+            keep, starts, ends, fflags = self.rayFilter()(rays[0::2].copy(), rays[1::2].copy())
+            keep = np.asarray(keep, dtype=bool)
+            n_keep = int(keep.sum())
+            if n_keep == 0:
+                return 0
+            kept = np.empty((2 * n_keep, 3), dtype=np.float64)
+            kept[0::2] = np.asarray(starts, dtype=np.float64)[keep]
+            kept[1::2] = np.asarray(ends, dtype=np.float64)[keep]
+            fflags = np.ascontiguousarray(np.asarray(fflags, dtype=np.uint8)[keep])
+            ints = None if ints is None else np.ascontiguousarray(ints[keep])
+            ts = None if ts is None else np.ascontiguousarray(ts[keep])
+            status = L.lib.ohmhip_map_integrate_rays_filtered(
+                self._handle, kept.ctypes.data, kept.shape[0], None if ints is None else ints.ctypes.data,
+                None if ts is None else ts.ctypes.data, int(ray_update_flags), fflags.ctypes.data, C.byref(done))
+            if status == L.ERR_UNSUPPORTED:
+                raise L.OhmHipError(status, "GpuMap.integrateRays")
+            if status != L.OK:
+                self._last_error = status
+                return 0
+            return int(done.value)
         status = L.lib.ohmhip_map_integrate_rays(
             self._handle, rays.ctypes.data, element_count, None if ints is None else ints.ctypes.data,
             None if ts is None else ts.ctypes.data, int(ray_update_flags), C.byref(done))
@@ -283,6 +321,11 @@ class GpuMap(RayMapper):
 
     def wait(self):
         L.check(L.lib.ohmhip_map_sync(self._handle), "sync")
+
+    def clear(self):
+        """OccupancyMap::clear() as the GPU cache sees it (GpuCache::clear, ohmgpu/GpuCache.cpp): drop every resident
+        region; the host map's chunks are the caller's to clear."""
+        L.check(L.lib.ohmhip_map_clear(self._handle), "clear")
 
     def regionKeys(self, dirty_only=False):
         n = C.c_size_t(0)

@@ -20,6 +20,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -54,6 +55,173 @@ struct dvec3
 {
   double x, y, z;
 };
+
+/// ohm/RayFilter.h:21-29
+enum RayFilterFlag : unsigned
+{
+  kRffInvalid = (1u << 0u),
+  kRffClippedStart = (1u << 1u),
+  kRffClippedEnd = (1u << 2u)
+};
+
+/// ohm/RayFilter.h:45: called per ray before integration; may move the points, set RayFilterFlag bits, or reject (false).
+using RayFilterFunction = std::function<bool(dvec3 *, dvec3 *, unsigned *)>;
+
+/// The parts of ohm::Aabb (ohm/Aabb.h) the stock ray filters use.
+class Aabb
+{
+public:
+  enum : unsigned
+  {
+    kClippedStart = 1u,
+    kClippedEnd = 2u
+  };
+  Aabb(const dvec3 &min_ext, const dvec3 &max_ext) : corners_{ min_ext, max_ext } {}
+  /// ohm/Aabb.h:301-312 with epsilon 0: closed box.
+  bool contains(const dvec3 &p) const
+  {
+    return !(corners_[1].x < p.x || corners_[1].y < p.y || corners_[1].z < p.z) &&
+           !(corners_[0].x > p.x || corners_[0].y > p.y || corners_[0].z > p.z);
+  }
+  /// ohm/Aabb.h:386-446 (allow_clamp false).
+  bool clipLine(dvec3 &start, dvec3 &end, unsigned *clip_flags = nullptr) const
+  {
+    const dvec3 origin = start;
+    dvec3 dir{ end.x - start.x, end.y - start.y, end.z - start.z };
+    if (clip_flags)
+    {
+      *clip_flags = 0;
+    }
+    const double d2 = (dir.x * dir.x + dir.y * dir.y) + dir.z * dir.z;
+    if (d2 < 1e-9)
+    {
+      return false;
+    }
+    const double length = std::sqrt(d2);
+    dir.x /= length;
+    dir.y /= length;
+    dir.z /= length;
+    double t[2] = { 0, 0 };
+    if (!rayIntersect(origin, dir, t))
+    {
+      return false;
+    }
+    int hits = 0;
+    if (t[0] > 0 && t[0] < length)
+    {
+      start = dvec3{ origin.x + dir.x * t[0], origin.y + dir.y * t[0], origin.z + dir.z * t[0] };
+      if (clip_flags)
+      {
+        *clip_flags |= kClippedStart;
+      }
+      ++hits;
+    }
+    if (t[1] > 0 && t[1] < length)
+    {
+      end = dvec3{ origin.x + dir.x * t[1], origin.y + dir.y * t[1], origin.z + dir.z * t[1] };
+      if (clip_flags)
+      {
+        *clip_flags |= kClippedEnd;
+      }
+      ++hits;
+    }
+    return hits > 0;
+  }
+
+private:
+  /// ohm/Aabb.h:330-383 (slab test).
+  bool rayIntersect(const dvec3 &o, const dvec3 &d, double t[2]) const
+  {
+    const double oo[3] = { o.x, o.y, o.z };
+    const double dd[3] = { d.x, d.y, d.z };
+    const double lo[3] = { corners_[0].x, corners_[0].y, corners_[0].z };
+    const double hi[3] = { corners_[1].x, corners_[1].y, corners_[1].z };
+    bool miss = false;
+    for (int a = 0; a < 3; ++a)
+    {
+      const double inv = 1.0 / dd[a];
+      const bool neg = dd[a] < 0.0;
+      const double tmin = ((neg ? hi[a] : lo[a]) - oo[a]) * inv;
+      const double tmax = ((neg ? lo[a] : hi[a]) - oo[a]) * inv;
+      if (a == 0)
+      {
+        t[0] = tmin;
+        t[1] = tmax;
+        continue;
+      }
+      miss = miss || (t[0] > tmax) || (tmin > t[1]);
+      t[0] = (tmin > t[0] || std::isnan(t[0])) ? tmin : t[0];
+      t[1] = (tmax < t[1] || std::isnan(t[1])) ? tmax : t[1];
+    }
+    return !miss;
+  }
+  dvec3 corners_[2];
+};
+
+/// ohm/RayFilter.cpp:12-34
+inline bool goodRayFilter(dvec3 *start, dvec3 *end, unsigned *filter_flags, double max_range)
+{
+  const double v[6] = { start->x, start->y, start->z, end->x, end->y, end->z };
+  bool good = true;
+  for (double c : v)
+  {
+    good = good && std::isfinite(c);
+  }
+  const double rx = end->x - start->x, ry = end->y - start->y, rz = end->z - start->z;
+  good = good && (max_range <= 0 || (rx * rx + ry * ry) + rz * rz <= max_range * max_range);
+  if (!good)
+  {
+    *filter_flags |= kRffInvalid;
+  }
+  return good;
+}
+
+/// ohm/RayFilter.cpp:37-58
+inline bool clipRayFilter(dvec3 *start, dvec3 *end, unsigned *filter_flags, double max_length)
+{
+  const double v[6] = { start->x, start->y, start->z, end->x, end->y, end->z };
+  bool good = true;
+  for (double c : v)
+  {
+    good = good && std::isfinite(c);
+  }
+  double rx = end->x - start->x, ry = end->y - start->y, rz = end->z - start->z;
+  const double len2 = (rx * rx + ry * ry) + rz * rz;
+  if (good && max_length > 0 && len2 > max_length * max_length)
+  {
+    const double len = std::sqrt(len2);
+    rx /= len;
+    ry /= len;
+    rz /= len;
+    *end = dvec3{ start->x + rx * max_length, start->y + ry * max_length, start->z + rz * max_length };
+    *filter_flags |= kRffClippedEnd;
+  }
+  *filter_flags |= good ? 0u : unsigned(kRffInvalid);
+  return good;
+}
+
+/// ohm/RayFilter.cpp:61-78
+inline bool clipBounded(dvec3 *start, dvec3 *end, unsigned *filter_flags, const Aabb &clip_box)
+{
+  unsigned line_clip_flags = 0;
+  if (clip_box.clipLine(*start, *end, &line_clip_flags))
+  {
+    if (!clip_box.contains(*start) && !clip_box.contains(*end))
+    {
+      return false;
+    }
+  }
+  *filter_flags |= (line_clip_flags & Aabb::kClippedStart) ? unsigned(kRffClippedStart) : 0u;
+  *filter_flags |= (line_clip_flags & Aabb::kClippedEnd) ? unsigned(kRffClippedEnd) : 0u;
+  return true;
+}
+
+/// ohm/RayFilter.cpp:81-93
+inline bool clipToBounds(dvec3 * /*start*/, dvec3 *end, unsigned *filter_flags, const Aabb &clip_box)
+{
+  *filter_flags |= clip_box.contains(*end) ? unsigned(kRffClippedEnd) : 0u;
+  return true;
+}
 
 /// ohm/MapProbability.h:20-36 (float)
 inline float probabilityToValue(float probability) { return std::log(probability / (1.0f - probability)); }
@@ -204,6 +372,14 @@ public:
   void setRaySegmentLength(double length) { ray_segment_length_ = length; }
   double raySegmentLength() const { return ray_segment_length_; }
 
+  /// ohmgpu/GpuMap.cpp:348-369.  With a filter set, integrateRays() runs it per ray on the host, as the reference does
+  /// (GpuMap.cpp:736-746), and hands the surviving rays and their RayFilterFlag bits to the device; without one the
+  /// map's built-in filter (OccupancyMap::setRayFilter(mode, range)) runs on the device.
+  void setRayFilter(const RayFilterFunction &ray_filter) { ray_filter_ = ray_filter; }
+  const RayFilterFunction &rayFilter() const { return ray_filter_; }
+  const RayFilterFunction &effectiveRayFilter() const { return ray_filter_; }
+  void clearRayFilter() { ray_filter_ = RayFilterFunction(); }
+
   using RayMapper::integrateRays;
   /// ohmgpu/GpuMap.cpp:416: returns points integrated, 0 on failure (gpuOk() false, device error).
   size_t integrateRays(const dvec3 *rays, size_t element_count, const float *intensities, const double *timestamps,
@@ -214,6 +390,43 @@ public:
       return 0;
     }
     size_t integrated = 0;
+    if (ray_filter_)
+    {
+      std::vector<dvec3> kept;
+      std::vector<unsigned char> kept_flags;
+      std::vector<float> kept_intensities;
+      std::vector<double> kept_timestamps;
+      kept.reserve(element_count);
+      for (size_t i = 0; i + 1 < element_count; i += 2)
+      {
+        dvec3 start = rays[i], end = rays[i + 1];
+        unsigned filter_flags = 0;
+        if (!ray_filter_(&start, &end, &filter_flags))
+        {
+          continue;
+        }
+        kept.push_back(start);
+        kept.push_back(end);
+        kept_flags.push_back(static_cast<unsigned char>(filter_flags));
+        if (intensities)
+        {
+          kept_intensities.push_back(intensities[i >> 1]);
+        }
+        if (timestamps)
+        {
+          kept_timestamps.push_back(timestamps[i >> 1]);
+        }
+      }
+      if (kept.empty())
+      {
+        return 0;
+      }
+      last_status_ = ohmhip_map_integrate_rays_filtered(
+        handle_, reinterpret_cast<const double *>(kept.data()), kept.size(),
+        intensities ? kept_intensities.data() : nullptr, timestamps ? kept_timestamps.data() : nullptr,
+        ray_update_flags, kept_flags.data(), &integrated);
+      return (last_status_ == OHMHIP_OK) ? integrated : 0;
+    }
     last_status_ = ohmhip_map_integrate_rays(handle_, reinterpret_cast<const double *>(rays), element_count,
                                              intensities, timestamps, ray_update_flags, &integrated);
     return (last_status_ == OHMHIP_OK) ? integrated : 0;
@@ -379,6 +592,7 @@ protected:
   ohmhip_map_t handle_ = nullptr;
   double ray_segment_length_ = 0;
   int last_status_ = OHMHIP_OK;
+  RayFilterFunction ray_filter_;
 };
 
 /// ohm::GpuNdtMap (ohmgpu/GpuNdtMap.h:63-132).  NDT parameters default as in ohm/private/NdtMapDetail.h:20-45 and may

@@ -19,7 +19,7 @@ int main(int argc, char **argv)
 {
   if (argc < 6)
   {
-    std::fprintf(stderr, "usage: %s <occ|occmean|occdev|occcoalesce|occowner|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <occ|occmean|occdev|occcoalesce|occowner|occclipbox|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>\n", argv[0]);
     return 2;
   }
   const std::string mode = argv[1];
@@ -51,7 +51,8 @@ int main(int argc, char **argv)
 
     ohm::OccupancyMap map(resolution);
     std::unique_ptr<ohm::GpuMap> gpu_map;
-    if (mode == "occ" || mode == "occmean" || mode == "occdev" || mode == "occcoalesce" || mode == "occowner")
+    if (mode == "occ" || mode == "occmean" || mode == "occdev" || mode == "occcoalesce" || mode == "occowner" ||
+        mode == "occclipbox")
     {
       if (mode == "occmean")
       {
@@ -61,6 +62,14 @@ int main(int argc, char **argv)
       if (mode == "occcoalesce")
       {
         gpu_map->setBatchCoalescing(3 * batch_rays + 1);  // every fourth call launches a device batch
+      }
+      if (mode == "occclipbox")
+      {
+        // GpuMap.ClipBox (tests/ohmtestgpu/GpuMapTest.cpp:633-647): a RayFilterFunction wrapping clipBounded
+        const ohm::Aabb clip_box(ohm::dvec3{ -1.0, -1.0, -1.0 }, ohm::dvec3{ 2.0, 2.0, 2.0 });
+        gpu_map->setRayFilter([clip_box](ohm::dvec3 *start, ohm::dvec3 *end, unsigned *filter_flags) {
+          return ohm::clipBounded(start, end, filter_flags, clip_box);
+        });
       }
       if (mode == "occowner")
       {

@@ -62,6 +62,9 @@ struct OracleMap
   float min_value, max_value;
   int saturate_min, saturate_max;
   int filter_mode;
+  /* RayFilterFlag bits per ray of the NEXT integrate call, when the caller ran the RayFilterFunction itself (an
+   * arbitrary host function in the reference, ohm/RayFilter.h:45); NULL: the built-in filter below applies. */
+  const unsigned char *batch_filter_flags;
   double filter_range;
   double first_ray_time;
   /* NDT */
@@ -195,6 +198,11 @@ void oracle_map_set_saturation(OracleMap *m, int at_min, int at_max)
   m->saturate_min = at_min;
   m->saturate_max = at_max;
 }
+void oracle_map_set_batch_filter_flags(OracleMap *m, const unsigned char *flags)
+{
+  m->batch_filter_flags = flags;
+}
+
 void oracle_map_set_ray_filter(OracleMap *m, int mode, double range)
 {
   m->filter_mode = mode;
@@ -868,8 +876,15 @@ enum
 
 static int all_finite(const double v[3]) { return isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]); }
 
-static int apply_filter(const OracleMap *m, double start[3], double end[3], unsigned *filter_flags)
+static int apply_filter(const OracleMap *m, double start[3], double end[3], unsigned *filter_flags, size_t ray_index)
 {
+  if (m->batch_filter_flags)
+  {
+    /* the caller's filter already accepted (and possibly moved) the ray; its flags are consumed as the mappers do:
+     * ohm/RayMapperOccupancy.cpp:209-223 */
+    *filter_flags |= m->batch_filter_flags[ray_index];
+    return 1;
+  }
   if (m->filter_mode == ORACLE_FILTER_NONE)
   {
     return 1;
@@ -974,7 +989,7 @@ size_t oracle_integrate_occupancy(OracleMap *m, const double *rays, size_t eleme
     unsigned filter_flags = 0;
     double start[3] = { rays[3 * i + 0], rays[3 * i + 1], rays[3 * i + 2] };
     double end[3] = { rays[3 * i + 3], rays[3 * i + 4], rays[3 * i + 5] };
-    if (!apply_filter(m, start, end, &filter_flags))
+    if (!apply_filter(m, start, end, &filter_flags, i >> 1))
     {
       continue;
     }
@@ -1339,7 +1354,7 @@ size_t oracle_integrate_ndt(OracleMap *m, const double *rays, size_t element_cou
     {
       intensity = intensities[i >> 1];
     }
-    if (!apply_filter(m, ctx.start, ctx.sample, &filter_flags))
+    if (!apply_filter(m, ctx.start, ctx.sample, &filter_flags, i >> 1))
     {
       continue;
     }
@@ -1501,7 +1516,7 @@ size_t oracle_integrate_tsdf(OracleMap *m, const double *rays, size_t element_co
       ray_start[a] = ctx.sensor[a] = rays[3 * i + a];
       ray_end[a] = ctx.sample[a] = rays[3 * i + 3 + a];
     }
-    if (!apply_filter(m, ray_start, ray_end, &filter_flags))
+    if (!apply_filter(m, ray_start, ray_end, &filter_flags, i >> 1))
     {
       continue;
     }

@@ -103,6 +103,9 @@ void oracle_map_set_miss_value(OracleMap *map, float v);
 void oracle_map_set_min_max(OracleMap *map, float min_value, float max_value);
 void oracle_map_set_saturation(OracleMap *map, int at_min, int at_max);
 void oracle_map_set_ray_filter(OracleMap *map, int mode, double range);
+/* Per-ray RayFilterFlag bits (ohm/RayFilter.h:21-29: 1 invalid, 2 clipped start, 4 clipped end) for integrate calls whose rays the caller already passed through a
+ * RayFilterFunction; NULL restores the built-in filter.  The array must outlive the calls it covers. */
+void oracle_map_set_batch_filter_flags(OracleMap *map, const unsigned char *flags);
 float oracle_map_hit_value(const OracleMap *map);
 float oracle_map_miss_value(const OracleMap *map);
 /* NDT parameters: ohm/private/NdtMapDetail.h:20-45. adaptation_rate < 0 => derive from miss probability

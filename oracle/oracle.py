@@ -49,6 +49,8 @@ for _n in ("hit_probability", "miss_probability", "threshold_probability", "hit_
 lib.oracle_map_set_min_max.argtypes = [_vp, C.c_float, C.c_float]
 lib.oracle_map_set_saturation.argtypes = [_vp, C.c_int, C.c_int]
 lib.oracle_map_set_ray_filter.argtypes = [_vp, C.c_int, C.c_double]
+lib.oracle_map_set_batch_filter_flags.argtypes = [_vp, _vp]
+lib.oracle_map_set_batch_filter_flags.restype = None
 lib.oracle_map_hit_value.restype = C.c_float
 lib.oracle_map_hit_value.argtypes = [_vp]
 lib.oracle_map_miss_value.restype = C.c_float
@@ -168,23 +170,35 @@ class OracleMap:
         n = min(n, cap)
         return ([(tuple(keys[i].region), tuple(keys[i].local)) for i in range(n)], list(enter[:n]), list(exit_[:n]))
 
-    def integrate_occupancy(self, rays, timestamps=None, flags=0):
+    def _with_filter_flags(self, filter_flags, call):
+        """Run one integrate call on rays the caller already filtered (per-ray RayFilterFlag bits)."""
+        if filter_flags is None:
+            return call()
+        ff = np.ascontiguousarray(filter_flags, dtype=np.uint8)
+        lib.oracle_map_set_batch_filter_flags(self._h, ff.ctypes.data)
+        try:
+            return call()
+        finally:
+            lib.oracle_map_set_batch_filter_flags(self._h, None)
+
+    def integrate_occupancy(self, rays, timestamps=None, flags=0, filter_flags=None):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 3)
         ts = None if timestamps is None else np.ascontiguousarray(timestamps, dtype=np.float64)
-        return lib.oracle_integrate_occupancy(self._h, rays.ctypes.data, rays.shape[0],
-                                              None if ts is None else ts.ctypes.data, int(flags))
+        return self._with_filter_flags(filter_flags, lambda: lib.oracle_integrate_occupancy(
+            self._h, rays.ctypes.data, rays.shape[0], None if ts is None else ts.ctypes.data, int(flags)))
 
-    def integrate_ndt(self, rays, intensities=None, timestamps=None, flags=0):
+    def integrate_ndt(self, rays, intensities=None, timestamps=None, flags=0, filter_flags=None):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 3)
         ints = None if intensities is None else np.ascontiguousarray(intensities, dtype=np.float32)
         ts = None if timestamps is None else np.ascontiguousarray(timestamps, dtype=np.float64)
-        return lib.oracle_integrate_ndt(self._h, rays.ctypes.data, rays.shape[0],
-                                        None if ints is None else ints.ctypes.data,
-                                        None if ts is None else ts.ctypes.data, int(flags))
+        return self._with_filter_flags(filter_flags, lambda: lib.oracle_integrate_ndt(
+            self._h, rays.ctypes.data, rays.shape[0], None if ints is None else ints.ctypes.data,
+            None if ts is None else ts.ctypes.data, int(flags)))
 
-    def integrate_tsdf(self, rays):
+    def integrate_tsdf(self, rays, filter_flags=None):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 3)
-        return lib.oracle_integrate_tsdf(self._h, rays.ctypes.data, rays.shape[0])
+        return self._with_filter_flags(filter_flags,
+                                       lambda: lib.oracle_integrate_tsdf(self._h, rays.ctypes.data, rays.shape[0]))
 
     def visit_count(self):
         return int(lib.oracle_map_visit_count(self._h))

@@ -102,3 +102,21 @@ def test_cpp_batch_coalescing_and_region_ownership(gpu):
     mine = {tuple(int(v) for v in k) for k, o in zip(keys, D.region_owner(keys, 2, 0)) if o == 1}
     assert set(owned.keys()) == mine and len(mine) > 0
     assert_parity(compare_maps({k: expect[k] for k in mine}, owned, ["occupancy"], exact_float=True))
+
+
+def test_cpp_set_ray_filter_clip_box(gpu):
+    """GpuMap::setRayFilter with a RayFilterFunction wrapping clipBounded, as GpuMap.ClipBox does
+    (tests/ohmtestgpu/GpuMapTest.cpp:633-647): the C++ mirror's Aabb / clipBounded against the numpy restatement."""
+    from ohm_amd import rayfilter as RF
+    rays = synth.random_rays(6000, extent=4.0, seed=12, origin_spread=2.0)
+    filt = RF.clip_bounded(RF.Aabb((-1.0, -1.0, -1.0), (2.0, 2.0, 2.0)))
+    gpu_chunks = run_driver("occclipbox", 0.1, 2048, rays, 1)
+    om = OracleMap(0.1, layers=("occupancy",))
+    for i in range(0, rays.shape[0], 2 * 2048):
+        chunk = rays[i:i + 2 * 2048]
+        keep, starts, ends, flags = filt(chunk[0::2].copy(), chunk[1::2].copy())
+        kept = np.empty((2 * int(keep.sum()), 3))
+        kept[0::2] = starts[keep]
+        kept[1::2] = ends[keep]
+        om.integrate_occupancy(kept, filter_flags=flags[keep])
+    assert_parity(compare_maps(om.chunks(), gpu_chunks, ["occupancy"], exact_float=True))
