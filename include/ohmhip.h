@@ -189,6 +189,13 @@ void ohmhip_map_config_default(ohmhip_map_config *config); /* reference defaults
 int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config); /* GpuMap ctor + gpumap::enableGpu,
                                                                               ohmgpu/GpuMap.cpp:272, 106-122 */
 int ohmhip_map_destroy(ohmhip_map_t map);
+/* The reference GpuMap reads the OccupancyMap's probabilities, clamps and NDT / TSDF parameters at every launch
+ * (ohmgpu/GpuMap.cpp:1036-1191, GpuNdtMap.cpp:289-503), so setters called on the map after the GpuMap exists take
+ * effect from the next batch.  Same here: pass the configuration again; resolution, region dimensions, origin, mode and
+ * layer set must equal those of creation (OHMHIP_ERR_INVALID_ARG otherwise), everything else applies to batches
+ * presented afterwards.  One exception: the TSDF truncation distance of a map that already holds regions cannot
+ * change (OHMHIP_ERR_UNSUPPORTED; free-space TSDF updates are exact only against one truncation distance). */
+int ohmhip_map_update_config(ohmhip_map_t map, const ohmhip_map_config *config);
 
 /* GpuMap::integrateRays (ohmgpu/GpuMap.cpp:416, 540-875): rays = element_count dvec3 (origin, sample pairs).
  * Host-pointer form stages through one of two pinned blocks and uploads on a side stream, so batch N+1 is copied while

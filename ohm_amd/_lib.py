@@ -112,6 +112,7 @@ _sigs = {
     "ohmhip_map_mark_dirty": (C.c_int, [_vp, _vp, C.c_size_t]),
     "ohmhip_map_integrate_rays_filtered": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_uint, _vp,
                                                     C.POINTER(C.c_size_t)]),
+    "ohmhip_map_update_config": (C.c_int, [_vp, C.POINTER(MapConfig)]),
     "ohmhip_map_set_batch_coalescing": (C.c_int, [_vp, C.c_size_t]),
     "ohmhip_map_set_region_ownership": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_int]),
     "ohmhip_region_owner": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_uint32, _vp]),

@@ -475,6 +475,34 @@ __global__ void k_clear_counts(MapConst mc, RegionTable rt, BatchScratch bs, uin
 }
 
 /// One ray batch through the pipeline (all map modes).  d_rays: device pointer to 6 doubles per ray.
+/// The value half of the configuration (probabilities, clamps, filter, NDT / TSDF parameters): everything a host map can
+/// change between batches.  Geometry, mode and the layer set are fixed at creation.
+void applyValueConfig(ohmhip_map_t m)
+{
+  MapConst &mc = m->mc;
+  mc.hit_value = m->config.hit_value;
+  mc.miss_value = m->config.miss_value;
+  mc.threshold_value = m->config.threshold_value;
+  mc.min_value = m->config.min_value;
+  mc.max_value = m->config.max_value;
+  // ohm/RayMapperOccupancy.cpp:92-93
+  mc.sat_min = m->config.saturate_at_min ? mc.min_value : std::numeric_limits<float>::lowest();
+  mc.sat_max = m->config.saturate_at_max ? mc.max_value : std::numeric_limits<float>::max();
+  mc.filter_mode = m->config.ray_filter;
+  mc.filter_range = m->config.ray_filter_range;
+  mc.sensor_noise = m->config.ndt_sensor_noise;
+  mc.sample_threshold = m->config.ndt_sample_threshold;
+  mc.adaptation_rate = m->config.ndt_adaptation_rate;
+  mc.reinit_threshold = m->config.ndt_reinit_threshold;
+  mc.reinit_count = m->config.ndt_reinit_count;
+  mc.initial_intensity_cov = m->config.ndt_initial_intensity_cov;
+  mc.tsdf_max_weight = m->config.tsdf_max_weight;
+  mc.tsdf_trunc = m->config.tsdf_trunc;
+  mc.tsdf_dropoff = m->config.tsdf_dropoff;
+  mc.tsdf_sparsity = m->config.tsdf_sparsity;
+
+}
+
 int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensities, const double *d_timestamps,
                    uint32_t n_rays, unsigned ray_flags)
 {
@@ -1079,26 +1107,7 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
     delete m;
     return OHMHIP_ERR_UNSUPPORTED;  // region tile must fit the LDS count tile / 15-bit voxel index
   }
-  mc.hit_value = m->config.hit_value;
-  mc.miss_value = m->config.miss_value;
-  mc.threshold_value = m->config.threshold_value;
-  mc.min_value = m->config.min_value;
-  mc.max_value = m->config.max_value;
-  // ohm/RayMapperOccupancy.cpp:92-93
-  mc.sat_min = m->config.saturate_at_min ? mc.min_value : std::numeric_limits<float>::lowest();
-  mc.sat_max = m->config.saturate_at_max ? mc.max_value : std::numeric_limits<float>::max();
-  mc.filter_mode = m->config.ray_filter;
-  mc.filter_range = m->config.ray_filter_range;
-  mc.sensor_noise = m->config.ndt_sensor_noise;
-  mc.sample_threshold = m->config.ndt_sample_threshold;
-  mc.adaptation_rate = m->config.ndt_adaptation_rate;
-  mc.reinit_threshold = m->config.ndt_reinit_threshold;
-  mc.reinit_count = m->config.ndt_reinit_count;
-  mc.initial_intensity_cov = m->config.ndt_initial_intensity_cov;
-  mc.tsdf_max_weight = m->config.tsdf_max_weight;
-  mc.tsdf_trunc = m->config.tsdf_trunc;
-  mc.tsdf_dropoff = m->config.tsdf_dropoff;
-  mc.tsdf_sparsity = m->config.tsdf_sparsity;
+  applyValueConfig(m);
 
   int err = OHMHIP_OK;
   auto fail = [&](int e) {
@@ -1546,6 +1555,41 @@ int ohmhip_map_integrate_rays_filtered(ohmhip_map_t m, const double *rays, size_
     return OHMHIP_ERR_INVALID_ARG;
   }
   return integrateRaysHost(m, rays, element_count, intensities, timestamps, ray_flags, filter_flags, integrated);
+}
+
+int ohmhip_map_update_config(ohmhip_map_t m, const ohmhip_map_config *config)
+{
+  if (!m || !config)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  ohmhip_map_config wanted = *config;
+  for (int a = 0; a < 3; ++a)
+  {
+    wanted.region_dim[a] = (wanted.region_dim[a] <= 0) ? 32 : wanted.region_dim[a];
+    if (wanted.region_dim[a] != m->config.region_dim[a] || wanted.origin[a] != m->config.origin[a])
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+  }
+  if (wanted.resolution != m->config.resolution || wanted.mode != m->config.mode || wanted.layers != m->config.layers)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);  // batches already presented keep the values they were presented under
+  if (m->config.mode == OHMHIP_MODE_TSDF && wanted.tsdf_trunc != m->config.tsdf_trunc && m->slots_committed != 0)
+  {
+    // Free-space TSDF updates are applied as counts, which is exact only while every untouched-by-surface voxel sits at
+    // the truncation distance in force: a new distance on a populated map would be an approximation.
+    return OHMHIP_ERR_UNSUPPORTED;
+  }
+  const uint64_t gpu_mem_size = m->config.gpu_mem_size;
+  const uint32_t region_capacity = m->config.region_capacity;
+  m->config = wanted;
+  m->config.gpu_mem_size = gpu_mem_size;
+  m->config.region_capacity = region_capacity;
+  applyValueConfig(m);
+  return OHMHIP_OK;
 }
 
 int ohmhip_map_set_batch_coalescing(ohmhip_map_t m, size_t min_rays)

@@ -173,6 +173,21 @@ class GpuMap(RayMapper):
             layer_bits |= 1 << LAYERS[name][0]
         cfg.layers = layer_bits
         cfg.mode = self._mode
+        self._fill_map_values(cfg)
+        cfg.gpu_mem_size = int(gpu_mem_size)
+        cfg.region_capacity = int(region_capacity)
+        self._fill_config(cfg)
+        self._cfg = cfg
+        status = L.lib.ohmhip_map_create(C.byref(self._handle), C.byref(cfg))
+        # gputil::Exception from the ctor on allocation failure (ohmgpu/GpuMap.h:53-54,159-160)
+        L.check(status, "GpuMap: ohmhip_map_create")
+        self._ok = True
+        self._upload_existing()
+
+    def _fill_map_values(self, cfg):
+        """The host map's probabilities, clamps and built-in filter: re-read before every batch, like the reference,
+        whose GpuMap takes them from the OccupancyMap at each launch (ohmgpu/GpuMap.cpp:1036-1191)."""
+        map_ = self._map
         cfg.hit_value = float(map_.hit_value)
         cfg.miss_value = float(map_.miss_value)
         cfg.threshold_value = float(map_.occupancy_threshold_value)
@@ -183,15 +198,14 @@ class GpuMap(RayMapper):
         mode, rng = map_.ray_filter if map_.ray_filter else ("none", 0.0)
         cfg.ray_filter = {"none": L.FILTER_NONE, "good": L.FILTER_GOOD, "clip": L.FILTER_CLIP}[mode]
         cfg.ray_filter_range = float(rng)
-        cfg.gpu_mem_size = int(gpu_mem_size)
-        cfg.region_capacity = int(region_capacity)
-        self._fill_config(cfg)
-        self._cfg = cfg
-        status = L.lib.ohmhip_map_create(C.byref(self._handle), C.byref(cfg))
-        # gputil::Exception from the ctor on allocation failure (ohmgpu/GpuMap.h:53-54,159-160)
-        L.check(status, "GpuMap: ohmhip_map_create")
-        self._ok = True
-        self._upload_existing()
+
+    def _push_config_if_changed(self):
+        now = L.MapConfig.from_buffer_copy(bytes(self._cfg))
+        self._fill_map_values(now)
+        self._fill_config(now)
+        if bytes(now) != bytes(self._cfg):
+            L.check(L.lib.ohmhip_map_update_config(self._handle, C.byref(now)), "update_config")
+            self._cfg = now
 
     # hooks for subclasses ---------------------------------------------------------------------------------------
     def _configure_layers(self):
@@ -260,6 +274,7 @@ class GpuMap(RayMapper):
         (ohmgpu/GpuMap.cpp:416, 548-551, 874)."""
         if not self._ok:
             return 0
+        self._push_config_if_changed()
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 3)
         element_count = rays.shape[0]
         if element_count < 2:
@@ -433,7 +448,11 @@ class GpuNdtMap(GpuMap):
         cfg.ndt_initial_intensity_cov = self.initial_intensity_covariance
 
     def setSensorNoise(self, noise):
-        raise L.OhmHipError(L.ERR_UNSUPPORTED, "setSensorNoise after construction; set .sensor_noise before")
+        """GpuNdtMap::setSensorNoise (ohmgpu/GpuNdtMap.h:63-132): applies from the next batch."""
+        self.sensor_noise = float(noise)
+
+    def sensorNoise(self):
+        return self.sensor_noise
 
 
 class GpuTsdfMap(GpuMap):

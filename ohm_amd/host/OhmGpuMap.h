@@ -20,6 +20,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <string>
@@ -389,6 +390,10 @@ public:
     {
       return 0;
     }
+    if (!pushConfigIfChanged())
+    {
+      return 0;
+    }
     size_t integrated = 0;
     if (ray_filter_)
     {
@@ -445,6 +450,10 @@ public:
   size_t integrateRays(const gputil::Buffer &device_rays, size_t element_count, unsigned ray_update_flags = kRfDefault)
   {
     if (!gpuOk() || !device_rays.isValid() || element_count < 2)
+    {
+      return 0;
+    }
+    if (!pushConfigIfChanged())
     {
       return 0;
     }
@@ -521,7 +530,8 @@ protected:
     : map_(map)
     , borrowed_map_(borrowed_map)
   {
-    ohmhip_map_config cfg;
+    ohmhip_map_config &cfg = cfg_;
+    std::memset(&cfg, 0, sizeof(cfg));
     ohmhip_map_config_default(&cfg);
     cfg.resolution = map->resolution();
     for (int a = 0; a < 3; ++a)
@@ -530,15 +540,7 @@ protected:
       cfg.origin[a] = map->origin()[a];
     }
     cfg.mode = mode;
-    cfg.hit_value = map->hitValue();
-    cfg.miss_value = map->missValue();
-    cfg.threshold_value = map->occupancyThresholdValue();
-    cfg.min_value = map->minVoxelValue();
-    cfg.max_value = map->maxVoxelValue();
-    cfg.saturate_at_min = map->saturateAtMinValue();
-    cfg.saturate_at_max = map->saturateAtMaxValue();
-    cfg.ray_filter = map->rayFilterMode();
-    cfg.ray_filter_range = map->rayFilterRange();
+    fillMapValues(cfg);
     cfg.gpu_mem_size = gpu_mem_size;
     if (hook)
     {
@@ -548,6 +550,42 @@ protected:
     // gputil::Exception on allocation failure from the ctor (ohmgpu/GpuMap.h:53-54,159-160).
     OHMHIP_GPUAPICHECK(ohmhip_map_create(&handle_, &cfg));
     uploadExisting();
+  }
+
+  /// The host map's probabilities, clamps and built-in filter.
+  void fillMapValues(ohmhip_map_config &cfg) const
+  {
+    cfg.hit_value = map_->hitValue();
+    cfg.miss_value = map_->missValue();
+    cfg.threshold_value = map_->occupancyThresholdValue();
+    cfg.min_value = map_->minVoxelValue();
+    cfg.max_value = map_->maxVoxelValue();
+    cfg.saturate_at_min = map_->saturateAtMinValue();
+    cfg.saturate_at_max = map_->saturateAtMaxValue();
+    cfg.ray_filter = map_->rayFilterMode();
+    cfg.ray_filter_range = map_->rayFilterRange();
+  }
+  /// Mapper-specific parameters (NDT, TSDF) as they stand now.
+  virtual void fillMapperValues(ohmhip_map_config &) const {}
+
+  /// The reference reads the map's parameters at every launch (ohmgpu/GpuMap.cpp:1036-1191): setters called on the
+  /// OccupancyMap / mapper after construction apply from the next batch.
+  /// @return false when the device refuses the new values (lastStatus() says why); nothing is integrated then.
+  bool pushConfigIfChanged()
+  {
+    ohmhip_map_config now = cfg_;
+    fillMapValues(now);
+    fillMapperValues(now);
+    if (std::memcmp(&now, &cfg_, sizeof(now)) != 0)
+    {
+      last_status_ = ohmhip_map_update_config(handle_, &now);
+      if (last_status_ != OHMHIP_OK)
+      {
+        return false;
+      }
+      cfg_ = now;
+    }
+    return true;
   }
 
   /// gpumap::enableGpu + GpuLayerCache::upload for chunks the CPU map already holds.
@@ -593,6 +631,7 @@ protected:
   double ray_segment_length_ = 0;
   int last_status_ = OHMHIP_OK;
   RayFilterFunction ray_filter_;
+  ohmhip_map_config cfg_;
 };
 
 /// ohm::GpuNdtMap (ohmgpu/GpuNdtMap.h:63-132).  NDT parameters default as in ohm/private/NdtMapDetail.h:20-45 and may
@@ -620,6 +659,19 @@ public:
   {}
   NdtMode mode() const { return mode_; }
   float sensorNoise() const { return params_.sensor_noise; }
+  /// ohmgpu/GpuNdtMap.h (setSensorNoise) and the NdtMap setters reached through ndtMap() in the reference
+  /// (ohm/NdtMap.h:100-160): apply from the next batch.
+  void setSensorNoise(float noise) { params_.sensor_noise = noise; }
+  void setSampleThreshold(unsigned count) { params_.sample_threshold = count; }
+  void setAdaptationRate(float rate) { params_.adaptation_rate = rate; }
+  void setReinitialiseCovarianceThreshold(float value) { params_.reinitialise_covariance_threshold = value; }
+  void setReinitialiseCovariancePointCount(unsigned count) { params_.reinitialise_covariance_point_count = count; }
+  const NdtParams &ndtParams() const { return params_; }
+
+protected:
+  void fillMapperValues(ohmhip_map_config &cfg) const override { fill(cfg, const_cast<NdtParams *>(&params_)); }
+
+public:
 
   /// ohm/NdtMap.h:146-149
   static float ndtAdaptationRateFromMissProbability(float miss_probability, float scale = 2.0f)
@@ -680,6 +732,16 @@ public:
   const TsdfOptions &tsdfOptions() const { return options_; }
   float maxWeight() const { return options_.max_weight; }
   float defaultTruncationDistance() const { return options_.default_truncation_distance; }
+  /// ohmgpu/GpuTsdfMap.h:37-94 setters: apply from the next batch.
+  void setTsdfOptions(const TsdfOptions &options) { options_ = options; }
+  void setMaxWeight(float max_weight) { options_.max_weight = max_weight; }
+  void setDefaultTruncationDistance(float distance) { options_.default_truncation_distance = distance; }
+  void setSparsityCompensationFactor(float factor) { options_.sparsity_compensation_factor = factor; }
+
+protected:
+  void fillMapperValues(ohmhip_map_config &cfg) const override { fill(cfg, const_cast<TsdfOptions *>(&options_)); }
+
+public:
 
 private:
   static OccupancyMap *prepare(OccupancyMap *map)
