@@ -352,7 +352,9 @@ class GpuMap(RayMapper):
         return keys
 
     def syncVoxels(self, layer_names=None):
-        """ohmgpu/GpuMap.cpp:308-324: fence + copy modified regions back into the host MapChunk blocks."""
+        """ohmgpu/GpuMap.cpp:308-345: fence + copy modified regions back into the host MapChunk blocks -- every layer,
+        or only `layer_names` (the regions then stay marked as modified: there is one mark per region, not per layer, so
+        a later full syncVoxels() still brings the other layers over)."""
         if not self._ok:
             return
         keys = self.regionKeys(dirty_only=True)
@@ -371,7 +373,8 @@ class GpuMap(RayMapper):
             ptrs = (C.c_void_p * len(blocks))(*[b.ctypes.data for b in blocks])
             L.check(L.lib.ohmhip_map_read_regions(self._handle, lid, keys.ctypes.data, len(blocks), ptrs),
                     "syncVoxels")
-        L.check(L.lib.ohmhip_map_clear_dirty(self._handle), "clear_dirty")
+        if layer_names is None:
+            L.check(L.lib.ohmhip_map_clear_dirty(self._handle), "clear_dirty")
         self.wait()
 
     def setBatchCoalescing(self, min_rays):

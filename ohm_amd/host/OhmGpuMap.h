@@ -17,6 +17,7 @@
 
 #include "gputil_hip.h"
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -471,7 +472,14 @@ public:
 
   /// ohmgpu/GpuMap.cpp:308-324 -> GpuLayerCache::syncToMainMemory: fence, then copy regions modified on the device
   /// into the host chunks (every enabled layer).
-  void syncVoxels()
+  void syncVoxels() { syncLayers(nullptr); }
+
+  /// ohmgpu/GpuMap.cpp:327-345: only the listed layers (OHMHIP_LID_* ids here).  The regions stay marked as modified
+  /// -- there is one mark per region, not per layer -- so a later syncVoxels() still brings the other layers over.
+  void syncVoxels(const std::vector<int> &layer_indices) { syncLayers(&layer_indices); }
+
+private:
+  void syncLayers(const std::vector<int> *only)
   {
     if (!gpuOk())
     {
@@ -491,6 +499,10 @@ public:
       {
         continue;
       }
+      if (only && std::find(only->begin(), only->end(), layer) == only->end())
+      {
+        continue;
+      }
       std::vector<void *> dsts(count);
       for (size_t i = 0; i < count; ++i)
       {
@@ -500,9 +512,14 @@ public:
       }
       OHMHIP_GPUAPICHECK(ohmhip_map_read_regions(handle_, layer, keys.data(), count, dsts.data()));
     }
-    OHMHIP_GPUAPICHECK(ohmhip_map_clear_dirty(handle_));
+    if (!only)
+    {
+      OHMHIP_GPUAPICHECK(ohmhip_map_clear_dirty(handle_));
+    }
     OHMHIP_GPUAPICHECK(ohmhip_map_sync(handle_));
   }
+
+public:
 
   ohmhip_batch_stats lastBatchStats() const
   {

@@ -70,3 +70,27 @@ def test_pinned_host_memory(gpu):
     assert np.all(out == 7)
     L.check(L.lib.ohmhip_buffer_destroy(buf))
     L.check(L.lib.ohmhip_host_free(ptr))
+
+
+def test_sync_voxels_layer_subset_keeps_regions_marked(gpu):
+    """GpuMap::syncVoxels(layer_indices) (ohmgpu/GpuMap.cpp:327-345): only the listed layers come back; the others must
+    still arrive with the next full syncVoxels()."""
+    import numpy as np
+    from ohm_amd import GpuMap, OccupancyMap, synth
+    from oracle.oracle import OracleMap
+    layers = ("occupancy", "mean")
+    map_ = OccupancyMap(0.1, layers=layers)
+    gm = GpuMap(map_)
+    rays = synth.rays_c0(n=3000, length=3.0)
+    gm.integrateRays(rays)
+    gm.syncVoxels(layer_names=["occupancy"])
+    assert map_.chunks and all("occupancy" in c and "mean" not in c for c in map_.chunks.values())
+    om = OracleMap(0.1, layers=layers)
+    om.integrate_occupancy(rays)
+    expect = om.chunks()
+    for key, c in map_.chunks.items():
+        assert np.array_equal(c["occupancy"].view(np.uint32), expect[key]["occupancy"].view(np.uint32))
+    gm.syncVoxels()
+    for key, c in map_.chunks.items():
+        assert np.array_equal(c["mean"].view(np.uint32), expect[key]["mean"].view(np.uint32))
+    assert len(gm.regionKeys(dirty_only=True)) == 0
