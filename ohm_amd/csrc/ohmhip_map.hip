@@ -307,6 +307,16 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   {
     OHMHIP_CHECK(hipMemcpyAsync(new_slot_keys, m->d_slot_keys, sizeof(uint64_t) * keep, hipMemcpyDeviceToDevice, s));
   }
+  // The per-voxel mask is persistent state for NDT / TSDF (voxels that take the ordered replay path): it moves with
+  // the regions it describes.
+  const size_t mask_row = ((rv + 31) / 32) * sizeof(uint32_t);
+  uint32_t *new_mask = nullptr;
+  OHMHIP_CHECK(hipMalloc(&new_mask, mask_row * capacity));
+  OHMHIP_CHECK(hipMemsetAsync(new_mask, 0, mask_row * capacity, s));
+  if (keep && m->d_hit_mask)
+  {
+    OHMHIP_CHECK(hipMemcpyAsync(new_mask, m->d_hit_mask, mask_row * keep, hipMemcpyDeviceToDevice, s));
+  }
   uint32_t *new_dirty = nullptr;
   OHMHIP_CHECK(hipMalloc(&new_dirty, sizeof(uint32_t) * capacity));
   OHMHIP_CHECK(hipMemsetAsync(new_dirty, 0, sizeof(uint32_t) * capacity, s));
@@ -362,7 +372,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_begin), sizeof(uint32_t) * capacity);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_end), sizeof(uint32_t) * capacity);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_miss_counts), sizeof(uint32_t) * rv * capacity);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_mask), sizeof(uint32_t) * ((rv + 31) / 32) * capacity);
+  m->d_hit_mask = new_mask;
   m->chunk_capacity = capacity + (1u << 16);
   err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_chunks), sizeof(Chunk) * m->chunk_capacity);
   if (err)

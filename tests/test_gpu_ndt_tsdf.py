@@ -180,3 +180,50 @@ def test_ndt_and_tsdf_soak_mixed_batch_sizes(gpu):
     gt.syncVoxels()
     assert_parity(compare_maps(on.chunks(), map_n.chunks, list(map_n.layers), rel=1e-5))
     assert_parity(compare_maps(ot.chunks(), map_t.chunks, ["tsdf"], exact_float=True))
+
+
+def test_ndt_and_tsdf_survive_pool_growth(gpu):
+    """A small region pool that grows while the map is being built.  The per-voxel "ordered replay" mask is persistent
+    state for NDT / TSDF and has to move with the regions when the pool is re-allocated: a wall is sampled densely, the
+    pool is then grown by rays elsewhere, and finally rays are shot THROUGH the wall voxels (NDT misses against their
+    Gaussians, TSDF free-space updates of near-surface voxels)."""
+    origin = np.array([0.05, 0.05, 0.05])
+    g = np.arange(-2.0, 2.0, 0.07)
+    yy, zz = np.meshgrid(g, g, indexing="ij")
+
+    def rays_to(points):
+        out = np.empty((2 * len(points), 3))
+        out[0::2] = origin
+        out[1::2] = points
+        return out
+
+    wall = np.stack([np.full(yy.size, 5.0), yy.ravel(), zz.ravel()], axis=1)
+    phase1 = [rays_to(wall + np.array([0.013 * k, 0.011 * k, -0.007 * k])) for k in range(3)]
+    elsewhere = [rays_to(np.stack([np.full(yy.size, x), 3.0 * yy.ravel(), 3.0 * zz.ravel()], axis=1)) for x in (-9.0, -14.0)]
+    through = [rays_to(origin + 1.8 * (wall - origin))]
+    calls = phase1 + elsewhere + through + phase1[:1]
+
+    map_n = OccupancyMap(0.2, (32, 32, 32), layers=("occupancy",))
+    gn = GpuNdtMap(map_n, region_capacity=4)
+    on = make_oracle(map_n)
+    on.set_ndt(sensor_noise=gn.sensor_noise, sample_threshold=gn.sample_threshold, adaptation_rate=gn.adaptation_rate,
+               reinit_threshold=gn.reinitialise_covariance_threshold,
+               reinit_count=gn.reinitialise_covariance_point_count, ndt_tm=False)
+    map_t = OccupancyMap(0.1, (32, 32, 32), layers=("tsdf",))
+    gt = GpuTsdfMap(map_t, default_truncation_distance=0.2, region_capacity=4)
+    ot = make_oracle(map_t)
+    opts = gt.tsdf_options
+    ot.set_tsdf(max_weight=opts[0], trunc=opts[1], dropoff=opts[2], sparsity=opts[3])
+    resident = []
+    for chunk in calls:
+        assert gn.integrateRays(chunk) == chunk.shape[0]
+        assert gt.integrateRays(chunk) == chunk.shape[0]
+        on.integrate_ndt(chunk)
+        ot.integrate_tsdf(chunk)
+        resident.append((gn.stats()["regions_resident"], gt.stats()["regions_resident"]))
+    assert resident[2][0] < resident[4][0] and resident[2][1] < resident[4][1], resident  # the pools did grow
+    assert resident[4][0] > 4 and resident[4][1] > 4
+    gn.syncVoxels()
+    gt.syncVoxels()
+    assert_parity(compare_maps(on.chunks(), map_n.chunks, list(map_n.layers), rel=1e-5))
+    assert_parity(compare_maps(ot.chunks(), map_t.chunks, ["tsdf"], exact_float=True))
