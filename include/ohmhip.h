@@ -252,6 +252,11 @@ int ohmhip_map_write_regions(ohmhip_map_t map, int layer_id, const int16_t *keys
                              const void *const *srcs);
 /* GpuCache::clear / MapRegionCache::remove (ohmgpu/GpuCache.cpp, ohm/MapRegionCache.h): drop all regions. */
 int ohmhip_map_clear(ohmhip_map_t map);
+/* MapRegionCache::remove as the core map calls it when it drops regions (OccupancyMap::cullRegions ->
+ * gpu_cache->remove, ohm/OccupancyMap.cpp:1202-1234; GpuLayerCache::remove, ohmgpu/GpuLayerCache.cpp): the listed
+ * regions leave the device map (their voxels are discarded, modified or not -- sync first to keep them); unknown keys
+ * are ignored.  *removed = regions actually dropped. */
+int ohmhip_map_remove_regions(ohmhip_map_t map, const int16_t *keys_xyz, size_t count, size_t *removed);
 
 /* LineKeysQueryGpu / `calculateLines` (ohmgpu/LineKeysQueryGpu.cpp, ohmgpu/gpu/LineKeys.cl:66-100): the voxel keys on
  * `line_count` query lines (6 doubles each: start, end), in walk order, with the CPU walk's fp64 semantics.  keys_out is

@@ -102,6 +102,7 @@ _sigs = {
     "ohmhip_map_read_regions": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp]),
     "ohmhip_map_write_regions": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp]),
     "ohmhip_map_clear": (C.c_int, [_vp]),
+    "ohmhip_map_remove_regions": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ohmhip_transform_samples": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_double, _vp, _vp,
                                            C.POINTER(C.c_uint32)]),
     "ohmhip_map_batch_timings": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_float)]),

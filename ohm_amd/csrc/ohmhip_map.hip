@@ -2097,6 +2097,122 @@ int ohmhip_map_ensure_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t co
   return OHMHIP_OK;
 }
 
+int ohmhip_map_remove_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed)
+{
+  if (removed)
+  {
+    *removed = 0;
+  }
+  if (!m || (count && !keys_xyz))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);
+  hipStream_t s = m->stream;
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+  int err = refreshHostRegionTable(m);
+  if (err)
+  {
+    return err;
+  }
+  const uint32_t n = m->slots_committed;
+  std::vector<uint8_t> drop(n, 0);
+  uint32_t k = 0;
+  for (size_t i = 0; i < count; ++i)
+  {
+    const auto it = m->region_slots.find(packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]));
+    if (it != m->region_slots.end() && !drop[it->second])
+    {
+      drop[it->second] = 1;
+      ++k;
+    }
+  }
+  if (removed)
+  {
+    *removed = k;
+  }
+  if (k == 0)
+  {
+    return OHMHIP_OK;
+  }
+  // Slots stay dense: the survivors at the tail move into the holes the removed regions leave further down, the vacated
+  // tail goes back to the pristine state every unassigned slot is in, and the hash table is rebuilt from the slot keys.
+  const uint32_t new_n = n - k;
+  const size_t rv = size_t(m->mc.region_voxels);
+  const size_t mask_row = ((rv + 31) / 32) * sizeof(uint32_t);
+  uint32_t src = new_n;
+  for (uint32_t dst = 0; dst < new_n; ++dst)
+  {
+    if (!drop[dst])
+    {
+      continue;
+    }
+    while (drop[src])
+    {
+      ++src;
+    }
+    for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+    {
+      if (m->layers[l])
+      {
+        const size_t stride = rv * kLayerBytes[l];
+        OHMHIP_CHECK(hipMemcpyAsync(static_cast<char *>(m->layers[l]) + stride * dst,
+                                    static_cast<const char *>(m->layers[l]) + stride * src, stride,
+                                    hipMemcpyDeviceToDevice, s));
+      }
+    }
+    OHMHIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(m->d_hit_mask) + mask_row * dst,
+                                reinterpret_cast<const char *>(m->d_hit_mask) + mask_row * src, mask_row,
+                                hipMemcpyDeviceToDevice, s));
+    OHMHIP_CHECK(hipMemcpyAsync(m->d_dirty + dst, m->d_dirty + src, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    m->slot_keys_host[dst] = m->slot_keys_host[src];
+    ++src;
+  }
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    if (!m->layers[l])
+    {
+      continue;
+    }
+    const size_t stride = rv * kLayerBytes[l];
+    char *tail = static_cast<char *>(m->layers[l]) + stride * new_n;
+    if (l == OHMHIP_LID_OCCUPANCY)
+    {
+      hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint32_t *>(tail), 0x7f800000u,
+                         stride * k / 4);
+    }
+    else
+    {
+      OHMHIP_CHECK(hipMemsetAsync(tail, 0, stride * k, s));
+    }
+  }
+  OHMHIP_CHECK(hipMemsetAsync(reinterpret_cast<char *>(m->d_hit_mask) + mask_row * new_n, 0, mask_row * k, s));
+  OHMHIP_CHECK(hipMemsetAsync(m->d_dirty + new_n, 0, sizeof(uint32_t) * k, s));
+  m->slot_keys_host.resize(new_n);
+  m->region_slots.clear();
+  for (uint32_t i = 0; i < new_n; ++i)
+  {
+    m->region_slots[m->slot_keys_host[i]] = i;
+  }
+  OHMHIP_CHECK(hipMemsetAsync(m->d_slot_keys, 0, sizeof(uint64_t) * n, s));
+  if (new_n)
+  {
+    OHMHIP_CHECK(hipMemcpyAsync(m->d_slot_keys, m->slot_keys_host.data(), sizeof(uint64_t) * new_n,
+                                hipMemcpyHostToDevice, s));
+  }
+  OHMHIP_CHECK(hipMemsetAsync(m->d_keys, 0, sizeof(unsigned long long) * m->hash_capacity, s));
+  OHMHIP_CHECK(hipMemcpyAsync(m->d_n_slots, &new_n, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  if (new_n)
+  {
+    hipLaunchKernelGGL(k_rehash, dim3((new_n + 255) / 256), dim3(256), 0, s, regionTable(m), new_n);
+  }
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+  OHMHIP_CHECK(hipGetLastError());
+  m->slots_committed = new_n;
+  m->spec_bucket_ok = false;  // per-slot sample ranges of the previous batch no longer describe these slots
+  return OHMHIP_OK;
+}
+
 int ohmhip_map_mark_dirty(ohmhip_map_t m, const uint32_t *slots, size_t count)
 {
   OHMHIP_SETTLE(m);

@@ -337,6 +337,15 @@ class GpuMap(RayMapper):
     def wait(self):
         L.check(L.lib.ohmhip_map_sync(self._handle), "sync")
 
+    def removeRegions(self, keys):
+        """MapRegionCache::remove (what OccupancyMap::cullRegions calls on the GPU cache, ohm/OccupancyMap.cpp:1202-1234):
+        drop the listed regions from the device map.  Returns how many were resident."""
+        keys = np.ascontiguousarray(keys, dtype=np.int16).reshape(-1, 3)
+        removed = C.c_size_t(0)
+        L.check(L.lib.ohmhip_map_remove_regions(self._handle, keys.ctypes.data, len(keys), C.byref(removed)),
+                "removeRegions")
+        return int(removed.value)
+
     def clear(self):
         """OccupancyMap::clear() as the GPU cache sees it (GpuCache::clear, ohmgpu/GpuCache.cpp): drop every resident
         region; the host map's chunks are the caller's to clear."""

@@ -527,6 +527,15 @@ public:
     ohmhip_map_last_stats(handle_, &st);
     return st;
   }
+  /// MapRegionCache::remove, as OccupancyMap::cullRegions calls it on the map's GPU cache
+  /// (ohm/OccupancyMap.cpp:1202-1234): drop regions (packed int16 x, y, z triples) from the device map.
+  size_t removeRegions(const int16_t *keys_xyz, size_t count)
+  {
+    size_t removed = 0;
+    OHMHIP_GPUAPICHECK(ohmhip_map_remove_regions(handle_, keys_xyz, count, &removed));
+    return removed;
+  }
+
   /// Not in the reference: run consecutive small integrateRays() batches as one device batch of at least @p min_rays
   /// rays (see ohmhip_map_set_batch_coalescing); 0 turns it off.
   void setBatchCoalescing(size_t min_rays) { OHMHIP_GPUAPICHECK(ohmhip_map_set_batch_coalescing(handle_, min_rays)); }

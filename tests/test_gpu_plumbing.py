@@ -94,3 +94,50 @@ def test_sync_voxels_layer_subset_keeps_regions_marked(gpu):
     for key, c in map_.chunks.items():
         assert np.array_equal(c["mean"].view(np.uint32), expect[key]["mean"].view(np.uint32))
     assert len(gm.regionKeys(dirty_only=True)) == 0
+
+
+def test_remove_regions_restarts_them_and_keeps_the_rest(gpu):
+    """MapRegionCache::remove (OccupancyMap::cullRegions -> gpu_cache->remove, ohm/OccupancyMap.cpp:1202-1234): removed
+    regions leave the device map and start from scratch when rays reach them again; the others are untouched although
+    their slots may have moved.  Occupancy and NDT (whose per-voxel replay mask has to move with the slots)."""
+    import numpy as np
+    from ohm_amd import GpuMap, GpuNdtMap, OccupancyMap, synth
+    from parity import assert_parity, compare_maps, make_oracle
+    a = synth.rays_c1(n=20000, max_range=12.0, seed=21)
+    b = synth.rays_c1(n=20000, max_range=12.0, seed=22, first=7000)
+    for cls, layers, res in ((GpuMap, ("occupancy", "mean"), 0.1), (GpuNdtMap, ("occupancy",), 0.2)):
+        map_ = OccupancyMap(res, (32, 32, 32), layers=layers)
+        gm = cls(map_)
+        ndt = cls is GpuNdtMap
+
+        def oracle():
+            om = make_oracle(map_)
+            if ndt:
+                om.set_ndt(sensor_noise=gm.sensor_noise, sample_threshold=gm.sample_threshold,
+                           adaptation_rate=gm.adaptation_rate, reinit_threshold=gm.reinitialise_covariance_threshold,
+                           reinit_count=gm.reinitialise_covariance_point_count, ndt_tm=False)
+            return om
+
+        def integrate(om, rays):
+            om.integrate_ndt(rays) if ndt else om.integrate_occupancy(rays)
+
+        gm.integrateRays(a)
+        gm.syncVoxels()
+        keys = gm.regionKeys()
+        victims = keys[(keys[:, 0] + keys[:, 1] + keys[:, 2]) % 2 == 0]  # every other region, scattered over the slots
+        assert 0 < len(victims) < len(keys)
+        assert gm.removeRegions(np.concatenate([victims, [[30000, 0, 0]]])) == len(victims)  # unknown key: ignored
+        left = {tuple(k) for k in gm.regionKeys().tolist()}
+        assert left == {tuple(k) for k in keys.tolist()} - {tuple(k) for k in victims.tolist()}
+        for k in victims:
+            map_.chunks.pop(tuple(int(v) for v in k), None)  # the host side of cullRegions
+        gm.integrateRays(b)
+        gm.syncVoxels()
+        both, only_b = oracle(), oracle()
+        integrate(both, a)
+        integrate(both, b)
+        integrate(only_b, b)
+        victim_set = {tuple(int(v) for v in k) for k in victims}
+        expect = {k: (only_b.chunks()[k] if k in victim_set else v) for k, v in both.chunks().items()
+                  if k not in victim_set or k in only_b.chunks()}
+        assert_parity(compare_maps(expect, map_.chunks, list(map_.layers), rel=1e-5, exact_float=not ndt))
