@@ -337,6 +337,23 @@ class GpuMap(RayMapper):
     def wait(self):
         L.check(L.lib.ohmhip_map_sync(self._handle), "sync")
 
+    def gpuCache(self):
+        """GpuMap::gpuCache(): the MapRegionCache face of the reference's GpuCache (flush / clear / remove) as a view of
+        this map -- the whole map is resident, there is no separate cache object."""
+        owner = self
+
+        class _GpuCacheView:
+            def flush(self):
+                owner.syncVoxels()
+
+            def clear(self):
+                owner.clear()
+
+            def remove(self, region_key):
+                owner.removeRegions([region_key])
+
+        return _GpuCacheView()
+
     def removeRegions(self, keys):
         """MapRegionCache::remove (what OccupancyMap::cullRegions calls on the GPU cache, ohm/OccupancyMap.cpp:1202-1234):
         drop the listed regions from the device map.  Returns how many were resident."""

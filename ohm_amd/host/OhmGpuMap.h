@@ -527,6 +527,25 @@ public:
     ohmhip_map_last_stats(handle_, &st);
     return st;
   }
+  /// The MapRegionCache face of the reference's GpuCache (ohm/MapRegionCache.h; ohmgpu/GpuCache.h:80): what the core
+  /// map and the tests call through gpuCache() -- flush / clear / remove.  There is no separate cache object here (the
+  /// whole map is resident), so this is a view of the GpuMap.
+  class GpuCache
+  {
+  public:
+    explicit GpuCache(GpuMap *owner) : owner_(owner) {}
+    /// GpuCache::flush: bring the host map up to date.
+    void flush() { owner_->syncVoxels(); }
+    /// GpuCache::clear: drop every resident region (modified or not).
+    void clear() { OHMHIP_GPUAPICHECK(ohmhip_map_clear(owner_->handle_)); }
+    /// MapRegionCache::remove(region_key)
+    void remove(const std::array<int16_t, 3> &region_key) { owner_->removeRegions(region_key.data(), 1); }
+
+  private:
+    GpuMap *owner_;
+  };
+  GpuCache *gpuCache() { return &cache_view_; }
+
   /// MapRegionCache::remove, as OccupancyMap::cullRegions calls it on the map's GPU cache
   /// (ohm/OccupancyMap.cpp:1202-1234): drop regions (packed int16 x, y, z triples) from the device map.
   size_t removeRegions(const int16_t *keys_xyz, size_t count)
@@ -658,6 +677,7 @@ protected:
   int last_status_ = OHMHIP_OK;
   RayFilterFunction ray_filter_;
   ohmhip_map_config cfg_;
+  GpuCache cache_view_{ this };
 };
 
 /// ohm::GpuNdtMap (ohmgpu/GpuNdtMap.h:63-132).  NDT parameters default as in ohm/private/NdtMapDetail.h:20-45 and may

@@ -128,6 +128,10 @@ int main(int argc, char **argv)
         total += gpu_map->integrateRays(rays.data() + i, count, nullptr, nullptr, ohm::kRfDefault);
       }
     }
+    if (mode == "occcoalesce")
+    {
+      gpu_map->gpuCache()->flush();  // GpuCache::flush == syncVoxels
+    }
     gpu_map->syncVoxels();
     std::printf("integrated %zu of %llu points, %zu regions\n", total, (unsigned long long)n_points, map.regionCount());
 
