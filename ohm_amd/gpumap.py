@@ -430,14 +430,28 @@ class GpuMap(RayMapper):
 
     def _upload_existing(self):
         """gpumap::enableGpu + GpuLayerCache::upload for regions the CPU map already holds."""
+        self.uploadRegions()
+
+    def uploadRegions(self, keys=None):
+        """Push host chunks to the device: all of them, or the listed regions -- what GpuLayerCache::upload does for a
+        region whose CPU copy is newer than the device's (ohmgpu/GpuLayerCache.cpp:172-182), e.g. after CPU-side
+        integration into the host map.  Layers a chunk does not hold keep their device contents."""
         if not self._map.chunks:
-            return
-        keys = np.array(sorted(self._map.chunks.keys()), dtype=np.int16).reshape(-1, 3)
+            return 0
+        if keys is None:
+            keys = sorted(self._map.chunks.keys())
+        keys = np.ascontiguousarray(keys, dtype=np.int16).reshape(-1, 3)
+        keys = np.array([k for k in keys if tuple(int(v) for v in k) in self._map.chunks], dtype=np.int16).reshape(-1, 3)
         for name in self._map.layers:
             lid, dtype, comps = LAYERS[name]
-            blocks = [np.ascontiguousarray(self._map.chunks[tuple(int(v) for v in k)][name], dtype=dtype) for k in keys]
+            have = [k for k in keys if name in self._map.chunks[tuple(int(v) for v in k)]]
+            if not have:
+                continue
+            sub = np.ascontiguousarray(np.array(have, dtype=np.int16).reshape(-1, 3))
+            blocks = [np.ascontiguousarray(self._map.chunks[tuple(int(v) for v in k)][name], dtype=dtype) for k in sub]
             ptrs = (C.c_void_p * len(blocks))(*[b.ctypes.data for b in blocks])
-            L.check(L.lib.ohmhip_map_write_regions(self._handle, lid, keys.ctypes.data, len(blocks), ptrs), "upload")
+            L.check(L.lib.ohmhip_map_write_regions(self._handle, lid, sub.ctypes.data, len(blocks), ptrs), "upload")
+        return len(keys)
 
 
 class GpuNdtMap(GpuMap):

@@ -76,3 +76,31 @@ def test_ndt_and_tsdf_continue_from_a_cpu_built_map(gpu):
     gt.syncVoxels()
     ot.integrate_tsdf(second)
     assert_parity(compare_maps(ot.chunks(), map_t.chunks, ["tsdf"], exact_float=True))
+
+
+def test_cpu_side_integration_between_device_batches(gpu):
+    """Mixed use: the device integrates A, the host map is synced and the CPU integrates X into it, the touched regions
+    are pushed back (GpuLayerCache::upload of CPU-newer regions) and the device integrates B: CPU result of A + X + B."""
+    layers = ("occupancy", "mean")
+    a = synth.rays_c1(n=12000, max_range=9.0, seed=71)
+    x = synth.random_rays(5000, extent=5.0, seed=72, origin_spread=2.0)
+    b = synth.rays_c1(n=12000, max_range=9.0, seed=73, first=3000)
+    map_ = OccupancyMap(0.1, layers=layers)
+    gm = GpuMap(map_)
+    gm.integrateRays(a)
+    gm.syncVoxels()
+    om = make_oracle(map_)
+    om.integrate_occupancy(a)
+    before = {k: {n: v.copy() for n, v in c.items()} for k, c in om.chunks().items()}
+    om.integrate_occupancy(x)  # the CPU mapper working on the host map
+    after = om.chunks()
+    edited = [k for k, c in after.items()
+              if k not in before or any(not np.array_equal(c[n].view(np.uint32), before[k][n].view(np.uint32)) for n in layers)]
+    assert edited
+    for k in edited:
+        map_.chunks[k] = {n: after[k][n].copy() for n in layers}
+    assert gm.uploadRegions(edited) == len(edited)
+    gm.integrateRays(b)
+    gm.syncVoxels()
+    om.integrate_occupancy(b)
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
