@@ -634,18 +634,14 @@ protected:
   }
 
   /// gpumap::enableGpu + GpuLayerCache::upload for chunks the CPU map already holds.
-  void uploadExisting()
+  void uploadExisting() { uploadRegions(nullptr, 0); }
+
+public:
+  /// Push host chunks to the device: all of them (keys_xyz == nullptr) or the listed regions -- what
+  /// GpuLayerCache::upload does for a region whose CPU copy is newer than the device's
+  /// (ohmgpu/GpuLayerCache.cpp:172-182), e.g. after CPU-side integration into the host map.
+  void uploadRegions(const int16_t *keys_xyz, size_t count)
   {
-    if (map_->chunks().empty())
-    {
-      return;
-    }
-    std::vector<int16_t> keys;
-    for (const auto &entry : map_->chunks())
-    {
-      keys.insert(keys.end(), entry.first.begin(), entry.first.end());
-    }
-    const size_t count = keys.size() / 3;
     for (int layer = 0; layer < OHMHIP_LID_COUNT; ++layer)
     {
       if (!map_->hasLayer(layer))
@@ -654,12 +650,30 @@ protected:
       }
       std::vector<const void *> srcs;
       std::vector<int16_t> layer_keys;
-      for (const auto &entry : map_->chunks())
-      {
-        if (entry.second.voxel_blocks.size() > size_t(layer) && !entry.second.voxel_blocks[layer].empty())
+      auto take = [&](const std::array<int16_t, 3> &key, const MapChunk &chunk) {
+        if (chunk.voxel_blocks.size() > size_t(layer) && !chunk.voxel_blocks[layer].empty())
         {
-          srcs.push_back(entry.second.voxel_blocks[layer].data());
-          layer_keys.insert(layer_keys.end(), entry.first.begin(), entry.first.end());
+          srcs.push_back(chunk.voxel_blocks[layer].data());
+          layer_keys.insert(layer_keys.end(), key.begin(), key.end());
+        }
+      };
+      if (!keys_xyz)
+      {
+        for (const auto &entry : map_->chunks())
+        {
+          take(entry.first, entry.second);
+        }
+      }
+      else
+      {
+        for (size_t i = 0; i < count; ++i)
+        {
+          const std::array<int16_t, 3> key{ { keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2] } };
+          const auto found = map_->chunks().find(key);
+          if (found != map_->chunks().end())
+          {
+            take(found->first, found->second);
+          }
         }
       }
       if (!srcs.empty())
@@ -667,9 +681,9 @@ protected:
         OHMHIP_GPUAPICHECK(ohmhip_map_write_regions(handle_, layer, layer_keys.data(), srcs.size(), srcs.data()));
       }
     }
-    (void)count;
   }
 
+protected:
   OccupancyMap *map_ = nullptr;
   bool borrowed_map_ = true;
   ohmhip_map_t handle_ = nullptr;
