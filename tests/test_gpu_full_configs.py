@@ -82,3 +82,46 @@ def test_c3_tsdf_first_revolution_vs_oracle_and_full_properties(gpu):
     w = np.concatenate([c["tsdf"].reshape(-1, 2)[:, 0] for c in map_a.chunks.values()])
     d = np.concatenate([c["tsdf"].reshape(-1, 2)[:, 1] for c in map_a.chunks.values()])
     assert w.max() <= 1e4 and np.all(np.abs(d) <= np.float32(0.1))
+
+
+def test_c4_shards_one_call_of_4m_rays_equals_four_calls(gpu):
+    """C4's ray sets (one sensor origin per shard): four shards through ONE map in a single 4 M-ray call and in four
+    1 M-ray calls.  Size-independent properties at a size the oracle is too slow for: the exact visit count and
+    bit-identical maps whatever the batch split (every voxel's events are applied in ray order)."""
+    shards = [synth.rays_c4_shard(r, n=1_000_000) for r in range(4)]
+    rays = np.concatenate(shards)
+    layers = ("occupancy", "mean")
+    one, four = OccupancyMap(0.1, layers=layers), OccupancyMap(0.1, layers=layers)
+    g1 = GpuMap(one, gpu_mem_size=8 << 30)
+    g4 = GpuMap(four, gpu_mem_size=8 << 30)
+    assert g1.integrateRays(rays) == rays.shape[0]
+    visits = g1.stats()["voxel_visits"]
+    total4 = 0
+    for s in shards:
+        assert g4.integrateRays(s) == s.shape[0]
+        total4 += g4.stats()["voxel_visits"]
+    # (the closed form of expected_visits() does not apply: these sensor origins sit exactly on voxel boundaries, where
+    # ohm's region / local key arithmetic and a plain floor(p / res) round differently)
+    assert visits == total4 and visits > 10 ** 9
+    g1.syncVoxels()
+    g4.syncVoxels()
+    assert set(one.chunks) == set(four.chunks) and len(one.chunks) > 3000
+    for key, c in one.chunks.items():
+        for name in layers:
+            assert np.array_equal(c[name].view(np.uint32), four.chunks[key][name].view(np.uint32)), (key, name)
+
+
+def test_c4_shard_origin_on_voxel_boundaries_matches_oracle(gpu):
+    """The C4 sensor origins (-60, -20, ...) sit exactly on voxel and region boundaries: ohm's key arithmetic
+    (region = floor(p / R + 0.5), local = floor((p - region_min) / res) with its 1e-6 edge fix-ups, ohm/MapCoord.h:45-93)
+    decides which voxel such a point belongs to, and the device has to decide the same way."""
+    for shard in (0, 5):
+        rays = synth.rays_c4_shard(shard, n=30000)
+        map_ = OccupancyMap(0.1, layers=("occupancy", "mean"))
+        gm = GpuMap(map_)
+        assert gm.integrateRays(rays) == rays.shape[0]
+        gm.syncVoxels()
+        om = make_oracle(map_)
+        om.integrate_occupancy(rays)
+        assert om.visit_count() == gm.stats()["voxel_visits"]
+        assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
