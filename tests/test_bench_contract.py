@@ -1,0 +1,42 @@
+"""CPU: the committed default bench line (profiles/r01_bench_default.json, produced by `python bench.py` on an MI355X)
+carries every field the bench contract names, with consistent arithmetic."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    with open(os.path.join(ROOT, "profiles", "r01_bench_default.json")) as fh:
+        line = json.load(fh)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["data"] == "synthetic" and line["dtype"] == "f64"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    rays = line["config"]["rays_per_step_per_gpu"]
+    assert abs(line["value"] - rays / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # achieved = algorithmic bytes per launch / the kernel's average duration (HIP events)
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * roof["achieved"]
+    visits = line["config"]["voxel_visits_per_step"]
+    assert roof["algorithmic_bytes_per_launch"] == 44 * rays + 8 * visits
+    cpu = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] == 1 and cpu["unit"] == "rays/s"
+
+
+def test_traffic_file_matches_the_profile_it_cites():
+    with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+        traffic = json.load(fh)
+    expect = (traffic["fetch_size_kb"] * traffic["fetch_correction"] + traffic["write_size_kb"]) * 1024.0
+    assert abs(traffic["traffic_bytes_per_launch"] - expect) < 1.0
+    summary = open(os.path.join(ROOT, "profiles", "r01_profile_final.txt")).read()
+    assert "k_region_walk" in summary and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary
+    assert f"{traffic['fetch_size_kb']:.1f}" in summary and f"{traffic['write_size_kb']:.1f}" in summary
