@@ -37,6 +37,7 @@ const char *ohmhip_error_string(int status)
 }
 
 int ohmhip_device_count(int *count)
+try
 {
   if (!count)
   {
@@ -51,14 +52,18 @@ int ohmhip_device_count(int *count)
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_device_select(int device)
+try
 {
   OHMHIP_CHECK(hipSetDevice(device));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_device_get_info(int device, ohmhip_device_info *info)
+try
 {
   if (!info)
   {
@@ -76,8 +81,10 @@ int ohmhip_device_get_info(int device, ohmhip_device_info *info)
   info->unified_memory = prop.integrated;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_stream_create(ohmhip_stream_t *stream)
+try
 {
   if (!stream)
   {
@@ -88,8 +95,10 @@ int ohmhip_stream_create(ohmhip_stream_t *stream)
   *stream = new (std::nothrow) ohmhip_stream_s{ s };
   return *stream ? OHMHIP_OK : OHMHIP_ERR_INTERNAL;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_stream_destroy(ohmhip_stream_t stream)
+try
 {
   if (!stream)
   {
@@ -99,14 +108,18 @@ int ohmhip_stream_destroy(ohmhip_stream_t stream)
   delete stream;
   return static_cast<int>(err);
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_stream_finish(ohmhip_stream_t stream)
+try
 {
   OHMHIP_CHECK(hipStreamSynchronize(stream ? stream->stream : nullptr));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_stream_wait_event(ohmhip_stream_t stream, ohmhip_event_t event)
+try
 {
   if (!event)
   {
@@ -119,8 +132,10 @@ int ohmhip_stream_wait_event(ohmhip_stream_t stream, ohmhip_event_t event)
   OHMHIP_CHECK(hipStreamWaitEvent(stream ? stream->stream : nullptr, event->event, 0));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_event_create(ohmhip_event_t *event)
+try
 {
   if (!event)
   {
@@ -131,8 +146,10 @@ int ohmhip_event_create(ohmhip_event_t *event)
   *event = new (std::nothrow) ohmhip_event_s{ e, false };
   return *event ? OHMHIP_OK : OHMHIP_ERR_INTERNAL;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_event_destroy(ohmhip_event_t event)
+try
 {
   if (!event)
   {
@@ -142,8 +159,10 @@ int ohmhip_event_destroy(ohmhip_event_t event)
   delete event;
   return static_cast<int>(err);
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_event_record(ohmhip_event_t event, ohmhip_stream_t stream)
+try
 {
   if (!event)
   {
@@ -153,8 +172,10 @@ int ohmhip_event_record(ohmhip_event_t event, ohmhip_stream_t stream)
   event->recorded = true;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_event_wait(ohmhip_event_t event)
+try
 {
   if (!event)
   {
@@ -167,8 +188,10 @@ int ohmhip_event_wait(ohmhip_event_t event)
   OHMHIP_CHECK(hipEventSynchronize(event->event));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_event_is_complete(ohmhip_event_t event, int *complete)
+try
 {
   if (!event || !complete)
   {
@@ -192,8 +215,10 @@ int ohmhip_event_is_complete(ohmhip_event_t event, int *complete)
   }
   return static_cast<int>(err);
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_event_elapsed_ms(ohmhip_event_t start, ohmhip_event_t stop, float *ms)
+try
 {
   if (!start || !stop || !ms)
   {
@@ -202,8 +227,10 @@ int ohmhip_event_elapsed_ms(ohmhip_event_t start, ohmhip_event_t stop, float *ms
   OHMHIP_CHECK(hipEventElapsedTime(ms, start->event, stop->event));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_buffer_create(ohmhip_buffer_t *buffer, size_t bytes, unsigned flags)
+try
 {
   if (!buffer)
   {
@@ -224,6 +251,7 @@ int ohmhip_buffer_create(ohmhip_buffer_t *buffer, size_t bytes, unsigned flags)
   *buffer = new (std::nothrow) ohmhip_buffer_s{ ptr, bytes, flags };
   return *buffer ? OHMHIP_OK : OHMHIP_ERR_INTERNAL;
 }
+OHMHIP_ABI_CATCH
 
 static int freeBufferMemory(ohmhip_buffer_t buffer)
 {
@@ -238,6 +266,7 @@ static int freeBufferMemory(ohmhip_buffer_t buffer)
 }
 
 int ohmhip_buffer_destroy(ohmhip_buffer_t buffer)
+try
 {
   if (!buffer)
   {
@@ -247,8 +276,10 @@ int ohmhip_buffer_destroy(ohmhip_buffer_t buffer)
   delete buffer;
   return err;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_buffer_resize(ohmhip_buffer_t buffer, size_t bytes, size_t *actual)
+try
 {
   if (!buffer)
   {
@@ -281,8 +312,10 @@ int ohmhip_buffer_resize(ohmhip_buffer_t buffer, size_t bytes, size_t *actual)
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_buffer_size(ohmhip_buffer_t buffer, size_t *bytes)
+try
 {
   if (!buffer || !bytes)
   {
@@ -291,8 +324,10 @@ int ohmhip_buffer_size(ohmhip_buffer_t buffer, size_t *bytes)
   *bytes = buffer->bytes;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_buffer_ptr(ohmhip_buffer_t buffer, void **device_ptr)
+try
 {
   if (!buffer || !device_ptr)
   {
@@ -301,6 +336,7 @@ int ohmhip_buffer_ptr(ohmhip_buffer_t buffer, void **device_ptr)
   *device_ptr = buffer->ptr;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 static int copyCommon(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, ohmhip_stream_t stream,
                       ohmhip_event_t block_on, ohmhip_event_t completion)
@@ -334,6 +370,7 @@ static int copyCommon(void *dst, const void *src, size_t bytes, hipMemcpyKind ki
 
 int ohmhip_buffer_write(ohmhip_buffer_t buffer, const void *src, size_t bytes, size_t dst_offset,
                         ohmhip_stream_t stream, ohmhip_event_t block_on, ohmhip_event_t completion)
+try
 {
   if (!buffer || (!src && bytes) || dst_offset + bytes > buffer->bytes)
   {
@@ -342,9 +379,11 @@ int ohmhip_buffer_write(ohmhip_buffer_t buffer, const void *src, size_t bytes, s
   return copyCommon(static_cast<char *>(buffer->ptr) + dst_offset, src, bytes, hipMemcpyHostToDevice, stream, block_on,
                     completion);
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_buffer_read(ohmhip_buffer_t buffer, void *dst, size_t bytes, size_t src_offset, ohmhip_stream_t stream,
                        ohmhip_event_t block_on, ohmhip_event_t completion)
+try
 {
   if (!buffer || (!dst && bytes) || src_offset + bytes > buffer->bytes)
   {
@@ -353,8 +392,10 @@ int ohmhip_buffer_read(ohmhip_buffer_t buffer, void *dst, size_t bytes, size_t s
   return copyCommon(dst, static_cast<const char *>(buffer->ptr) + src_offset, bytes, hipMemcpyDeviceToHost, stream,
                     block_on, completion);
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_buffer_fill(ohmhip_buffer_t buffer, int byte_value, size_t bytes, size_t offset, ohmhip_stream_t stream)
+try
 {
   if (!buffer || offset + bytes > buffer->bytes)
   {
@@ -375,8 +416,10 @@ int ohmhip_buffer_fill(ohmhip_buffer_t buffer, int byte_value, size_t bytes, siz
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_host_alloc(void **ptr, size_t bytes)
+try
 {
   if (!ptr)
   {
@@ -385,8 +428,10 @@ int ohmhip_host_alloc(void **ptr, size_t bytes)
   OHMHIP_CHECK(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_host_free(void *ptr)
+try
 {
   if (ptr)
   {
@@ -394,5 +439,6 @@ int ohmhip_host_free(void *ptr)
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <new>
 
 #include "../../include/ohmhip.h"
 
@@ -18,6 +19,17 @@
       return err__;                       \
     }                                     \
   } while (0)
+
+/// Closes the function-try-block of every entry point: no C++ exception crosses the C ABI (include/ohmhip.h).
+#define OHMHIP_ABI_CATCH                \
+  catch (const std::bad_alloc &)        \
+  {                                     \
+    return OHMHIP_ERR_CAPACITY;         \
+  }                                     \
+  catch (...)                           \
+  {                                     \
+    return OHMHIP_ERR_INTERNAL;         \
+  }
 
 struct ohmhip_stream_s
 {

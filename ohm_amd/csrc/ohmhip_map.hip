@@ -1073,6 +1073,7 @@ void ohmhip_map_config_default(ohmhip_map_config *c)
 }
 
 int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
+try
 {
   if (!map || !config || !(config->resolution > 0))
   {
@@ -1242,8 +1243,10 @@ int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config)
   *map = m;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_destroy(ohmhip_map_t m)
+try
 {
   if (!m)
   {
@@ -1335,6 +1338,7 @@ int ohmhip_map_destroy(ohmhip_map_t m)
   delete m;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 }  // extern "C"
 
@@ -1438,6 +1442,7 @@ extern "C" {
 int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_t element_count,
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
                                      size_t *integrated)
+try
 {
   if (integrated)
   {
@@ -1446,6 +1451,7 @@ int ohmhip_map_integrate_rays_device(ohmhip_map_t m, const double *d_rays, size_
   OHMHIP_SETTLE(m);  // batches presented earlier through the host entry point come first
   return integrateRaysDevice(m, d_rays, element_count, d_intensities, d_timestamps, ray_flags, integrated);
 }
+OHMHIP_ABI_CATCH
 
 }  // extern "C"
 
@@ -1548,13 +1554,16 @@ extern "C" {
 
 int ohmhip_map_integrate_rays(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
                               const double *timestamps, unsigned ray_flags, size_t *integrated)
+try
 {
   return integrateRaysHost(m, rays, element_count, intensities, timestamps, ray_flags, nullptr, integrated);
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_integrate_rays_filtered(ohmhip_map_t m, const double *rays, size_t element_count,
                                        const float *intensities, const double *timestamps, unsigned ray_flags,
                                        const unsigned char *filter_flags, size_t *integrated)
+try
 {
   if (!filter_flags && element_count >= 2)
   {
@@ -1566,8 +1575,10 @@ int ohmhip_map_integrate_rays_filtered(ohmhip_map_t m, const double *rays, size_
   }
   return integrateRaysHost(m, rays, element_count, intensities, timestamps, ray_flags, filter_flags, integrated);
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_update_config(ohmhip_map_t m, const ohmhip_map_config *config)
+try
 {
   if (!m || !config)
   {
@@ -1601,8 +1612,10 @@ int ohmhip_map_update_config(ohmhip_map_t m, const ohmhip_map_config *config)
   applyValueConfig(m);
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_set_batch_coalescing(ohmhip_map_t m, size_t min_rays)
+try
 {
   if (!m)
   {
@@ -1612,8 +1625,10 @@ int ohmhip_map_set_batch_coalescing(ohmhip_map_t m, size_t min_rays)
   m->coalesce_min_rays = min_rays;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_sync(ohmhip_map_t m)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m)
@@ -1653,8 +1668,10 @@ int ohmhip_map_sync(ohmhip_map_t m)
   OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_batch_timings(ohmhip_map_t m, uint32_t batches_back, float ms[4])
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || !ms)
@@ -1676,8 +1693,10 @@ int ohmhip_map_batch_timings(ohmhip_map_t m, uint32_t batches_back, float ms[4])
   ms[3] = sort_ms + apply_ms;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_last_stats(ohmhip_map_t m, ohmhip_batch_stats *stats)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || !stats)
@@ -1699,8 +1718,10 @@ int ohmhip_map_last_stats(ohmhip_map_t m, ohmhip_batch_stats *stats)
   *stats = m->stats;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_region_count(ohmhip_map_t m, size_t *count)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || !count)
@@ -1710,8 +1731,10 @@ int ohmhip_map_region_count(ohmhip_map_t m, size_t *count)
   *count = m->slots_committed;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity, size_t *count)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || !count)
@@ -1731,8 +1754,10 @@ int ohmhip_map_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity, size_
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_dirty_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity, size_t *count)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || !count)
@@ -1765,8 +1790,10 @@ int ohmhip_map_dirty_regions(ohmhip_map_t m, int16_t *keys_xyz, size_t capacity,
   *count = n;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_clear_dirty(ohmhip_map_t m)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m)
@@ -1776,8 +1803,10 @@ int ohmhip_map_clear_dirty(ohmhip_map_t m)
   OHMHIP_CHECK(hipMemsetAsync(m->d_dirty, 0, sizeof(uint32_t) * m->slot_capacity, m->stream));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_region_slot(ohmhip_map_t m, const int16_t key_xyz[3], uint32_t *slot)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || !key_xyz || !slot)
@@ -1798,8 +1827,10 @@ int ohmhip_map_region_slot(ohmhip_map_t m, const int16_t key_xyz[3], uint32_t *s
   *slot = it->second;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_device_layer_ptr(ohmhip_map_t m, int layer_id, void **device_ptr, size_t *region_stride_bytes)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || !device_ptr)
@@ -1817,8 +1848,10 @@ int ohmhip_map_device_layer_ptr(ohmhip_map_t m, int layer_id, void **device_ptr,
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_read_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, size_t count, void *const *dsts)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || (count && (!keys_xyz || !dsts)))
@@ -1946,9 +1979,11 @@ int ohmhip_map_read_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xy
   (void)hipEventDestroy(done[1]);
   return status;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_write_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, size_t count,
                              const void *const *srcs)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || layer_id < 0 || layer_id >= OHMHIP_LID_COUNT || (count && (!keys_xyz || !srcs)))
@@ -2041,8 +2076,10 @@ int ohmhip_map_write_regions(ohmhip_map_t m, int layer_id, const int16_t *keys_x
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_ensure_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, uint32_t *slots)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || (count && !keys_xyz))
@@ -2096,8 +2133,10 @@ int ohmhip_map_ensure_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t co
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_remove_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed)
+try
 {
   if (removed)
   {
@@ -2212,8 +2251,10 @@ int ohmhip_map_remove_regions(ohmhip_map_t m, const int16_t *keys_xyz, size_t co
   m->spec_bucket_ok = false;  // per-slot sample ranges of the previous batch no longer describe these slots
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_mark_dirty(ohmhip_map_t m, const uint32_t *slots, size_t count)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m || (count && !slots))
@@ -2232,8 +2273,10 @@ int ohmhip_map_mark_dirty(ohmhip_map_t m, const uint32_t *slots, size_t count)
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_set_region_ownership(ohmhip_map_t m, uint32_t world_size, uint32_t rank, int block_shift)
+try
 {
   if (!m || (world_size > 1 && rank >= world_size) || block_shift < 0 || block_shift > 15)
   {
@@ -2249,8 +2292,10 @@ int ohmhip_map_set_region_ownership(ohmhip_map_t m, uint32_t world_size, uint32_
   m->mc.owner_shift = block_shift;
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_region_owner(const int16_t *keys_xyz, size_t count, int block_shift, uint32_t world_size, uint32_t *owners)
+try
 {
   if ((count && (!keys_xyz || !owners)) || block_shift < 0 || block_shift > 15)
   {
@@ -2264,9 +2309,11 @@ int ohmhip_region_owner(const int16_t *keys_xyz, size_t count, int block_shift, 
   }
   return OHMHIP_OK;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_line_keys(ohmhip_map_t m, const double *lines, size_t line_count, uint32_t max_keys_per_line,
                          void *keys_out, uint32_t *counts_out)
+try
 {
   if (!m || (line_count && (!lines || !keys_out || !counts_out)) || max_keys_per_line == 0)
   {
@@ -2312,8 +2359,10 @@ int ohmhip_map_line_keys(ohmhip_map_t m, const double *lines, size_t line_count,
   cleanup();
   return status;
 }
+OHMHIP_ABI_CATCH
 
 int ohmhip_map_clear(ohmhip_map_t m)
+try
 {
   OHMHIP_SETTLE(m);
   if (!m)
@@ -2326,5 +2375,6 @@ int ohmhip_map_clear(ohmhip_map_t m)
   m->slot_keys_host.clear();
   return allocPool(m, m->slot_capacity, 0);
 }
+OHMHIP_ABI_CATCH
 
 }  // extern "C"

@@ -183,6 +183,7 @@ extern "C" int ohmhip_transform_samples(const double *transform_times, const dou
                                         const double *sample_times, const double *local_samples, uint32_t point_count,
                                         double max_range, ohmhip_stream_t stream, ohmhip_buffer_t output,
                                         uint32_t *ray_elements)
+try
 {
   if (ray_elements)
   {
@@ -267,3 +268,4 @@ extern "C" int ohmhip_transform_samples(const double *transform_times, const dou
   cleanup();
   return status;
 }
+OHMHIP_ABI_CATCH
