@@ -250,7 +250,7 @@ int ohmhip_map_read_regions(ohmhip_map_t map, int layer_id, const int16_t *keys_
 /* GpuLayerCache::upload (ohmgpu/GpuLayerCache.cpp:172-182): make CPU-side voxel blocks resident (creates regions). */
 int ohmhip_map_write_regions(ohmhip_map_t map, int layer_id, const int16_t *keys_xyz, size_t count,
                              const void *const *srcs);
-/* GpuCache::clear / MapRegionCache::remove (ohmgpu/GpuCache.cpp, ohm/MapRegionCache.h): drop all regions. */
+/* GpuCache::clear (ohmgpu/GpuCache.cpp, ohm/MapRegionCache.h): drop all regions. */
 int ohmhip_map_clear(ohmhip_map_t map);
 /* MapRegionCache::remove as the core map calls it when it drops regions (OccupancyMap::cullRegions ->
  * gpu_cache->remove, ohm/OccupancyMap.cpp:1202-1234; GpuLayerCache::remove, ohmgpu/GpuLayerCache.cpp): the listed
