@@ -25,6 +25,61 @@ int main(int argc, char **argv)
   const std::string mode = argv[1];
   const double resolution = std::atof(argv[2]);
   const size_t batch_rays = size_t(std::atoll(argv[3]));
+  if (mode.compare(0, 7, "filter:") == 0)
+  {
+    // Host only (no device): run one of the stock ray filters of OhmGpuMap.h over the rays and write, per ray,
+    // accepted (1 byte), filter flags (1 byte), start and end (6 doubles).  Box (-1,-1,-1)..(2,2,2), length = resolution.
+    FILE *in = std::fopen(argv[4], "rb");
+    uint64_t n_points = 0;
+    if (!in || std::fread(&n_points, sizeof(n_points), 1, in) != 1)
+    {
+      return 4;
+    }
+    std::vector<ohm::dvec3> rays(n_points);
+    if (std::fread(rays.data(), sizeof(ohm::dvec3), n_points, in) != n_points)
+    {
+      return 4;
+    }
+    std::fclose(in);
+    const ohm::Aabb box(ohm::dvec3{ -1.0, -1.0, -1.0 }, ohm::dvec3{ 2.0, 2.0, 2.0 });
+    FILE *out = std::fopen(argv[5], "wb");
+    if (!out)
+    {
+      return 4;
+    }
+    for (uint64_t i = 0; i + 1 < n_points; i += 2)
+    {
+      ohm::dvec3 start = rays[i], end = rays[i + 1];
+      unsigned flags = 0;
+      bool ok = false;
+      if (mode == "filter:clipbounded")
+      {
+        ok = ohm::clipBounded(&start, &end, &flags, box);
+      }
+      else if (mode == "filter:cliptobounds")
+      {
+        ok = ohm::clipToBounds(&start, &end, &flags, box);
+      }
+      else if (mode == "filter:clipray")
+      {
+        ok = ohm::clipRayFilter(&start, &end, &flags, resolution);
+      }
+      else if (mode == "filter:goodray")
+      {
+        ok = ohm::goodRayFilter(&start, &end, &flags, resolution);
+      }
+      else
+      {
+        return 2;
+      }
+      const unsigned char head[2] = { static_cast<unsigned char>(ok), static_cast<unsigned char>(flags) };
+      std::fwrite(head, 1, 2, out);
+      std::fwrite(&start, sizeof(start), 1, out);
+      std::fwrite(&end, sizeof(end), 1, out);
+    }
+    std::fclose(out);
+    return 0;
+  }
   try
   {
     if (ohm::configureGpu(0) != 0)

@@ -70,3 +70,40 @@ def test_oracle_clipbox_expectations():
     om2.integrate_occupancy(rays, filter_flags=flags)
     occupied = sum(int(np.count_nonzero(np.isfinite(l["occupancy"]) & (l["occupancy"] > 0))) for l in om2.chunks().values())
     assert occupied == 1
+
+
+def test_cpp_mirror_filters_agree_with_the_numpy_restatement(tmp_path):
+    """The two host mirrors restate ohm/RayFilter.cpp + ohm::Aabb::clipLine independently (C++ per ray, numpy per
+    batch): same decisions, same flags, same clipped points bit for bit.  Runs the driver's host-only filter mode."""
+    import os
+    import struct
+    import subprocess
+
+    import ohm_amd
+    from ohm_amd import synth
+    driver = os.path.join(os.path.dirname(ohm_amd.LIB_PATH), "gpumap_driver")
+    assert os.path.exists(driver), "gpumap_driver missing: run __graft_entry__.build()"
+    rays = synth.random_rays(4000, extent=4.0, seed=91, origin_spread=3.0)
+    rays[10] = np.nan
+    rays[21] = np.inf
+    rays[30:32] = [[0.5, 0.5, 0.5], [0.5, 0.5, 0.5]]      # degenerate
+    rays[40:42] = [[-3.0, 0.0, 0.0], [4.0, 0.0, 0.0]]     # axis aligned (infinite slab times on two axes)
+    rp, op = tmp_path / "rays.bin", tmp_path / "out.bin"
+    with open(rp, "wb") as f:
+        f.write(struct.pack("<Q", rays.shape[0]))
+        f.write(np.ascontiguousarray(rays).tobytes())
+    box = RF.Aabb((-1.0, -1.0, -1.0), (2.0, 2.0, 2.0))
+    cases = {"filter:clipbounded": (RF.clip_bounded(box), 0.0), "filter:cliptobounds": (RF.clip_to_bounds(box), 0.0),
+             "filter:clipray": (RF.clip_ray_filter(2.5), 2.5), "filter:goodray": (RF.good_ray_filter(3.0), 3.0)}
+    rec = np.dtype([("ok", np.uint8), ("flags", np.uint8), ("start", np.float64, 3), ("end", np.float64, 3)])
+    for mode, (filt, param) in cases.items():
+        res = subprocess.run([driver, mode, repr(param), "0", str(rp), str(op)], capture_output=True, text=True)
+        assert res.returncode == 0, (mode, res.stderr)
+        got = np.frombuffer(open(op, "rb").read(), dtype=rec)
+        keep, starts, ends, flags = filt(rays[0::2].copy(), rays[1::2].copy())
+        assert np.array_equal(got["ok"].astype(bool), keep), mode
+        k = keep
+        # the per-ray form sets kRffInvalid on rejected rays; compare the flags of the accepted ones
+        assert np.array_equal(got["flags"][k], flags[k]), mode
+        assert np.array_equal(got["start"][k].view(np.uint64), np.asarray(starts)[k].view(np.uint64)), mode
+        assert np.array_equal(got["end"][k].view(np.uint64), np.asarray(ends)[k].view(np.uint64)), mode
