@@ -321,19 +321,29 @@ __device__ inline uint32_t ltabFind(const LdsRegionTable &tab, uint64_t key, uin
   return kLtabSize;
 }
 
-/// Walk the regions a ray crosses and call f(region key, s0, s1, s2) for every ray-region segment which produces at
-/// least one voxel visit.  With `with_resume_state` the three words are the packed Segment fields (see Segment): the
-/// per-axis step counts at the moment the region is entered, the first / end flags and the number of voxels visited in
-/// the region; otherwise they are zero (the counting passes only need the keys).  Segments in regions another replica
-/// owns (MapConst::owner_world > 1) are skipped: every segment carries its own resume state, so dropping some of a
-/// ray's segments does not change what the others do.
+/// Where a ray enters a region and how much of it lies inside (forEachSegment with resume state).
+struct SegmentEntry
+{
+  uint32_t k0 = 0, k1 = 0, k2 = 0;  ///< steps taken per axis at the moment the region is entered
+  uint32_t count = 0;               ///< voxels the ray visits inside the region
+  double t_base = 0;                ///< time of the step that enters the region (0 for the ray's first segment)
+  bool first = false;               ///< the segment starts at the ray's origin voxel
+  bool end = false;                 ///< the segment's last voxel is the ray's end voxel (visited as part of the ray)
+};
+
+/// Walk the regions a ray crosses and call emit(region key, entry) for every ray-region segment which produces at
+/// least one voxel visit.  With `with_resume_state` the entry is filled in: the per-axis step counts at the moment the
+/// region is entered, the time of the entering step, the first / end flags and the number of voxels visited in the
+/// region; otherwise it is empty (the counting passes only need the keys).  Segments in regions another replica owns
+/// (MapConst::owner_world > 1) are skipped: every segment carries its own resume state, so dropping some of a ray's
+/// segments does not change what the others do.
 template <typename F>
 __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, bool with_resume_state, F emit)
 {
-  auto f = [&](uint64_t key, uint32_t w0, uint32_t w1, uint32_t w2) {
+  auto f = [&](uint64_t key, const SegmentEntry &entry) {
     if (ownsRegion(mc, key))
     {
-      emit(key, w0, w1, w2);
+      emit(key, entry);
     }
   };
   if (!(rw.flags & kRwValid) || !(rw.flags & kRwWalk))
@@ -347,16 +357,16 @@ __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, boo
   // A segment's voxel count is known once the NEXT region entry is: emission trails the enumeration by one.
   bool have = false;
   uint64_t p_key = 0;
-  uint32_t p0 = 0, p1 = 0, p2 = 0;
+  SegmentEntry p;
   int p_sum = 0;
   if (manhattan > 0 || include_end)
   {
     p_key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
-    p0 = kSegFirst;
+    p.first = true;
     have = true;
     if (!with_resume_state)
     {
-      f(p_key, 0u, 0u, 0u);
+      f(p_key, p);
     }
   }
   // Reciprocals of the step deltas for the step-count estimates (one division per axis per ray, not per crossing).
@@ -378,7 +388,7 @@ __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, boo
     const uint64_t key = packRegionKey(rc.region[0], rc.region[1], rc.region[2]);
     if (!with_resume_state)
     {
-      f(key, 0u, 0u, 0u);
+      f(key, p);
       continue;
     }
     const double ta = stepTime(sel3(axis, rw.init[0], rw.init[1], rw.init[2]),
@@ -389,21 +399,114 @@ __device__ inline void forEachSegment(const MapConst &mc, const RayWalk &rw, boo
     const int sum = int(rs0 + rs1 + rs2);
     if (have)
     {
-      const uint32_t count = uint32_t(sum - p_sum);
-      f(p_key, p0, p1 | (count << 24), p2 | ((count >> 8) << 24));
+      p.count = uint32_t(sum - p_sum);
+      f(p_key, p);
     }
     p_key = key;
-    p0 = rs0;
-    p1 = rs1;
-    p2 = rs2;
+    p.k0 = rs0;
+    p.k1 = rs1;
+    p.k2 = rs2;
+    p.t_base = ta;
+    p.first = false;
     p_sum = sum;
     have = true;
   }
   if (have && with_resume_state)
   {
-    const uint32_t count = uint32_t(manhattan - p_sum) + (include_end ? 1u : 0u);
-    f(p_key, p0 | (include_end ? kSegEnd : 0u), p1 | (count << 24), p2 | ((count >> 8) << 24));
+    p.count = uint32_t(manhattan - p_sum) + (include_end ? 1u : 0u);
+    p.end = include_end;
+    f(p_key, p);
   }
+}
+
+/// Per-ray part of the fixed-point walk predictor (see Segment): the step deltas in fixed point, with the step direction
+/// in the top bit, and whether the ray has to be walked exactly throughout.
+struct RayFix
+{
+  uint32_t e0, e1, e2;
+  bool poison;
+};
+
+__device__ inline RayFix rayFix(const MapConst &mc, const RayWalk &rw)
+{
+  RayFix rf;
+  rf.poison = false;
+  double t_last = 0;       // time of the ray's last real step
+  double t_phantom = dInf();  // earliest step the predictor would take beyond an axis' last real one
+  uint32_t e[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+  {
+    e[a] = 0;
+    if (rw.total[a] > 0)
+    {
+      const double ex = rw.delta[a] * mc.fix_scale;
+      // (negated comparisons: NaN fails them and poisons the ray)
+      rf.poison = rf.poison || !(ex >= 1.0);
+      e[a] = !(ex >= 1.0) ? 0u : ((ex >= double(kFixMaxDelta)) ? kFixMaxDelta : uint32_t(ex));
+      const double tl = stepTime(rw.init[a], rw.delta[a], rw.total[a]);
+      const double tp = rw.init[a] + rw.delta[a] * double(rw.total[a]);
+      rf.poison = rf.poison || !(tl >= 0.0) || !(tp >= tl);
+      t_last = (tl > t_last) ? tl : t_last;
+      t_phantom = (tp < t_phantom) ? tp : t_phantom;
+    }
+    e[a] |= rwSign(rw, a) ? kSegNegative : 0u;
+  }
+  // An axis which has taken its last step keeps stepping in the predictor.  That is harmless when every such phantom
+  // step lies at or beyond the last real step of the ray (it then never leads a step the walk still needs by the trust
+  // margin); where the end point's key and the geometry disagree (end points within the 1e-6 quantisation slack of a
+  // region face) that can fail, and the ray is walked exactly.
+  rf.poison = rf.poison || !(t_phantom >= t_last);
+  rf.e0 = e[0];
+  rf.e1 = e[1];
+  rf.e2 = e[2];
+  return rf;
+}
+
+/// Fixed-point time of the next step along one axis at a region entry (see Segment).  Returns false when the value
+/// cannot be represented safely (negative or non-finite): the segment is then poisoned.
+__device__ inline bool fixTime(const MapConst &mc, double init, double delta, int total, uint32_t k, double t_base,
+                               uint32_t &f)
+{
+  if (int(k) >= total)
+  {
+    f = kFixFar;  // no steps left on this axis: time_next = inf (ohm/LineWalkCompute.h:299-301)
+    return true;
+  }
+  const double t = (k == 0) ? init : init + delta * double(k);
+  const double x = (t - t_base) * mc.fix_scale;
+  const bool ok = x >= 0.0;  // (false for NaN)
+  f = !ok ? 0u : ((x >= double(kFixFar)) ? kFixFar : uint32_t(x));
+  return ok;
+}
+
+/// Build the walk kernel's record of one ray-region segment.
+__device__ inline Segment makeSegment(const MapConst &mc, const RayWalk &rw, const RayFix &rf, uint32_t ray,
+                                      const SegmentEntry &en)
+{
+  Segment sg;
+  bool ok = !rf.poison;
+  ok = fixTime(mc, rw.init[0], rw.delta[0], rw.total[0], en.k0, en.t_base, sg.f[0]) && ok;
+  ok = fixTime(mc, rw.init[1], rw.delta[1], rw.total[1], en.k1, en.t_base, sg.f[1]) && ok;
+  ok = fixTime(mc, rw.init[2], rw.delta[2], rw.total[2], en.k2, en.t_base, sg.f[2]) && ok;
+  // An axis without steps left never moves: its delta is irrelevant, zero keeps the candidate at kFixFar.
+  sg.e[0] = (int(en.k0) < rw.total[0]) ? rf.e0 : (rf.e0 & kSegNegative);
+  sg.e[1] = (int(en.k1) < rw.total[1]) ? rf.e1 : (rf.e1 & kSegNegative);
+  sg.e[2] = (int(en.k2) < rw.total[2]) ? rf.e2 : (rf.e2 & kSegNegative);
+  if (!ok)
+  {
+    sg.f[0] = sg.f[1] = sg.f[2] = 0;
+    sg.e[0] &= kSegNegative;
+    sg.e[1] &= kSegNegative;
+    sg.e[2] &= kSegNegative;
+  }
+  const int l0 = localCoord(rw.g0[0] + rwDir(rw, 0) * int(en.k0), mc.dim[0]);
+  const int l1 = localCoord(rw.g0[1] + rwDir(rw, 1) * int(en.k1), mc.dim[1]);
+  const int l2 = localCoord(rw.g0[2] + rwDir(rw, 2) * int(en.k2), mc.dim[2]);
+  const uint32_t vi = uint32_t(l0 + l1 * mc.dim[0] + l2 * mc.dim[0] * mc.dim[1]);
+  sg.vox = vi | (en.count << kSegVoxelBits);
+  sg.ray = ray | ((en.first && (rw.flags & kRwExcludeStart)) ? kSegSkipFirst : 0u) | (en.end ? kSegEnd : 0u);
+  return sg;
 }
 
 /// Region / voxel of the ray's sample (end) voxel.
@@ -566,7 +669,7 @@ __global__ void __launch_bounds__(kBinThreads)
     }
     my_visits += (rw.flags & kRwApplySample) ? 1u : 0u;
 
-    forEachSegment(mc, rw, false, [&](uint64_t key, uint32_t, uint32_t, uint32_t) {
+    forEachSegment(mc, rw, false, [&](uint64_t key, const SegmentEntry &) {
       const uint32_t e = ltabFindOrInsert(tab, key, tab_mask);
       if (e < kLtabSize)
       {
@@ -1010,7 +1113,8 @@ __global__ void __launch_bounds__(kBinThreads)
   {
     const uint32_t ray = first + order.perm[idx];
     const RayWalk rw = walks[ray];
-    forEachSegment(mc, rw, true, [&](uint64_t key, uint32_t rs0, uint32_t rs1, uint32_t rs2) {
+    const RayFix rf = rayFix(mc, rw);
+    forEachSegment(mc, rw, true, [&](uint64_t key, const SegmentEntry &entry) {
       const uint32_t e = ltabFind(tab, key, tab_mask);
       uint32_t pos;
       if (e < kLtabSize)
@@ -1024,12 +1128,7 @@ __global__ void __launch_bounds__(kBinThreads)
       }
       if (pos < segment_capacity)
       {
-        Segment sg;
-        sg.ray = ray;
-        sg.s0 = rs0;
-        sg.s1 = rs1;
-        sg.s2 = rs2;
-        segments[pos] = sg;
+        segments[pos] = makeSegment(mc, rw, rf, ray, entry);
       }
     });
   }
@@ -1467,6 +1566,115 @@ __device__ inline int addMask(int value, unsigned long long mask)
   return value;
 }
 
+constexpr int kIcmpEq = 32;   ///< llvm::CmpInst::ICMP_EQ
+constexpr int kIcmpUlt = 36;  ///< llvm::CmpInst::ICMP_ULT
+
+/// mask ? if_set : 0
+__device__ inline uint32_t selectOrZero(unsigned long long mask, uint32_t if_set)
+{
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask));
+  return r;
+}
+
+__device__ inline uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t r;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+/// a + b, saturating at 2^32 - 1 (the predictor's candidates never wrap into small values).
+__device__ inline uint32_t addSat(uint32_t a, uint32_t b)
+{
+  uint32_t r;
+  asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+/// The same with a wave-uniform second operand (kept in an SGPR).
+__device__ inline uint32_t addSatUniform(uint32_t a, uint32_t b)
+{
+  uint32_t r;
+  asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+
+/// Returning LDS add on the count tile.  Issued as inline assembly so that (a) the tile's address needs no base add (it
+/// sits at LDS offset 0: the kernel has no static LDS, checked by the parity tests on every run) and (b) the wait for
+/// the returned value is placed by hand, after the walk step (waitTile).
+__device__ inline uint32_t tileAdd(uint32_t byte_address, uint32_t value)
+{
+  uint32_t old;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(old) : "v"(byte_address), "v"(value) : "memory");
+  return old;
+}
+
+/// 1 << (shift & 31): the hardware shift only reads the low five bits of its shift operand.
+__device__ inline uint32_t shiftOne(uint32_t shift)
+{
+  uint32_t r;
+  asm("v_lshlrev_b32_e64 %0, %1, 1" : "=v"(r) : "v"(shift));
+  return r;
+}
+
+__device__ inline uint32_t waitTile(uint32_t old)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(old) : : "memory");
+  return old;
+}
+
+/// Local voxel coordinates of voxel index `vi` of a region.
+__device__ inline void voxelLocal(const MapConst &mc, uint32_t vi, int &lx, int &ly, int &lz)
+{
+  const uint32_t dx = uint32_t(mc.dim[0]);
+  const uint32_t dxy = dx * uint32_t(mc.dim[1]);
+  lz = int(vi / dxy);
+  const uint32_t r = vi - uint32_t(lz) * dxy;
+  ly = int(r / dx);
+  lx = int(r - uint32_t(ly) * dx);
+}
+
+/// Steps a ray has taken along each axis when it stands in voxel `vi` of region (rx, ry, rz): the walk moves
+/// monotonically away from the start voxel on every axis.
+__device__ inline void stepsAtVoxel(const MapConst &mc, const RayWalk &rw, int rx, int ry, int rz, uint32_t vi, int &k0,
+                                    int &k1, int &k2)
+{
+  int lx, ly, lz;
+  voxelLocal(mc, vi, lx, ly, lz);
+  k0 = abs(rx * mc.dim[0] + lx - rw.g0[0]);
+  k1 = abs(ry * mc.dim[1] + ly - rw.g0[1]);
+  k2 = abs(rz * mc.dim[2] + lz - rw.g0[2]);
+}
+
+/// time_next of one axis after k steps along it (ohm/LineWalkCompute.h:299-301, :375-378).
+__device__ inline double timeNext(double init, double delta, int k, int total)
+{
+  return (k < total) ? ((k == 0) ? init : init + delta * double(k)) : dInf();
+}
+
+/// The exact decision of the reference walk for a ray standing in voxel `vi` of region (rx, ry, rz): the axis of the
+/// next step.  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): smallest time_next, ties go to the higher axis.
+__device__ inline int exactNextAxis(const MapConst &mc, const RayWalk &rw, int rx, int ry, int rz, uint32_t vi)
+{
+  int k0, k1, k2;
+  stepsAtVoxel(mc, rw, rx, ry, rz, vi, k0, k1, k2);
+  const double t0 = timeNext(rw.init[0], rw.delta[0], k0, rw.total[0]);
+  const double t1 = timeNext(rw.init[1], rw.delta[1], k1, rw.total[1]);
+  const double t2 = timeNext(rw.init[2], rw.delta[2], k2, rw.total[2]);
+  const bool m01 = t0 < t1;
+  const double t01 = m01 ? t0 : t1;
+  const bool m2 = t01 < t2;
+  return m2 ? (m01 ? 0 : 1) : 2;
+}
+
 /// Kernel parameters of k_region_walk (one struct keeps the template instantiations readable).
 struct WalkArgs
 {
@@ -1475,6 +1683,7 @@ struct WalkArgs
   const Chunk *chunks;
   const Segment *segments;
   const RayWalk *walks;
+  const uint64_t *slot_keys;  ///< region key per slot (exact decisions need the region's coordinates)
   const unsigned long long *sorted_hits;
   const uint32_t *hit_mask;
   uint32_t *miss_counts;
@@ -1495,12 +1704,17 @@ struct WalkArgs
   uint32_t n_chunks;
 };
 
+constexpr uint32_t kWalkCursorWords = 12;  ///< l_cursor[]: see k_region_walk
+
 /// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
 /// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every iteration
 /// of an active lane is a miss.
 /// kTraversal: also accumulate the ray length inside every visited voxel (traversal layer, ohm/RayMapperOccupancy.cpp:
-/// 166-173).  Float adds in arbitrary order: that layer matches the CPU to summation-order rounding, not bit for bit.
-template <bool kSpecial, bool kTraversal>
+/// 166-173).  That needs the exact fp64 time of every step, so these instantiations run the reference's fp64 step for
+/// every lane instead of the fixed-point predictor.
+/// kTrace: development instrumentation (OHMHIP_DEBUG_FLAGS 64 / 128): per-chunk time stamps and loop counters.  Compiled
+/// out of the production instantiations.
+template <bool kSpecial, bool kTraversal, bool kTrace>
 __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1514,8 +1728,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   uint2 *l_queues = reinterpret_cast<uint2 *>(lds + ((count_words + 3u) & ~3u));
   unsigned long long *l_hits = reinterpret_cast<unsigned long long *>(l_queues + kWalkWaves * kQueueCap);
   uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] u16 interval counters
+  // l_cursor[0]: segment cursor, [1]: next chunk index, [2..5]: its record, [6..7]: its samples, [8..9]: its region key
   uint32_t *l_cursor = l_intervals + kLdsHits / 2;
-  uint32_t *l_hist = l_cursor + 8;  // l_cursor[0]: segment cursor, [1]: next chunk index, [2..5]: its record, [6..7]: its hits
+  uint32_t *l_hist = l_cursor + kWalkCursorWords;
   uint16_t *l_order = reinterpret_cast<uint16_t *>(l_hist + kLengthClasses);
 
   // Persistent workgroups: the launch has one workgroup per CU and each takes chunks from a device-wide cursor until
@@ -1537,6 +1752,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       l_cursor[5] = c.hash_index;
       l_cursor[6] = defer_all ? 0u : args.bs.hit_begin[c.slot];
       l_cursor[7] = defer_all ? 0u : args.bs.hit_end[c.slot];
+      const uint64_t key = args.slot_keys[c.slot];
+      l_cursor[8] = uint32_t(key);
+      l_cursor[9] = uint32_t(key >> 32);
     }
   };
   if (threadIdx.x == 0)
@@ -1549,7 +1767,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   uint32_t chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
   while (chunk_index < args.n_chunks)
   {
-    const unsigned long long clk_start = args.dbg_counters ? wall_clock64() : 0ull;
+    unsigned long long clk_start = 0;
+    if (kTrace)
+    {
+      clk_start = wall_clock64();
+    }
     Chunk chunk;
     chunk.slot = __builtin_amdgcn_readfirstlane(l_cursor[2]);
     chunk.seg_begin = __builtin_amdgcn_readfirstlane(l_cursor[3]);
@@ -1557,6 +1779,12 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     chunk.hash_index = __builtin_amdgcn_readfirstlane(l_cursor[5]);
     const uint32_t hb = __builtin_amdgcn_readfirstlane(l_cursor[6]);
     const uint32_t he = __builtin_amdgcn_readfirstlane(l_cursor[7]);
+    const uint32_t key_lo = __builtin_amdgcn_readfirstlane(l_cursor[8]);
+    const uint32_t key_hi = __builtin_amdgcn_readfirstlane(l_cursor[9]);
+    // Region coordinates (packRegionKey): only the exact decisions use them.
+    const int region_x = int(int16_t(key_lo & 0xffffu));
+    const int region_y = int(int16_t(key_lo >> 16));
+    const int region_z = int(int16_t(key_hi & 0xffffu));
     const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
     const Segment *chunk_segments = args.segments + chunk.seg_begin;
 
@@ -1586,8 +1814,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     for (int j = 0; j < kSegPerThread; ++j)
     {
       const uint32_t i = min(threadIdx.x + uint32_t(j) * kWalkThreads, n_seg - 1u);
-      const uint2 w = *reinterpret_cast<const uint2 *>(&chunk_segments[i].s1);
-      lens[j] = min((w.x >> 24) | ((w.y >> 24) << 8), kLengthClasses - 1u);
+      lens[j] = min(chunk_segments[i].vox >> kSegVoxelBits, kLengthClasses - 1u);
     }
     if (threadIdx.x < kLengthClasses)
     {
@@ -1597,7 +1824,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     {
       l_cursor[0] = 0;
     }
-    const bool stamp = args.dbg_counters && threadIdx.x == 0;
+    const bool stamp = kTrace && threadIdx.x == 0;
     unsigned long long clk_p[6] = { 0, 0, 0, 0, 0, 0 };
     if (stamp)
     {
@@ -1724,24 +1951,32 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
     const int ray_shift = args.ray_shift;
     const int refill_min_idle = args.refill_min_idle;
-    const bool refill_only = (args.dbg & 16u) != 0;
+    const bool refill_only = kTrace && (args.dbg & 16u) != 0;
+    const uint32_t fix_margin = mc.fix_margin;
 
     // Per-lane walk state (all named scalars: no run-time indexed arrays).
     int left = 0;  // voxels this lane still has to visit in its segment (<= 0: idle)
-    double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
-    double t0 = 0, t1 = 0, t2 = 0;                          // time_next per axis
-    int k0 = 0, k1 = 0, k2 = 0, tot0 = 0, tot1 = 0, tot2 = 0;  // steps taken / steps in the whole ray per axis
-    int sx = 0, sy = 0, sz = 0;
-    uint32_t vi = 0;
+    uint32_t f0 = 0, f1 = 0, f2 = 0, d0 = 0, d1 = 0, d2 = 0;  // predictor: next step time / step delta per axis
+    int sx = 0, sy = 0, sz = 0;  // change of `va` per step along each axis
+    uint32_t va = 0;             // byte offset of the current voxel's u16 tile entry (2 x voxel index)
     uint32_t ray = 0;
     uint32_t skip = 0;      // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
     uint32_t end_last = 0;  // kSpecial only: the segment's last voxel is the ray's end voxel
-    double t_enter = 0;     // kTraversal: range at which the current voxel was entered
-    double ray_len = 0;     // kTraversal && kSpecial: exit range of the end voxel
+    // kTraversal only: the reference's fp64 walk state.
+    double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
+    double t0 = 0, t1 = 0, t2 = 0;                          // time_next per axis
+    int k0 = 0, k1 = 0, k2 = 0, tot0 = 0, tot1 = 0, tot2 = 0;  // steps taken / steps in the whole ray per axis
+    double t_enter = 0;     // range at which the current voxel was entered
+    double ray_len = 0;     // kSpecial: exit range of the end voxel
+    uint32_t old = 0;        // tile word returned by the visit's LDS add
     uint32_t qcount = 0;     // wave-uniform
     bool exhausted = false;  // wave-uniform
-    uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0;  // wave-uniform
-    const unsigned long long clk_loop = args.dbg_counters ? wall_clock64() : 0ull;
+    uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0, dbg_slow = 0;  // wave-uniform (kTrace)
+    unsigned long long clk_loop = 0;
+    if (kTrace)
+    {
+      clk_loop = wall_clock64();
+    }
 
     while (true)
     {
@@ -1750,7 +1985,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       const int n_idle = 64 - __popcll(am);
       if (!exhausted && (n_idle >= refill_min_idle))
       {
-        ++dbg_refills;
+        if (kTrace)
+        {
+          ++dbg_refills;
+        }
         uint32_t base = 0;
         if (lane == 0)
         {
@@ -1763,55 +2001,50 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           base + __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
         if (left <= 0 && mine < n_seg)
         {
-          const Segment seg = chunk_segments[l_order[mine]];
-          const RayWalk rw = args.walks[seg.ray];
-          const int s0 = int(seg.s0 & kSegStepMask);
-          const int s1 = int(seg.s1 & kSegStepMask);
-          const int s2 = int(seg.s2 & kSegStepMask);
-          i0 = rw.init[0];
-          i1 = rw.init[1];
-          i2 = rw.init[2];
-          e0 = rw.delta[0];
-          e1 = rw.delta[1];
-          e2 = rw.delta[2];
-          const int d0 = rwDir(rw, 0);
-          const int d1 = rwDir(rw, 1);
-          const int d2 = rwDir(rw, 2);
-          const int l0 = localCoord(rw.g0[0] + d0 * s0, mc.dim[0]);
-          const int l1 = localCoord(rw.g0[1] + d1 * s1, mc.dim[1]);
-          const int l2 = localCoord(rw.g0[2] + d2 * s2, mc.dim[2]);
-          k0 = s0;
-          k1 = s1;
-          k2 = s2;
-          tot0 = rw.total[0];
-          tot1 = rw.total[1];
-          tot2 = rw.total[2];
-          // time_next per axis (ohm/LineWalkCompute.h:299-301, :375-378)
-          t0 = (s0 < tot0) ? ((s0 == 0) ? i0 : i0 + e0 * double(s0)) : inf;
-          t1 = (s1 < tot1) ? ((s1 == 0) ? i1 : i1 + e1 * double(s1)) : inf;
-          t2 = (s2 < tot2) ? ((s2 == 0) ? i2 : i2 + e2 * double(s2)) : inf;
-          sx = d0;
-          sy = d1 * dimx;
-          sz = d2 * dimxy;
-          vi = uint32_t(l0 + l1 * dimx + l2 * dimxy);
-          ray = seg.ray;
-          left = int((seg.s1 >> 24) | ((seg.s2 >> 24) << 8));
+          const uint4 *rec = reinterpret_cast<const uint4 *>(chunk_segments + l_order[mine]);
+          const uint4 ra = rec[0];
+          const uint4 rb = rec[1];
+          f0 = ra.x;
+          f1 = ra.y;
+          f2 = ra.z;
+          va = (ra.w & ((1u << kSegVoxelBits) - 1u)) << 1;
+          left = int(ra.w >> kSegVoxelBits);
+          d0 = rb.x & ~kSegNegative;
+          d1 = rb.y & ~kSegNegative;
+          d2 = rb.z & ~kSegNegative;
+          sx = (rb.x & kSegNegative) ? -2 : 2;
+          sy = (rb.y & kSegNegative) ? -2 * dimx : 2 * dimx;
+          sz = (rb.z & kSegNegative) ? -2 * dimxy : 2 * dimxy;
+          ray = rb.w & kSegRayMask;
+          if (kSpecial)
+          {
+            skip = (rb.w & kSegSkipFirst) ? 1u : 0u;
+            end_last = (rb.w & kSegEnd) ? 1u : 0u;
+          }
           if (kTraversal)
           {
+            const RayWalk rw = args.walks[ray];
+            stepsAtVoxel(mc, rw, region_x, region_y, region_z, va >> 1, k0, k1, k2);
+            i0 = rw.init[0];
+            i1 = rw.init[1];
+            i2 = rw.init[2];
+            e0 = rw.delta[0];
+            e1 = rw.delta[1];
+            e2 = rw.delta[2];
+            tot0 = rw.total[0];
+            tot1 = rw.total[1];
+            tot2 = rw.total[2];
+            t0 = timeNext(i0, e0, k0, tot0);
+            t1 = timeNext(i1, e1, k1, tot1);
+            t2 = timeNext(i2, e2, k2, tot2);
             // The step which entered this region is the latest step taken so far.
-            double te = 0;
-            te = (s0 > 0) ? stepTime(i0, e0, s0) : te;
-            const double te1 = (s1 > 0) ? stepTime(i1, e1, s1) : 0.0;
-            const double te2 = (s2 > 0) ? stepTime(i2, e2, s2) : 0.0;
+            double te = (k0 > 0) ? stepTime(i0, e0, k0) : 0.0;
+            const double te1 = (k1 > 0) ? stepTime(i1, e1, k1) : 0.0;
+            const double te2 = (k2 > 0) ? stepTime(i2, e2, k2) : 0.0;
             te = (te1 > te) ? te1 : te;
             te = (te2 > te) ? te2 : te;
             t_enter = te;
             ray_len = rw.length;
-          }
-          if (kSpecial)
-          {
-            skip = ((seg.s0 & kSegFirst) && (rw.flags & kRwExcludeStart)) ? 1u : 0u;
-            end_last = (seg.s0 & kSegEnd) ? 1u : 0u;
           }
           left = refill_only ? 0 : left;
         }
@@ -1824,52 +2057,49 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 
       // ---- visit: count the miss and fetch the voxel's mask flag with one returning LDS atomic.  Masked voxels (which
       // ---- also receive samples) are counted too; the ordering pass moves such a miss to an interval counter when a
-      // ---- later sample of the voxel exists.
-      const bool active = left > 0;
+      // ---- later sample of the voxel exists.  `va` is the byte offset of the voxel's u16 tile entry (2 x voxel index):
+      // ---- word address = va & ~3, and both shifts below only use the low five bits of their shift operand, so
+      // ---- (va << 3) selects bit 0 or 16 of the word for the count and (.. | 15) bit 15 or 31 for the flag.
       // kSpecial: the ray's end voxel (last voxel of a kSegEnd segment) is always visited; kRfExcludeOrigin drops the
       // first voxel of the ray otherwise.
       const bool at_end = kSpecial && end_last && left == 1;
-      const bool visit = kSpecial ? (active && (at_end || !skip)) : active;
-      const uint32_t vi_visit = vi;
-      const uint32_t sh = (vi_visit & 1u) << 4;
-      uint32_t old = 0;
+      const bool visit = kSpecial ? (left > 0 && (at_end || !skip)) : (left > 0);
+      const uint32_t sh = va << 3;
+      const unsigned long long vm = __ballot(visit);
       if (visit)
       {
-        old = atomicAdd(&l_counts[vi_visit >> 1], 1u << sh);
+        old = tileAdd(va & ~3u, shiftOne(sh));
       }
-      double t_exit = 0;
+      if (kSpecial)
+      {
+        skip = 0;
+      }
+      if (kTrace)
+      {
+        ++dbg_iters;
+        dbg_active += uint32_t(__popcll(am));
+      }
+
+      int stride;
       if (kTraversal)
       {
+        const bool active = left > 0;
         // exit range of this voxel == time of the next step (the ray's length at its end voxel)
         const double tm01 = (t0 < t1) ? t0 : t1;
-        t_exit = (tm01 < t2) ? tm01 : t2;
+        double t_exit = (tm01 < t2) ? tm01 : t2;
         if (kSpecial)
         {
           t_exit = at_end ? ray_len : t_exit;
         }
         if (visit)
         {
-          atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + vi_visit], float(t_exit - t_enter));
-          t_enter = t_exit;
+          atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + (va >> 1)],
+                    float(t_exit - t_enter));
         }
-        else if (active)
-        {
-          t_enter = t_exit;
-        }
-      }
-      if (kSpecial)
-      {
-        skip = 0;
-      }
-      ++dbg_iters;
-
-      // ---- one branch-free walk step, taken by every lane (an idle lane's state is dead, and the step after a
-      // ---- segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties go to the
-      // ---- higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
-      {
-        // Lane masks and selects are spelled out (compare builtins + v_cndmask / v_addc on the 64-bit masks): left to
-        // itself the compiler evaluates each fp64 compare twice (a < b and !(a < b) are different predicates under
-        // NaN rules) and turns every `k += predicate` into a select plus an add.
+        t_enter = active ? t_exit : t_enter;
+        // ---- the reference's fp64 step, branch free, taken by every lane (an idle lane's state is dead, and the step
+        // ---- after a segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties
+        // ---- go to the higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
         const unsigned long long m01 = __builtin_amdgcn_fcmp(t0, t1, kFcmpOlt);
         const double t01 = selectD(m01, t0, t1);
         const unsigned long long m2 = __builtin_amdgcn_fcmp(t01, t2, kFcmpOlt);
@@ -1879,31 +2109,64 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         k0 = addMask(k0, a0);
         k1 = addMask(k1, a1);
         k2 = addMask(k2, a2);
-        const unsigned long long f0 = __builtin_amdgcn_sicmp(k0, tot0, kIcmpSlt);
-        const unsigned long long f1 = __builtin_amdgcn_sicmp(k1, tot1, kIcmpSlt);
-        const unsigned long long f2 = __builtin_amdgcn_sicmp(k2, tot2, kIcmpSlt);
-        const double n0 = selectD(f0, i0 + e0 * double(k0), inf);
-        const double n1 = selectD(f1, i1 + e1 * double(k1), inf);
-        const double n2 = selectD(f2, i2 + e2 * double(k2), inf);
+        const unsigned long long g0 = __builtin_amdgcn_sicmp(k0, tot0, kIcmpSlt);
+        const unsigned long long g1 = __builtin_amdgcn_sicmp(k1, tot1, kIcmpSlt);
+        const unsigned long long g2 = __builtin_amdgcn_sicmp(k2, tot2, kIcmpSlt);
+        const double n0 = selectD(g0, i0 + e0 * double(k0), inf);
+        const double n1 = selectD(g1, i1 + e1 * double(k1), inf);
+        const double n2 = selectD(g2, i2 + e2 * double(k2), inf);
         t0 = selectD(a0, n0, t0);
         t1 = selectD(a1, n1, t1);
         t2 = selectD(a2, n2, t2);
-        const int stride = selectI(a2, sz, selectI(a0, sx, sy));
-        vi += uint32_t(stride);
-        left -= 1;
+        stride = selectI(a2, sz, selectI(a0, sx, sy));
       }
+      else
+      {
+        // ---- one walk step from the fixed-point predictor (see Segment), taken by every lane.  The smallest candidate
+        // ---- is trusted when it lies inside the region's range (below kFixMaxDelta) and leads the second smallest by
+        // ---- more than the accumulated truncation error; an active lane that cannot trust it asks the reference's
+        // ---- fp64 arithmetic (rare: near-ties, ray ends that disagree with their keys, degenerate rays).
+        const uint32_t fmin = umin3(f0, f1, f2);
+        const uint32_t fmed = umed3(f0, f1, f2);
+        const uint32_t limit = min(fmed, kFixMaxDelta);
+        const uint32_t lead = addSatUniform(fmin, fix_margin);
+        const unsigned long long certain = __builtin_amdgcn_uicmp(lead, limit, kIcmpUlt);
+        unsigned long long a0 = __builtin_amdgcn_uicmp(f0, fmin, kIcmpEq);
+        unsigned long long a2 = __builtin_amdgcn_uicmp(f2, fmin, kIcmpEq);
+        const unsigned long long slow = am & ~certain;
+        if (slow)
+        {
+          int axis = 1;
+          if ((slow >> lane) & 1ull)
+          {
+            axis = exactNextAxis(mc, args.walks[ray], region_x, region_y, region_z, va >> 1);
+          }
+          a0 = (a0 & ~slow) | (slow & __ballot(axis == 0));
+          a2 = (a2 & ~slow) | (slow & __ballot(axis == 2));
+          if (kTrace)
+          {
+            ++dbg_slow;
+          }
+        }
+        const unsigned long long a1 = ~(a0 | a2);
+        f0 = addSat(f0, selectOrZero(a0, d0));
+        f1 = addSat(f1, selectOrZero(a1, d1));
+        f2 = addSat(f2, selectOrZero(a2, d2));
+        stride = selectI(a2, sz, selectI(a0, sx, sy));
+      }
+      va += uint32_t(stride);
+      left -= 1;
 
-      // ---- deferred ordering of misses on masked voxels.  Consumed after the step so the atomic's return latency is
-      // ---- covered by the step arithmetic: the empty asm pins the step's results ahead of this point (the optimiser
-      // ---- otherwise sinks the step below the flag test and the wave waits on the LDS round trip every iteration).
-      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(k0), "+v"(k1), "+v"(k2), "+v"(vi), "+v"(left));
+      // ---- deferred ordering of misses on masked voxels.  The returned tile word is consumed after the step, so the
+      // ---- LDS round trip is covered by the step arithmetic (waitTile carries the s_waitcnt).
       __builtin_amdgcn_sched_barrier(0);
       {
-        const bool flagged = __builtin_amdgcn_ubfe(old, sh + 15u, 1u) != 0;
-        const unsigned long long fm = __ballot(flagged);
-        if (args.dbg_counters)
+        old = waitTile(old);
+        // (a lane that did not visit holds a stale word: masked out)
+        const unsigned long long fm = vm & __ballot(__builtin_amdgcn_ubfe(old, sh | 15u, 1u) != 0);
+        const bool flagged = ((fm >> lane) & 1ull) != 0;
+        if (kTrace)
         {
-          dbg_active += uint32_t(__popcll(__ballot(visit)));
           dbg_fm += fm ? 1u : 0u;
         }
         if (fm)
@@ -1912,7 +2175,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           {
             const uint32_t pos =
               qcount + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u));
-            queue[pos] = make_uint2(vi_visit, ray);
+            // (the voxel just visited: the step has already moved on)
+            queue[pos] = make_uint2((va - uint32_t(stride)) >> 1, ray);
           }
           qcount += uint32_t(__popcll(fm));
           if (qcount > uint32_t(kQueueCap - 64))
@@ -1926,10 +2190,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       }
     }
 
-    unsigned long long clk_end_loop = 0;
-    if (args.dbg_counters && lane == 0)
+    if (kTrace && lane == 0)
     {
-      clk_end_loop = wall_clock64();
+      const unsigned long long clk_end_loop = wall_clock64();
       if (chunk_index < kTraceChunks)
       {
         unsigned long long *rec = args.dbg_counters + 16 + size_t(chunk_index) * kTraceWords;
@@ -1952,6 +2215,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         atomicAdd(&args.dbg_counters[1], (unsigned long long)dbg_active);
         atomicAdd(&args.dbg_counters[2], (unsigned long long)dbg_refills);
         atomicAdd(&args.dbg_counters[3], (unsigned long long)dbg_fm);
+        atomicAdd(&args.dbg_counters[4], (unsigned long long)dbg_slow);
       }
     }
     // Final queue flush.

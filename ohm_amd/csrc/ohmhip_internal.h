@@ -85,6 +85,10 @@ struct MapConst
   /// Per-ray RayFilterFlag bits of a batch the CALLER filtered (ohmhip_map_integrate_rays_filtered; null otherwise):
   /// the device then applies no filter of its own and takes "end point was clipped" from kRffClippedEnd (bit 2).
   const unsigned char *batch_filter_flags;
+  /// Fixed-point walk predictor (see Segment): units per metre of ray parameter, chosen so that a region's diagonal
+  /// maps to 2^30 / 1.01, and the lead (in units) the smallest candidate needs over the second smallest to be trusted.
+  double fix_scale;
+  uint32_t fix_margin;
 };
 
 /// Per-ray line-walk parameters: everything ohm/LineWalkCompute.h:260-280 derives once per ray, in fp64, plus the
@@ -112,21 +116,43 @@ enum : unsigned
   kRwWalk = 1u << 7           ///< ray part is walked (not kRfExcludeRay)
 };
 
-/// One (ray, region) unit of line-walk work: "resume ray `ray` with these per-axis step counts and visit `count`
-/// voxels", i.e. the walk state at the step that enters the region (all zero for the ray's first segment) and the number
-/// of voxels the ray visits before it leaves the region or ends.  Computed densely by k_ray_bin so the walk kernel's
-/// lane refill is a couple of loads and its loop needs one counter instead of six.
-/// Packing: s0/s1/s2 hold the step counts in their low 24 bits (a ray crosses at most 2^16 regions x 255 voxels per
-/// axis); s0 bit 31 marks the ray's first segment, s0 bit 30 that the segment's last voxel is the ray's end voxel
-/// (visited as part of the ray); the voxel count (<= 3 x 255 + 1) sits in the top bytes of s1 (low 8 bits) and s2.
+/// One (ray, region) unit of line-walk work: "visit `count` voxels of ray `ray` starting at voxel `vi` of the region".
+/// Computed densely by k_ray_bin so the walk kernel's lane refill is two 16-byte loads and a few unpacking
+/// instructions.
+///
+/// The record carries a FIXED-POINT PREDICTOR of the walk, not the walk state itself: f[a] is the time of the next step
+/// along axis a relative to the time the ray entered the region (the segment's first step for the ray's first segment),
+/// e[a] the step delta, both in units of 1 / MapConst::fix_scale metres of ray parameter, truncated.  The walk kernel
+/// advances the predictor with integer adds and takes its choice of axis whenever the smallest candidate leads the
+/// second smallest by more than MapConst::fix_margin units (the accumulated truncation error is at most 1 + steps per
+/// candidate); otherwise -- ties included -- the lane recomputes the exact fp64 time_next values from the ray's RayWalk
+/// record and the step counts implied by its position, and decides exactly as ohm/LineWalkCompute.h:282-301 does.  The
+/// voxel sequence is therefore bit-identical to the CPU walk and the common step needs no fp64 arithmetic.
+///   * values are clamped LOW only: f >= 2^31 is stored as kFixFar, e >= 2^30 as kFixMaxDelta; the kernel never trusts
+///     a candidate at or beyond kFixMaxDelta (every step a segment needs happens within the region's diagonal, which
+///     fix_scale maps to 2^30 / 1.01)
+///   * an axis with no steps left in the whole ray has f = kFixFar, e = 0 (time_next = inf in the reference)
+///   * an axis that runs out of steps INSIDE the segment keeps counting (its phantom steps lie beyond the ray's last
+///     real step; rays for which that cannot be shown in fp64 are poisoned)
+///   * a poisoned record (f = e = 0: negative / non-finite times, degenerate rays) is never certain: every step of it
+///     is decided exactly
+/// Packing: vox = first voxel index (15 bits) | voxel count << 15 (16 bits); e[a] bit 31 = the ray steps towards
+/// negative coordinates on axis a; ray = ray index (29 bits, as in the sample sort key) | kSegSkipFirst | kSegEnd.
 struct Segment
 {
+  uint32_t f[3];
+  uint32_t vox;
+  uint32_t e[3];
   uint32_t ray;
-  uint32_t s0, s1, s2;
 };
-constexpr uint32_t kSegFirst = 0x80000000u;
-constexpr uint32_t kSegEnd = 0x40000000u;
-constexpr uint32_t kSegStepMask = 0x00ffffffu;
+static_assert(sizeof(Segment) == 32, "segment records are loaded as two 16-byte words");
+constexpr uint32_t kSegRayMask = (1u << 29) - 1u;
+constexpr uint32_t kSegSkipFirst = 1u << 29;  ///< the segment's first voxel is the ray's origin voxel and kRfExcludeOrigin is set
+constexpr uint32_t kSegEnd = 1u << 30;        ///< the segment's last voxel is the ray's end voxel, visited as part of the ray
+constexpr uint32_t kSegVoxelBits = 15;
+constexpr uint32_t kSegNegative = 0x80000000u;
+constexpr uint32_t kFixFar = 0x80000000u;
+constexpr uint32_t kFixMaxDelta = 0x40000000u;
 
 struct Chunk
 {

@@ -469,7 +469,8 @@ size_t walkLdsBytes(const MapConst &mc, uint32_t chunk_segments)
   // [count tile, padded to 16 B][per-wave queues][staged sample keys][interval counters][cursor + pad]
   // [length histogram][segment order, u16 each]
   const size_t count_words = (size_t((mc.region_voxels + 1) / 2) + 3u) & ~size_t(3);
-  return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) + 8 +
+  return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) +
+          kWalkCursorWords +
           kLengthClasses + (chunk_segments + 1) / 2) *
          sizeof(uint32_t);
 }
@@ -735,6 +736,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.chunks = m->d_chunks;
         wa.segments = static_cast<const Segment *>(m->segments.ptr);
         wa.walks = static_cast<const RayWalk *>(m->walks.ptr);
+        wa.slot_keys = m->d_slot_keys;
         wa.sorted_hits = sorted;
         wa.hit_mask = m->d_hit_mask;
         wa.miss_counts = m->d_miss_counts;
@@ -749,7 +751,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.occupancy = direct_occ;
         wa.tsdf = tsdf_mode ? static_cast<float *>(m->layers[OHMHIP_LID_TSDF]) : nullptr;
         wa.ray_flags = ray_flags;
-        wa.dbg_counters = (m->debug_flags & 64u) ? m->d_dbg : nullptr;
+        const bool trace = (m->debug_flags & (16u | 64u | 128u)) != 0;
+        wa.dbg_counters = trace ? m->d_dbg : nullptr;
         wa.traversal = sec.traversal;
         wa.chunk_cursor = m->d_event_count + 1;
         wa.n_chunks = info.n_chunks;
@@ -763,19 +766,23 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments);
         if (special && sec.traversal)
         {
-          hipLaunchKernelGGL((k_region_walk<true, true>), wgrid, wblock, wlds, s, wa);
+          hipLaunchKernelGGL((k_region_walk<true, true, false>), wgrid, wblock, wlds, s, wa);
         }
         else if (special)
         {
-          hipLaunchKernelGGL((k_region_walk<true, false>), wgrid, wblock, wlds, s, wa);
+          hipLaunchKernelGGL((k_region_walk<true, false, false>), wgrid, wblock, wlds, s, wa);
         }
         else if (sec.traversal)
         {
-          hipLaunchKernelGGL((k_region_walk<false, true>), wgrid, wblock, wlds, s, wa);
+          hipLaunchKernelGGL((k_region_walk<false, true, false>), wgrid, wblock, wlds, s, wa);
+        }
+        else if (trace)
+        {
+          hipLaunchKernelGGL((k_region_walk<false, false, true>), wgrid, wblock, wlds, s, wa);
         }
         else
         {
-          hipLaunchKernelGGL((k_region_walk<false, false>), wgrid, wblock, wlds, s, wa);
+          hipLaunchKernelGGL((k_region_walk<false, false, false>), wgrid, wblock, wlds, s, wa);
         }
         OHMHIP_CHECK(hipEventRecord(tev[3], s));
         if (occupancy_mode)
@@ -1113,6 +1120,14 @@ try
     mc.origin[a] = m->config.origin[a];
   }
   mc.region_voxels = mc.dim[0] * mc.dim[1] * mc.dim[2];
+  {
+    // Fixed-point walk predictor (ohmhip_internal.h, Segment): a region's diagonal maps to 2^30 / 1.01 units; the
+    // trusted lead covers one truncation per candidate plus one per step a candidate can take inside a region.
+    const double diagonal = std::sqrt(mc.region_dim[0] * mc.region_dim[0] + mc.region_dim[1] * mc.region_dim[1] +
+                                      mc.region_dim[2] * mc.region_dim[2]);
+    mc.fix_scale = double(kFixMaxDelta) / (1.01 * diagonal);
+    mc.fix_margin = 2u * uint32_t(std::max(mc.dim[0], std::max(mc.dim[1], mc.dim[2]))) + 8u;
+  }
   if (mc.region_voxels > (1 << kHitVoxelBits))
   {
     delete m;
@@ -1221,10 +1236,11 @@ try
     m->chunk_segments /= 2;
   }
   const size_t lds_bytes = walkLdsBytes(mc, m->chunk_segments);
-  const void *walk_kernels[4] = { reinterpret_cast<const void *>(k_region_walk<false, false>),
-                                  reinterpret_cast<const void *>(k_region_walk<false, true>),
-                                  reinterpret_cast<const void *>(k_region_walk<true, false>),
-                                  reinterpret_cast<const void *>(k_region_walk<true, true>) };
+  const void *walk_kernels[5] = { reinterpret_cast<const void *>(k_region_walk<false, false, false>),
+                                  reinterpret_cast<const void *>(k_region_walk<false, true, false>),
+                                  reinterpret_cast<const void *>(k_region_walk<true, false, false>),
+                                  reinterpret_cast<const void *>(k_region_walk<true, true, false>),
+                                  reinterpret_cast<const void *>(k_region_walk<false, false, true>) };
   for (const void *kernel : walk_kernels)
   {
     if ((err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
