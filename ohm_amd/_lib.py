@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libohmhip.so")
+# OHMHIP_LIB: development knob for A/B timing runs of differently built libraries (scripts/build_variant.sh).
+LIB_PATH = os.environ.get("OHMHIP_LIB") or os.path.join(_HERE, "lib", "libohmhip.so")
 
 
 class OhmHipError(RuntimeError):

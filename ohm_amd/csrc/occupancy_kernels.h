@@ -1443,6 +1443,8 @@ constexpr int kWalkThreads = 1024;
 constexpr int kWalkWaves = kWalkThreads / 64;
 constexpr int kQueueCap = 128;     ///< deferred events per wave (8 B each)
 constexpr int kLdsHits = 6144;     ///< a region's sample list is staged in LDS when it has at most this many samples
+constexpr uint32_t kIndexShift = 5;  ///< staged samples are indexed by voxel index >> kIndexShift ...
+constexpr uint32_t kIndexBuckets = (1u << kHitVoxelBits) >> kIndexShift;  ///< ... in this many buckets (+ 1 end entry)
 constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
 constexpr uint32_t kTileFlag = 0x8000u;       ///< mask flag inside a u16 tile entry
 constexpr uint32_t kTileCountMask = 0x7fffu;  ///< count bits of a u16 tile entry (a chunk adds <= kMaxChunkSegments)
@@ -1450,6 +1452,21 @@ constexpr uint32_t kMaxChunkSegments = 8192;  ///< bounded by the 15-bit counter
 constexpr uint32_t kTraceChunks = 4096;  ///< debug trace: records kept per launch
 constexpr uint32_t kTraceWords = 32;     ///< debug trace: u64 words per record
 constexpr uint32_t kLengthClasses = 128;      ///< segment length histogram bins (lengths above the last bin share it)
+
+/// Physical position of the count tile's logical word `w` (two voxels per word, voxel order).  A word's LDS bank is its
+/// index modulo 32, which in voxel order is (x / 2, y & 1): lanes whose rays advance in step through a region -- a
+/// lidar's vertical fan of beams has the same x and y in every lane -- would all hit one or two banks.  The tile is
+/// therefore stored with the bank bits XOR-ed with the y / z bits of the index (a permutation inside every 32-word row).
+__device__ inline uint32_t tileWord(uint32_t w)
+{
+  return w ^ (((w >> 5) ^ (w >> 10)) & 31u);
+}
+
+/// Byte address of the tile word holding the u16 entry at byte offset `va` (= 2 x voxel index).
+__device__ inline uint32_t tileAddress(uint32_t va)
+{
+  return (va & ~3u) ^ ((((va >> 5) ^ (va >> 10)) & (31u << 2)));
+}
 
 /// Resolve one deferred miss event: find the first sample of the same voxel with a larger ray index; the miss counts
 /// towards the interval before that sample, or towards the voxel's trailing count if there is none.
@@ -1482,7 +1499,8 @@ __device__ inline void resolveFlaggedMiss(unsigned long long key, const BatchScr
 /// for NDT / TSDF).
 __device__ inline void flushQueue(const uint2 *queue, uint32_t qcount, unsigned lane, unsigned long long slot_bits,
                                   int ray_shift, bool lds_resolve, const unsigned long long *l_hits,
-                                  uint32_t n_region_hits, uint32_t *l_intervals, uint32_t *l_counts,
+                                  const uint16_t *l_index, uint32_t n_region_hits, uint32_t *l_intervals,
+                                  uint32_t *l_counts,
                                   unsigned long long *__restrict__ events, uint32_t event_capacity,
                                   uint32_t *__restrict__ event_count, int defer_all, const BatchScratch &bs,
                                   const unsigned long long *__restrict__ sorted_hits,
@@ -1496,8 +1514,9 @@ __device__ inline void flushQueue(const uint2 *queue, uint32_t qcount, unsigned 
       const uint2 e = queue[q];
       const unsigned long long ev =
         slot_bits | ((unsigned long long)e.x << kHitRayBits) | ((unsigned long long)e.y << ray_shift);
-      // First staged sample with key > ev.
-      uint32_t lo = 0, hi = n_region_hits;
+      // First staged sample with key > ev: the bucket index narrows the search to the samples of the event's 32
+      // voxels (a handful), a binary search finishes it.
+      uint32_t lo = l_index[e.x >> kIndexShift], hi = l_index[(e.x >> kIndexShift) + 1u];
       while (lo < hi)
       {
         const uint32_t mid = (lo + hi) >> 1;
@@ -1510,11 +1529,12 @@ __device__ inline void flushQueue(const uint2 *queue, uint32_t qcount, unsigned 
           lo = mid + 1;
         }
       }
+      // (lo may be the first sample of the next bucket: the voxel test below rejects it)
       if (lo < n_region_hits && (l_hits[lo] >> kHitRayBits) == (ev >> kHitRayBits))
       {
         // Belongs before a later sample of the voxel: move it from the voxel's count to that sample's interval.
         atomicAdd(&l_intervals[lo >> 1], 1u << ((lo & 1u) * 16u));
-        atomicSub(&l_counts[e.x >> 1], 1u << ((e.x & 1u) * 16u));
+        atomicSub(&l_counts[tileWord(e.x >> 1)], 1u << ((e.x & 1u) * 16u));
       }
     }
     return;
@@ -1705,6 +1725,10 @@ struct WalkArgs
 };
 
 constexpr uint32_t kWalkCursorWords = 12;  ///< l_cursor[]: see k_region_walk
+#ifndef OHMHIP_WALK_UNROLL
+#define OHMHIP_WALK_UNROLL 2
+#endif
+constexpr int kWalkUnroll = OHMHIP_WALK_UNROLL;  ///< walk steps per loop trip (see the loop)
 
 /// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
 /// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every iteration
@@ -1725,13 +1749,15 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   const uint32_t count_words = uint32_t(mc.region_voxels + 1) >> 1;
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
   uint32_t *l_counts = lds;
-  uint2 *l_queues = reinterpret_cast<uint2 *>(lds + ((count_words + 3u) & ~3u));
+  uint2 *l_queues = reinterpret_cast<uint2 *>(lds + ((count_words + 31u) & ~31u));  // (whole rows: see tileWord)
   unsigned long long *l_hits = reinterpret_cast<unsigned long long *>(l_queues + kWalkWaves * kQueueCap);
   uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] u16 interval counters
   // l_cursor[0]: segment cursor, [1]: next chunk index, [2..5]: its record, [6..7]: its samples, [8..9]: its region key
   uint32_t *l_cursor = l_intervals + kLdsHits / 2;
   uint32_t *l_hist = l_cursor + kWalkCursorWords;
-  uint16_t *l_order = reinterpret_cast<uint16_t *>(l_hist + kLengthClasses);
+  uint32_t *l_idle = l_hist + kLengthClasses;  // [64] scratch words: where a lane with nothing to visit aims its LDS add
+  uint16_t *l_index = reinterpret_cast<uint16_t *>(l_idle + 64);  // [kIndexBuckets + 2] first staged sample per bucket
+  uint16_t *l_order = l_index + kIndexBuckets + 2;
 
   // Persistent workgroups: the launch has one workgroup per CU and each takes chunks from a device-wide cursor until
   // none are left.  A static blockIdx -> chunk binding leaves the hardware's round-robin of workgroups over the 8 XCDs
@@ -1824,37 +1850,47 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     {
       l_cursor[0] = 0;
     }
+    if (threadIdx.x < 64)
+    {
+      l_idle[threadIdx.x] = 0;
+    }
     const bool stamp = kTrace && threadIdx.x == 0;
     unsigned long long clk_p[6] = { 0, 0, 0, 0, 0, 0 };
     if (stamp)
     {
       clk_p[0] = wall_clock64();
     }
-    // Tile entries start at zero count with the voxel's mask flag in the top bit: one mask word covers 16 tile words.
+    // Tile entries start at zero count with the voxel's mask flag in the top bit: one mask word covers 16 tile words,
+    // half a row of the tile, which tileWord() maps onto half a row again: the 4-word groups permuted by the high bits
+    // of the row's XOR constant, the words inside a group by its low two bits.
     for (uint32_t w = threadIdx.x; w < mask_words; w += kWalkThreads)
     {
       const uint32_t mword = (w == threadIdx.x) ? my_mask : g_mask[w];
+      const uint32_t swizzle = tileWord(w * 16u) ^ (w * 16u);
 #pragma unroll
       for (uint32_t q = 0; q < 4; ++q)
       {
-        uint32_t v[4];
+        const uint32_t logical = w * 16u + q * 4u;
+        if (logical + 3u < count_words)
+        {
+          uint32_t v[4];
 #pragma unroll
-        for (uint32_t r = 0; r < 4; ++r)
-        {
-          const uint32_t two = (mword >> ((q * 4u + r) * 2u)) & 3u;
-          v[r] = ((two & 1u) << 15) | ((two & 2u) << 30);
-        }
-        if (w * 16u + q * 4u + 3u < count_words)
-        {
-          *reinterpret_cast<uint4 *>(&l_counts[w * 16u + q * 4u]) = make_uint4(v[0], v[1], v[2], v[3]);
+          for (uint32_t r = 0; r < 4; ++r)
+          {
+            // physical word r of the group holds logical word r ^ (swizzle & 3)
+            const uint32_t two = (mword >> ((q * 4u + (r ^ (swizzle & 3u))) * 2u)) & 3u;
+            v[r] = ((two & 1u) << 15) | ((two & 2u) << 30);
+          }
+          *reinterpret_cast<uint4 *>(&l_counts[logical ^ (swizzle & ~3u)]) = make_uint4(v[0], v[1], v[2], v[3]);
         }
         else
         {
           for (uint32_t r = 0; r < 4; ++r)
           {
-            if (w * 16u + q * 4u + r < count_words)
+            if (logical + r < count_words)
             {
-              l_counts[w * 16u + q * 4u + r] = v[r];
+              const uint32_t two = (mword >> ((q * 4u + r) * 2u)) & 3u;
+              l_counts[tileWord(logical + r)] = ((two & 1u) << 15) | ((two & 2u) << 30);
             }
           }
         }
@@ -1900,6 +1936,34 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     if (stamp)
     {
       clk_p[3] = wall_clock64();
+    }
+    if (lds_resolve && n_region_hits)
+    {
+      // Bucket index over the staged samples (sorted by voxel): l_index[b] = first sample of a voxel in bucket >= b.
+#pragma unroll
+      for (int j = 0; j < kHitsPerThread; ++j)
+      {
+        const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
+        if (i < n_region_hits)
+        {
+          auto bucketOf = [](unsigned long long key) {
+            return (uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u)) >> kIndexShift;
+          };
+          const uint32_t b = bucketOf(my_hits[j]);
+          const uint32_t first = (i == 0) ? 0u : bucketOf(l_hits[i - 1]) + 1u;
+          for (uint32_t k = first; k <= b; ++k)
+          {
+            l_index[k] = uint16_t(i);
+          }
+          if (i + 1 == n_region_hits)
+          {
+            for (uint32_t k = b + 1u; k <= kIndexBuckets; ++k)
+            {
+              l_index[k] = uint16_t(n_region_hits);
+            }
+          }
+        }
+      }
     }
     if (threadIdx.x < 64)
     {
@@ -1953,6 +2017,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     const int refill_min_idle = args.refill_min_idle;
     const bool refill_only = kTrace && (args.dbg & 16u) != 0;
     const uint32_t fix_margin = mc.fix_margin;
+    const uint32_t idle_address = uint32_t(reinterpret_cast<char *>(l_idle + lane) - reinterpret_cast<char *>(lds));
 
     // Per-lane walk state (all named scalars: no run-time indexed arrays).
     int left = 0;  // voxels this lane still has to visit in its segment (<= 0: idle)
@@ -1968,7 +2033,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     int k0 = 0, k1 = 0, k2 = 0, tot0 = 0, tot1 = 0, tot2 = 0;  // steps taken / steps in the whole ray per axis
     double t_enter = 0;     // range at which the current voxel was entered
     double ray_len = 0;     // kSpecial: exit range of the end voxel
-    uint32_t old = 0;        // tile word returned by the visit's LDS add
     uint32_t qcount = 0;     // wave-uniform
     bool exhausted = false;  // wave-uniform
     uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0, dbg_slow = 0;  // wave-uniform (kTrace)
@@ -1978,13 +2042,22 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       clk_loop = wall_clock64();
     }
 
+    // The walk loop.  A wave's trip is a chain of dependent hops (LDS round trip, mask algebra on the scalar unit,
+    // branches), and with four waves per SIMD the chain, not instruction issue, sets the pace.  So one trip takes
+    // kWalkUnroll steps per lane: one refill / exit test per trip, the steps' LDS adds in flight together, their
+    // returned flags tested after the last step.  A lane whose segment ends inside a trip idles for the rest of it.
+    int refill_threshold = refill_min_idle;  // idle lanes that trigger a refill; 64 once the chunk has no segments left
     while (true)
     {
       // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
-      unsigned long long am = __ballot(left > 0);
+      const unsigned long long am = __ballot(left > 0);
       const int n_idle = 64 - __popcll(am);
-      if (!exhausted && (n_idle >= refill_min_idle))
+      if (n_idle >= refill_threshold)
       {
+        if (exhausted)
+        {
+          break;  // every lane idle and nothing left to hand out
+        }
         if (kTrace)
         {
           ++dbg_refills;
@@ -1996,6 +2069,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         }
         base = __builtin_amdgcn_readfirstlane(base);
         exhausted = base + uint32_t(n_idle) >= n_seg;
+        refill_threshold = exhausted ? 64 : refill_threshold;
         const unsigned long long idle = ~am;
         const uint32_t mine =
           base + __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
@@ -2048,123 +2122,151 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           }
           left = refill_only ? 0 : left;
         }
-        am = __ballot(left > 0);
-      }
-      if (am == 0)
-      {
-        break;
       }
 
-      // ---- visit: count the miss and fetch the voxel's mask flag with one returning LDS atomic.  Masked voxels (which
-      // ---- also receive samples) are counted too; the ordering pass moves such a miss to an interval counter when a
-      // ---- later sample of the voxel exists.  `va` is the byte offset of the voxel's u16 tile entry (2 x voxel index):
-      // ---- word address = va & ~3, and both shifts below only use the low five bits of their shift operand, so
-      // ---- (va << 3) selects bit 0 or 16 of the word for the count and (.. | 15) bit 15 or 31 for the flag.
-      // kSpecial: the ray's end voxel (last voxel of a kSegEnd segment) is always visited; kRfExcludeOrigin drops the
-      // first voxel of the ray otherwise.
-      const bool at_end = kSpecial && end_last && left == 1;
-      const bool visit = kSpecial ? (left > 0 && (at_end || !skip)) : (left > 0);
-      const uint32_t sh = va << 3;
-      const unsigned long long vm = __ballot(visit);
-      if (visit)
+      uint32_t olds[kWalkUnroll];     // tile word returned by each step's LDS add
+      uint32_t visited[kWalkUnroll];  // `va` of each step's voxel
+#pragma unroll
+      for (int u = 0; u < kWalkUnroll; ++u)
       {
-        old = tileAdd(va & ~3u, shiftOne(sh));
-      }
-      if (kSpecial)
-      {
-        skip = 0;
-      }
-      if (kTrace)
-      {
-        ++dbg_iters;
-        dbg_active += uint32_t(__popcll(am));
-      }
-
-      int stride;
-      if (kTraversal)
-      {
-        const bool active = left > 0;
-        // exit range of this voxel == time of the next step (the ray's length at its end voxel)
-        const double tm01 = (t0 < t1) ? t0 : t1;
-        double t_exit = (tm01 < t2) ? tm01 : t2;
+        // ---- visit: count the miss and fetch the voxel's mask flag with one returning LDS atomic.  Masked voxels
+        // ---- (which also receive samples) are counted too; the ordering pass moves such a miss to an interval counter
+        // ---- when a later sample of the voxel exists.  `va` is the byte offset of the voxel's u16 tile entry
+        // ---- (2 x voxel index): word address = va & ~3, and the shifts only read the low five bits of their shift
+        // ---- operand, so (va << 3) selects bit 0 or 16 of the word for the count and (.. | 15) bit 15 or 31 for the
+        // ---- flag.  A lane with nothing to visit adds to its own scratch word instead (no exec-mask juggling; the
+        // ---- scratch words start every chunk at zero and a lane idles for far fewer than 2^15 steps of a chunk, so
+        // ---- their flag bits stay clear).
+        // kSpecial: the ray's end voxel (last voxel of a kSegEnd segment) is always visited; kRfExcludeOrigin drops
+        // the first voxel of the ray otherwise.
+        const bool at_end = kSpecial && end_last && left == 1;
+        const bool visit = kSpecial ? (left > 0 && (at_end || !skip)) : (left > 0);
+        visited[u] = va;
+#ifdef OHMHIP_ABL_NOLDS
+        olds[u] = 0;
+#elif defined(OHMHIP_ABL_LINEAR)
+        olds[u] = tileAdd(((lane + (uint32_t(left) & 255u) * 64u) & 16383u) << 2, shiftOne(va << 3));
+#elif defined(OHMHIP_ABL_RANDOM)
+        olds[u] = tileAdd((((va * 2654435761u) ^ (ray * 0x9E3779B1u)) >> 16) & 0xfffcu, shiftOne(va << 3));
+#else
+        olds[u] = tileAdd(visit ? tileAddress(va) : idle_address, shiftOne(va << 3));
+#endif
         if (kSpecial)
         {
-          t_exit = at_end ? ray_len : t_exit;
+          skip = 0;
         }
-        if (visit)
+        if (kTrace)
         {
-          atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + (va >> 1)],
-                    float(t_exit - t_enter));
+          ++dbg_iters;
+          dbg_active += uint32_t(__popcll(__ballot(visit)));
         }
-        t_enter = active ? t_exit : t_enter;
-        // ---- the reference's fp64 step, branch free, taken by every lane (an idle lane's state is dead, and the step
-        // ---- after a segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): ties
-        // ---- go to the higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
-        const unsigned long long m01 = __builtin_amdgcn_fcmp(t0, t1, kFcmpOlt);
-        const double t01 = selectD(m01, t0, t1);
-        const unsigned long long m2 = __builtin_amdgcn_fcmp(t01, t2, kFcmpOlt);
-        const unsigned long long a0 = m2 & m01;
-        const unsigned long long a1 = m2 & ~m01;
-        const unsigned long long a2 = ~m2;
-        k0 = addMask(k0, a0);
-        k1 = addMask(k1, a1);
-        k2 = addMask(k2, a2);
-        const unsigned long long g0 = __builtin_amdgcn_sicmp(k0, tot0, kIcmpSlt);
-        const unsigned long long g1 = __builtin_amdgcn_sicmp(k1, tot1, kIcmpSlt);
-        const unsigned long long g2 = __builtin_amdgcn_sicmp(k2, tot2, kIcmpSlt);
-        const double n0 = selectD(g0, i0 + e0 * double(k0), inf);
-        const double n1 = selectD(g1, i1 + e1 * double(k1), inf);
-        const double n2 = selectD(g2, i2 + e2 * double(k2), inf);
-        t0 = selectD(a0, n0, t0);
-        t1 = selectD(a1, n1, t1);
-        t2 = selectD(a2, n2, t2);
-        stride = selectI(a2, sz, selectI(a0, sx, sy));
-      }
-      else
-      {
-        // ---- one walk step from the fixed-point predictor (see Segment), taken by every lane.  The smallest candidate
-        // ---- is trusted when it lies inside the region's range (below kFixMaxDelta) and leads the second smallest by
-        // ---- more than the accumulated truncation error; an active lane that cannot trust it asks the reference's
-        // ---- fp64 arithmetic (rare: near-ties, ray ends that disagree with their keys, degenerate rays).
-        const uint32_t fmin = umin3(f0, f1, f2);
-        const uint32_t fmed = umed3(f0, f1, f2);
-        const uint32_t limit = min(fmed, kFixMaxDelta);
-        const uint32_t lead = addSatUniform(fmin, fix_margin);
-        const unsigned long long certain = __builtin_amdgcn_uicmp(lead, limit, kIcmpUlt);
-        unsigned long long a0 = __builtin_amdgcn_uicmp(f0, fmin, kIcmpEq);
-        unsigned long long a2 = __builtin_amdgcn_uicmp(f2, fmin, kIcmpEq);
-        const unsigned long long slow = am & ~certain;
-        if (slow)
-        {
-          int axis = 1;
-          if ((slow >> lane) & 1ull)
-          {
-            axis = exactNextAxis(mc, args.walks[ray], region_x, region_y, region_z, va >> 1);
-          }
-          a0 = (a0 & ~slow) | (slow & __ballot(axis == 0));
-          a2 = (a2 & ~slow) | (slow & __ballot(axis == 2));
-          if (kTrace)
-          {
-            ++dbg_slow;
-          }
-        }
-        const unsigned long long a1 = ~(a0 | a2);
-        f0 = addSat(f0, selectOrZero(a0, d0));
-        f1 = addSat(f1, selectOrZero(a1, d1));
-        f2 = addSat(f2, selectOrZero(a2, d2));
-        stride = selectI(a2, sz, selectI(a0, sx, sy));
-      }
-      va += uint32_t(stride);
-      left -= 1;
 
-      // ---- deferred ordering of misses on masked voxels.  The returned tile word is consumed after the step, so the
-      // ---- LDS round trip is covered by the step arithmetic (waitTile carries the s_waitcnt).
+        int stride;
+        if (kTraversal)
+        {
+          const bool active = left > 0;
+          // exit range of this voxel == time of the next step (the ray's length at its end voxel)
+          const double tm01 = (t0 < t1) ? t0 : t1;
+          double t_exit = (tm01 < t2) ? tm01 : t2;
+          if (kSpecial)
+          {
+            t_exit = at_end ? ray_len : t_exit;
+          }
+          if (visit)
+          {
+            atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + (va >> 1)],
+                      float(t_exit - t_enter));
+          }
+          t_enter = active ? t_exit : t_enter;
+          // ---- the reference's fp64 step, branch free, taken by every lane (an idle lane's state is dead, and the
+          // ---- step after a segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289):
+          // ---- ties go to the higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
+          const unsigned long long m01 = __builtin_amdgcn_fcmp(t0, t1, kFcmpOlt);
+          const double t01 = selectD(m01, t0, t1);
+          const unsigned long long m2 = __builtin_amdgcn_fcmp(t01, t2, kFcmpOlt);
+          const unsigned long long a0 = m2 & m01;
+          const unsigned long long a1 = m2 & ~m01;
+          const unsigned long long a2 = ~m2;
+          k0 = addMask(k0, a0);
+          k1 = addMask(k1, a1);
+          k2 = addMask(k2, a2);
+          const unsigned long long g0 = __builtin_amdgcn_sicmp(k0, tot0, kIcmpSlt);
+          const unsigned long long g1 = __builtin_amdgcn_sicmp(k1, tot1, kIcmpSlt);
+          const unsigned long long g2 = __builtin_amdgcn_sicmp(k2, tot2, kIcmpSlt);
+          const double n0 = selectD(g0, i0 + e0 * double(k0), inf);
+          const double n1 = selectD(g1, i1 + e1 * double(k1), inf);
+          const double n2 = selectD(g2, i2 + e2 * double(k2), inf);
+          t0 = selectD(a0, n0, t0);
+          t1 = selectD(a1, n1, t1);
+          t2 = selectD(a2, n2, t2);
+          stride = selectI(a2, sz, selectI(a0, sx, sy));
+        }
+        else
+        {
+          // ---- one walk step from the fixed-point predictor (see Segment), taken by every lane.  The smallest
+          // ---- candidate is trusted when it lies inside the region's range (below kFixMaxDelta) and leads the second
+          // ---- smallest by more than the accumulated truncation error; a visiting lane that cannot trust it asks the
+          // ---- reference's fp64 arithmetic (rare: near-ties, ray ends that disagree with their keys, degenerate rays).
+          const uint32_t fmin = umin3(f0, f1, f2);
+          const uint32_t fmed = umed3(f0, f1, f2);
+          const uint32_t limit = min(fmed, kFixMaxDelta);
+          const uint32_t lead = addSatUniform(fmin, fix_margin);
+          const unsigned long long certain = __builtin_amdgcn_uicmp(lead, limit, kIcmpUlt);
+          unsigned long long a0 = __builtin_amdgcn_uicmp(f0, fmin, kIcmpEq);
+          unsigned long long a2 = __builtin_amdgcn_uicmp(f2, fmin, kIcmpEq);
+#ifdef OHMHIP_ABL_NOSLOW
+          const unsigned long long slow = 0;
+          (void)certain;
+#else
+          const unsigned long long slow = __ballot(left > 0) & ~certain;
+#endif
+          if (slow)
+          {
+            int axis = 1;
+            if ((slow >> lane) & 1ull)
+            {
+              uint32_t r = ray;
+              asm volatile("" : "+v"(r));  // keeps the record's address arithmetic inside this (rare) block
+              axis = exactNextAxis(mc, args.walks[r], region_x, region_y, region_z, va >> 1);
+            }
+            a0 = (a0 & ~slow) | (slow & __ballot(axis == 0));
+            a2 = (a2 & ~slow) | (slow & __ballot(axis == 2));
+            if (kTrace)
+            {
+              ++dbg_slow;
+            }
+          }
+          const unsigned long long a1 = ~(a0 | a2);
+          f0 = addSat(f0, selectOrZero(a0, d0));
+          f1 = addSat(f1, selectOrZero(a1, d1));
+          f2 = addSat(f2, selectOrZero(a2, d2));
+          stride = selectI(a2, sz, selectI(a0, sx, sy));
+        }
+        va += uint32_t(stride);
+        left -= 1;
+      }
+
+      // ---- deferred ordering of misses on masked voxels.  The returned tile words are consumed after the trip's last
+      // ---- step, so the LDS round trips are covered by the step arithmetic (waitTile carries the s_waitcnt).
       __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kWalkUnroll; ++u)
       {
-        old = waitTile(old);
-        // (a lane that did not visit holds a stale word: masked out)
-        const unsigned long long fm = vm & __ballot(__builtin_amdgcn_ubfe(old, sh | 15u, 1u) != 0);
-        const bool flagged = ((fm >> lane) & 1ull) != 0;
+        olds[u] = waitTile(olds[u]);  // (the first one waits; LDS operations return in order)
+      }
+#ifdef OHMHIP_ABL_NOFLAG
+      if (olds[0] == 0x12345u)
+      {
+        ++qcount;
+      }
+      if (false)
+#endif
+#pragma unroll
+      for (int u = 0; u < kWalkUnroll; ++u)
+      {
+        // (a lane that did not visit holds its scratch word, whose flag bits are clear)
+        const bool flagged = __builtin_amdgcn_ubfe(olds[u], (visited[u] << 3) | 15u, 1u) != 0;
+        const unsigned long long fm = __ballot(flagged);
         if (kTrace)
         {
           dbg_fm += fm ? 1u : 0u;
@@ -2175,14 +2277,13 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           {
             const uint32_t pos =
               qcount + __builtin_amdgcn_mbcnt_hi(uint32_t(fm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(fm), 0u));
-            // (the voxel just visited: the step has already moved on)
-            queue[pos] = make_uint2((va - uint32_t(stride)) >> 1, ray);
+            queue[pos] = make_uint2(visited[u] >> 1, ray);
           }
           qcount += uint32_t(__popcll(fm));
           if (qcount > uint32_t(kQueueCap - 64))
           {
-            flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals,
-                       l_counts, args.events, args.event_capacity, args.event_count, defer_all, args.bs,
+            flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, l_index, n_region_hits,
+                       l_intervals, l_counts, args.events, args.event_capacity, args.event_count, defer_all, args.bs,
                        args.sorted_hits, args.miss_counts, args.interval_counts, mc.region_voxels);
             qcount = 0;
           }
@@ -2221,8 +2322,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // Final queue flush.
     if (qcount)
     {
-      flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, n_region_hits, l_intervals, l_counts,
-                 args.events, args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits,
+      flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, l_index, n_region_hits, l_intervals,
+                 l_counts, args.events, args.event_capacity, args.event_count, defer_all, args.bs, args.sorted_hits,
                  args.miss_counts, args.interval_counts, mc.region_voxels);
     }
     if (threadIdx.x == 0)
@@ -2263,11 +2364,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       for (uint32_t j = 0; j < kWordsPerThread; ++j)
       {
         const uint32_t i = threadIdx.x + j * kWalkThreads;
-        uint32_t w = (i < count_words) ? l_counts[i] : 0u;
+        const uint32_t flagged_w = (i < count_words) ? l_counts[tileWord(i)] : 0u;
+        uint32_t w = flagged_w;
         // Keep only the entries applied here: unflagged voxels with a count.
         w = (w & kTileFlag) ? (w & 0xffff0000u) : w;
         w = (w & (kTileFlag << 16)) ? (w & 0x0000ffffu) : w;
-        const uint32_t flagged_w = (i < count_words) ? l_counts[i] : 0u;
         if (!defer_all)
         {
           // Voxels which also receive samples keep their count for the ordered replay (k_apply_hits).
@@ -2337,7 +2438,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         for (uint32_t j = 0; j < kTsdfBatch; ++j)
         {
           const uint32_t i = first + j * kWalkThreads;
-          uint32_t w = (i < count_words) ? l_counts[i] : 0u;
+          uint32_t w = (i < count_words) ? l_counts[tileWord(i)] : 0u;
           w = (w & kTileFlag) ? (w & 0xffff0000u) : w;
           w = (w & (kTileFlag << 16)) ? (w & 0x0000ffffu) : w;
           words[j] = w;
@@ -2382,7 +2483,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // entries of masked voxels are skipped -- their visits travel as events.)
     for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
     {
-      const uint32_t w = l_counts[i];
+      const uint32_t w = l_counts[tileWord(i)];
       if (w & (kTileCountMask | (kTileCountMask << 16)))
       {
 #pragma unroll

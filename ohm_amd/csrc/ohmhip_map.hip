@@ -468,9 +468,9 @@ size_t walkLdsBytes(const MapConst &mc, uint32_t chunk_segments)
 {
   // [count tile, padded to 16 B][per-wave queues][staged sample keys][interval counters][cursor + pad]
   // [length histogram][segment order, u16 each]
-  const size_t count_words = (size_t((mc.region_voxels + 1) / 2) + 3u) & ~size_t(3);
+  const size_t count_words = (size_t((mc.region_voxels + 1) / 2) + 31u) & ~size_t(31);  // whole 32-word rows (tileWord)
   return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) +
-          kWalkCursorWords +
+          kWalkCursorWords + 64 + (kIndexBuckets + 2) / 2 +
           kLengthClasses + (chunk_segments + 1) / 2) *
          sizeof(uint32_t);
 }
@@ -1652,12 +1652,13 @@ try
     return OHMHIP_ERR_INVALID_ARG;
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
-  if (m->debug_flags & 64u)
+  if (m->debug_flags & (64u | 128u))
   {
     static unsigned long long c[kDbgWords];
     OHMHIP_CHECK(hipMemcpy(c, m->d_dbg, sizeof(c), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[ohmhip dbg] wave-iterations %llu visits %llu refills %llu flagged-iterations %llu\n", c[0], c[1], c[2],
-                 c[3]);
+    std::fprintf(stderr,
+                 "[ohmhip dbg] wave-steps %llu visits %llu refills %llu flagged wave-steps %llu exact wave-steps %llu\n",
+                 c[0], c[1], c[2], c[3], c[4]);
     if (const char *path = std::getenv("OHMHIP_DEBUG_TRACE"))
     {
       if (FILE *f = std::fopen(path, "w"))
