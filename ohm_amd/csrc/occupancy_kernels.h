@@ -1724,7 +1724,7 @@ struct WalkArgs
   uint32_t n_chunks;
 };
 
-constexpr uint32_t kWalkCursorWords = 12;  ///< l_cursor[]: see k_region_walk
+constexpr uint32_t kWalkCursorWords = 24;  ///< l_cursor[]: see k_region_walk
 #ifndef OHMHIP_WALK_UNROLL
 #define OHMHIP_WALK_UNROLL 2
 #endif
@@ -1752,7 +1752,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   uint2 *l_queues = reinterpret_cast<uint2 *>(lds + ((count_words + 31u) & ~31u));  // (whole rows: see tileWord)
   unsigned long long *l_hits = reinterpret_cast<unsigned long long *>(l_queues + kWalkWaves * kQueueCap);
   uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] u16 interval counters
-  // l_cursor[0]: segment cursor, [1]: next chunk index, [2..5]: its record, [6..7]: its samples, [8..9]: its region key
+  // l_cursor[0]: segment cursor, [1]: a fetched chunk's index, [2..5]: its record, [6..7]: its samples, [8..9]: its
+  // region key; [12..21]: a second record (start-up only)
   uint32_t *l_cursor = l_intervals + kLdsHits / 2;
   uint32_t *l_hist = l_cursor + kWalkCursorWords;
   uint32_t *l_idle = l_hist + kLengthClasses;  // [64] scratch words: where a lane with nothing to visit aims its LDS add
@@ -1766,81 +1767,131 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   // the next one while the other waves are still finishing their loop, so a trip does not start with a chain of
   // dependent global loads.
   const int defer_all = args.defer_all;
-  auto fetchNextChunk = [&]() {
+  auto fetchNextChunk = [&](uint32_t *record) {
     const uint32_t next = atomicAdd(args.chunk_cursor, 1u);
-    l_cursor[1] = next;
+    record[1] = next;
     if (next < args.n_chunks)
     {
       const Chunk c = args.chunks[next];
-      l_cursor[2] = c.slot;
-      l_cursor[3] = c.seg_begin;
-      l_cursor[4] = c.seg_end;
-      l_cursor[5] = c.hash_index;
-      l_cursor[6] = defer_all ? 0u : args.bs.hit_begin[c.slot];
-      l_cursor[7] = defer_all ? 0u : args.bs.hit_end[c.slot];
+      record[2] = c.slot;
+      record[3] = c.seg_begin;
+      record[4] = c.seg_end;
+      record[5] = c.hash_index;
+      record[6] = defer_all ? 0u : args.bs.hit_begin[c.slot];
+      record[7] = defer_all ? 0u : args.bs.hit_end[c.slot];
       const uint64_t key = args.slot_keys[c.slot];
-      l_cursor[8] = uint32_t(key);
-      l_cursor[9] = uint32_t(key >> 32);
+      record[8] = uint32_t(key);
+      record[9] = uint32_t(key >> 32);
     }
   };
-  if (threadIdx.x == 0)
+  // A workgroup holds two chunk records: the chunk it works on and the next one.  While it walks chunk N every thread
+  // loads its share of chunk N + 1's prologue inputs (segment lengths, the region's sample keys and mask words) into
+  // registers -- issued behind the first lane refill of chunk N, so the loads complete under the walk and the next
+  // prologue starts without a memory round trip -- and thread 0 claims chunk N + 2 while the other waves finish their
+  // loop.
+  constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
+  constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
+  struct ChunkRecord
   {
-    fetchNextChunk();
+    uint32_t index, slot, seg_begin, seg_end, hash_index, hb, he, key_lo, key_hi;
+  };
+  auto readRecord = [&](const uint32_t *record) {
+    // (readfirstlane: the values are wave-uniform, so the chunk loop's condition is a scalar branch and the barriers
+    // inside the loop are not restructured as if threads could leave at different trips.)
+    ChunkRecord r;
+    r.index = __builtin_amdgcn_readfirstlane(record[1]);
+    r.slot = __builtin_amdgcn_readfirstlane(record[2]);
+    r.seg_begin = __builtin_amdgcn_readfirstlane(record[3]);
+    r.seg_end = __builtin_amdgcn_readfirstlane(record[4]);
+    r.hash_index = __builtin_amdgcn_readfirstlane(record[5]);
+    r.hb = __builtin_amdgcn_readfirstlane(record[6]);
+    r.he = __builtin_amdgcn_readfirstlane(record[7]);
+    r.key_lo = __builtin_amdgcn_readfirstlane(record[8]);
+    r.key_hi = __builtin_amdgcn_readfirstlane(record[9]);
+    return r;
+  };
+  unsigned long long pf_hits[kHitsPerThread] = {};
+  uint32_t pf_vox[kSegPerThread] = {};
+  uint32_t pf_mask = 0;
+  // Every global load of a chunk's prologue that depends only on the chunk record, issued back to back: clamped instead
+  // of predicated so the loads share one basic block.
+  auto prefetchChunk = [&](const ChunkRecord &r) {
+    const uint32_t n_hits = r.he - r.hb;
+    if (!defer_all && n_hits && n_hits <= uint32_t(kLdsHits))
+    {
+#pragma unroll
+      for (int j = 0; j < kHitsPerThread; ++j)
+      {
+        pf_hits[j] = args.sorted_hits[r.hb + min(threadIdx.x + uint32_t(j) * kWalkThreads, n_hits - 1u)];
+      }
+    }
+    pf_mask = args.hit_mask[size_t(r.slot) * mask_words + min(threadIdx.x, mask_words - 1u)];
+    const uint32_t n = r.seg_end - r.seg_begin;
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j)
+    {
+      pf_vox[j] = args.segments[r.seg_begin + min(threadIdx.x + uint32_t(j) * kWalkThreads, n - 1u)].vox;
+    }
+  };
+  // The first two records: claimed by two waves at once (which of them gets the earlier chunk does not matter).
+  if (threadIdx.x == 0 || threadIdx.x == 64)
+  {
+    fetchNextChunk(l_cursor + (threadIdx.x ? kWalkCursorWords / 2 : 0));
   }
   __syncthreads();
-  // (readfirstlane: the values are wave-uniform, so the loop condition is a scalar branch and the barriers inside the
-  // loop are not restructured as if threads could leave at different trips.)
-  uint32_t chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
-  while (chunk_index < args.n_chunks)
+  ChunkRecord cur = readRecord(l_cursor);
+  ChunkRecord next = readRecord(l_cursor + kWalkCursorWords / 2);
+  if (next.index < cur.index)
+  {
+    const ChunkRecord swap = cur;
+    cur = next;
+    next = swap;
+  }
+  if (cur.index < args.n_chunks)
+  {
+    prefetchChunk(cur);
+  }
+  __syncthreads();  // (everyone has read the records: thread 0 may overwrite the first one)
+  while (cur.index < args.n_chunks)
   {
     unsigned long long clk_start = 0;
     if (kTrace)
     {
       clk_start = wall_clock64();
     }
+    const uint32_t chunk_index = cur.index;
     Chunk chunk;
-    chunk.slot = __builtin_amdgcn_readfirstlane(l_cursor[2]);
-    chunk.seg_begin = __builtin_amdgcn_readfirstlane(l_cursor[3]);
-    chunk.seg_end = __builtin_amdgcn_readfirstlane(l_cursor[4]);
-    chunk.hash_index = __builtin_amdgcn_readfirstlane(l_cursor[5]);
-    const uint32_t hb = __builtin_amdgcn_readfirstlane(l_cursor[6]);
-    const uint32_t he = __builtin_amdgcn_readfirstlane(l_cursor[7]);
-    const uint32_t key_lo = __builtin_amdgcn_readfirstlane(l_cursor[8]);
-    const uint32_t key_hi = __builtin_amdgcn_readfirstlane(l_cursor[9]);
+    chunk.slot = cur.slot;
+    chunk.seg_begin = cur.seg_begin;
+    chunk.seg_end = cur.seg_end;
+    chunk.hash_index = cur.hash_index;
+    const uint32_t hb = cur.hb;
+    const uint32_t he = cur.he;
     // Region coordinates (packRegionKey): only the exact decisions use them.
-    const int region_x = int(int16_t(key_lo & 0xffffu));
-    const int region_y = int(int16_t(key_lo >> 16));
-    const int region_z = int(int16_t(key_hi & 0xffffu));
+    const int region_x = int(int16_t(cur.key_lo & 0xffffu));
+    const int region_y = int(int16_t(cur.key_lo >> 16));
+    const int region_z = int(int16_t(cur.key_hi & 0xffffu));
     const uint32_t n_seg = chunk.seg_end - chunk.seg_begin;
     const Segment *chunk_segments = args.segments + chunk.seg_begin;
 
-    // ---- prologue.  One workgroup owns the CU (the tile takes most of its LDS), so nothing overlaps this phase: every
-    // ---- global load that depends only on the chunk record is issued back to back, clamped instead of predicated so
-    // ---- the loads share one basic block, and consumed afterwards.
-    constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
-    constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
-    // (The conditional sample loads come first: the segment words are consumed right below, and a wait for them placed
-    // ahead of the sample loads would serialise two memory round trips.)
-    // Stage the region's sorted sample keys so deferred misses can be ordered against them at LDS latency.
+    // ---- prologue.  One workgroup owns the CU (the tile takes most of its LDS), so nothing overlaps this phase; its
+    // ---- inputs are in registers already (prefetchChunk).
+    // The region's sorted sample keys are staged in LDS so deferred misses can be ordered against them at LDS latency.
     const uint32_t n_region_hits = he - hb;
     const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(kLdsHits);
     unsigned long long my_hits[kHitsPerThread];
-    if (lds_resolve && n_region_hits)
-    {
 #pragma unroll
-      for (int j = 0; j < kHitsPerThread; ++j)
-      {
-        my_hits[j] = args.sorted_hits[hb + min(threadIdx.x + uint32_t(j) * kWalkThreads, n_region_hits - 1u)];
-      }
+    for (int j = 0; j < kHitsPerThread; ++j)
+    {
+      my_hits[j] = pf_hits[j];
     }
     const uint32_t *g_mask = args.hit_mask + size_t(chunk.slot) * mask_words;
-    const uint32_t my_mask = g_mask[min(threadIdx.x, mask_words - 1u)];
+    const uint32_t my_mask = pf_mask;
     uint32_t lens[kSegPerThread];
 #pragma unroll
     for (int j = 0; j < kSegPerThread; ++j)
     {
-      const uint32_t i = min(threadIdx.x + uint32_t(j) * kWalkThreads, n_seg - 1u);
-      lens[j] = min(chunk_segments[i].vox >> kSegVoxelBits, kLengthClasses - 1u);
+      lens[j] = min(pf_vox[j] >> kSegVoxelBits, kLengthClasses - 1u);
     }
     if (threadIdx.x < kLengthClasses)
     {
@@ -1901,6 +1952,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       clk_p[1] = wall_clock64();
     }
     __syncthreads();
+    bool prefetched = false;  // wave-uniform: the next chunk's prologue loads have been issued
     if (stamp)
     {
       clk_p[2] = wall_clock64();
@@ -2122,6 +2174,16 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           }
           left = refill_only ? 0 : left;
         }
+        if (!prefetched)
+        {
+          // First refill of the chunk: the lanes' records are on their way, now queue the next chunk's prologue loads
+          // behind them (loads return in order, so nothing in this chunk ever waits for these).
+          prefetched = true;
+          if (next.index < args.n_chunks)
+          {
+            prefetchChunk(next);
+          }
+        }
       }
 
       uint32_t olds[kWalkUnroll];     // tile word returned by each step's LDS add
@@ -2328,9 +2390,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     }
     if (threadIdx.x == 0)
     {
-      fetchNextChunk();  // overlaps with the other waves finishing their loop
+      fetchNextChunk(l_cursor);  // the chunk after the next one; overlaps with the other waves finishing their loop
     }
     __syncthreads();
+    const ChunkRecord after_next = readRecord(l_cursor);
     if (stamp && chunk_index < kTraceChunks)
     {
       args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 24] = wall_clock64();  // epilogue start
@@ -2354,16 +2417,19 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       // straight from LDS (no count round trip through HBM).  Voxels which also receive samples keep their count for
       // the ordered replay (occupancy: k_apply_hits; NDT: their visits are events, the tile entry is not used).
       float *g_occ = args.occupancy + size_t(chunk.slot) * size_t(mc.region_voxels);
-      // Two passes so the loads of all the voxels a thread updates are in flight together (a load -> update -> store
-      // loop would pay the memory latency once per touched word, and nothing else runs on this CU to hide it).
-      constexpr uint32_t kWordsPerThread = (1u << kHitVoxelBits) / 2u / kWalkThreads;
+      // Load pass / update pass, so the loads of the voxels a thread updates are in flight together (a load -> update ->
+      // store loop would pay the memory latency once per touched word, and nothing else runs on this CU to hide it);
+      // in two halves, which keeps the kernel's register peak below the walk loop's budget.
+      constexpr uint32_t kWordsPerThread = (1u << kHitVoxelBits) / 2u / kWalkThreads / 2u;
+      const bool even_voxels = (mc.region_voxels & 1) == 0;
+      for (uint32_t half = 0; half < 2u; ++half)
+      {
       uint32_t words[kWordsPerThread];
       float2 values[kWordsPerThread];
-      const bool even_voxels = (mc.region_voxels & 1) == 0;
 #pragma unroll
       for (uint32_t j = 0; j < kWordsPerThread; ++j)
       {
-        const uint32_t i = threadIdx.x + j * kWalkThreads;
+        const uint32_t i = threadIdx.x + (half * kWordsPerThread + j) * kWalkThreads;
         const uint32_t flagged_w = (i < count_words) ? l_counts[tileWord(i)] : 0u;
         uint32_t w = flagged_w;
         // Keep only the entries applied here: unflagged voxels with a count.
@@ -2399,7 +2465,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
       for (uint32_t j = 0; j < kWordsPerThread; ++j)
       {
-        const uint32_t i = threadIdx.x + j * kWalkThreads;
+        const uint32_t i = threadIdx.x + (half * kWordsPerThread + j) * kWalkThreads;
         const uint32_t w = words[j];
         if (w)
         {
@@ -2415,12 +2481,14 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           }
         }
       }
+      }  // halves
       if (stamp && chunk_index < kTraceChunks)
       {
         args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
       }
       __syncthreads();
-      chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
+      cur = next;
+      next = after_next;
       continue;
     }
     if (args.tsdf && (chunk.hash_index & 0x80000000u))
@@ -2476,7 +2544,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
       }
       __syncthreads();
-      chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
+      cur = next;
+      next = after_next;
       continue;
     }
     // Flush the tile: integer adds, so the merge across chunks of one region is order independent.  (NDT / TSDF:
@@ -2504,7 +2573,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     }
     // The tile is reused by the next trip: everyone must be done reading it.
     __syncthreads();
-    chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[1]);
+    cur = next;
+    next = after_next;
   }  // chunk loop
 }
 

@@ -115,6 +115,7 @@ struct ohmhip_map_s
   uint32_t event_demand = 0;
   bool spec_bucket_ok = false;  ///< the previous occupancy batch used the per-region sample sort: bin speculatively
   double segments_per_ray = 10.0;            ///< running estimate (previous batch) used to size the next batch's chunks
+  uint32_t bin_rays_per_block = kBinRaysPerBlock;  ///< tunable (OHMHIP_BIN_RAYS): rays per binning workgroup, large batches
   uint32_t min_chunk_segments = 2048;  ///< tunable (OHMHIP_MIN_CHUNK_SEGMENTS): floor of the small-batch chunk size (two rounds of the walk workgroup's 1024 lanes)
   uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= kMaxChunkSegments (15-bit LDS counters)
   /// OHMHIP_DEBUG_FLAGS (development only): 16 = walk kernel refills lanes but does not walk (timing experiments,
@@ -526,7 +527,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   const uint32_t ray_blocks = (n_rays + 255) / 256;
   // Binning launch shape: 1024 rays per 512-thread workgroup for large batches; small batches use smaller workgroups
   // with as many rays as threads so they still cover the CUs.
-  uint32_t bin_rays_per_block = kBinRaysPerBlock;
+  uint32_t bin_rays_per_block = m->bin_rays_per_block;
   uint32_t bin_threads = kBinThreads;
   while (bin_rays_per_block > 128 && n_rays / bin_rays_per_block < 2 * m->walk_workgroups)
   {
@@ -1224,6 +1225,10 @@ try
   if (const char *env = std::getenv("OHMHIP_CHUNK_SEGMENTS"))
   {
     m->chunk_segments = uint32_t(std::max(64, std::min(int(kMaxChunkSegments), std::atoi(env))));
+  }
+  if (const char *env = std::getenv("OHMHIP_BIN_RAYS"))
+  {
+    m->bin_rays_per_block = uint32_t(std::max(128, std::min(int(kBinRaysPerBlock), std::atoi(env))));
   }
   if (const char *env = std::getenv("OHMHIP_MIN_CHUNK_SEGMENTS"))
   {
