@@ -2600,14 +2600,14 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------------------------------------
 // k_apply_hits: one lane per sorted hit; the first hit of each voxel group replays the whole group in ray order.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-  k_apply_hits(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags,
-               const unsigned long long *__restrict__ sorted, uint32_t *__restrict__ interval_counts,
-               uint32_t *__restrict__ miss_counts, const double *__restrict__ rays, float *__restrict__ occupancy,
-               uint32_t *__restrict__ mean, SecondaryLayers sec, const RayWalk *__restrict__ walks)
+__device__ inline void applyHits(uint32_t i, const MapConst &mc, const RegionTable &rt, const BatchScratch &bs,
+                                 unsigned ray_flags, const unsigned long long *__restrict__ sorted,
+                                 uint32_t *__restrict__ interval_counts, uint32_t *__restrict__ miss_counts,
+                                 const double *__restrict__ rays, float *__restrict__ occupancy,
+                                 uint32_t *__restrict__ mean, const SecondaryLayers &sec,
+                                 const RayWalk *__restrict__ walks)
 {
   const uint32_t n_hits = bs.info->n_hits;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_hits)
   {
     return;
@@ -2702,15 +2702,28 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+__global__ void __launch_bounds__(256)
+  k_apply_hits(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags,
+               const unsigned long long *__restrict__ sorted, uint32_t *__restrict__ interval_counts,
+               uint32_t *__restrict__ miss_counts, const double *__restrict__ rays, float *__restrict__ occupancy,
+               uint32_t *__restrict__ mean, SecondaryLayers sec, const RayWalk *__restrict__ walks)
+{
+  applyHits(blockIdx.x * blockDim.x + threadIdx.x, mc, rt, bs, ray_flags, sorted, interval_counts, miss_counts, rays,
+            occupancy, mean, sec, walks);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_apply_counts: one block per touched region: apply plain miss counts, clear scratch.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-  k_apply_counts(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags, uint32_t *__restrict__ miss_counts,
-                 uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy, int clear_mask,
-                 uint32_t *__restrict__ hit_miss_counts, uint32_t direct_chunk_segments, int skip_masked)
+/// `skip_masked`: voxels whose mask bit is set are somebody else's (NDT: the ordered replay; occupancy, when this runs
+/// beside applyHits in one launch: applyHits) -- their counts are neither applied nor touched.
+__device__ inline void applyCounts(uint32_t region_index, const MapConst &mc, const RegionTable &rt,
+                                   const BatchScratch &bs, unsigned ray_flags, uint32_t *__restrict__ miss_counts,
+                                   uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy, int clear_mask,
+                                   uint32_t *__restrict__ hit_miss_counts, uint32_t direct_chunk_segments,
+                                   int skip_masked, int preserve_masked)
 {
-  const uint32_t h = bs.touched[blockIdx.x];
+  const uint32_t h = bs.touched[region_index];
   const uint32_t slot = rt.vals[h];
   const size_t base = size_t(slot) * size_t(mc.region_voxels);
   // Regions with a single chunk were applied by the walk kernel itself (direct_chunk_segments != 0).
@@ -2728,10 +2741,11 @@ __global__ void __launch_bounds__(1024)
       uint4 n = counts4[q];
       if (n.x | n.y | n.z | n.w)
       {
+        uint32_t bits = 0;
         if (skip_masked)
         {
           // NDT: voxels holding samples are updated by the ordered replay only; their tile entry is not used.
-          const uint32_t bits = mask[(4 * q) >> 5] >> ((4 * q) & 31);
+          bits = (mask[(4 * q) >> 5] >> ((4 * q) & 31)) & 15u;
           n.x = (bits & 1u) ? 0u : n.x;
           n.y = (bits & 2u) ? 0u : n.y;
           n.z = (bits & 4u) ? 0u : n.z;
@@ -2742,8 +2756,22 @@ __global__ void __launch_bounds__(1024)
         o.y = n.y ? occMissN(mc, ray_flags, o.y, n.y) : o.y;
         o.z = n.z ? occMissN(mc, ray_flags, o.z, n.z) : o.z;
         o.w = n.w ? occMissN(mc, ray_flags, o.w, n.w) : o.w;
-        occ4[q] = o;
-        counts4[q] = make_uint4(0, 0, 0, 0);
+        if (preserve_masked && bits)
+        {
+          // A masked voxel's log-odds and count belong to applyHits, which may be at work on them right now: only the
+          // other voxels of the group are written.
+          float *o1 = occupancy + base + 4 * q;
+          uint32_t *c1 = miss_counts + base + 4 * q;
+          if (!(bits & 1u)) { o1[0] = o.x; c1[0] = 0; }
+          if (!(bits & 2u)) { o1[1] = o.y; c1[1] = 0; }
+          if (!(bits & 4u)) { o1[2] = o.z; c1[2] = 0; }
+          if (!(bits & 8u)) { o1[3] = o.w; c1[3] = 0; }
+        }
+        else
+        {
+          occ4[q] = o;
+          counts4[q] = make_uint4(0, 0, 0, 0);
+        }
         if (hit_miss_counts)
         {
           // NDT-TM: every plain miss increments HitMissCount::miss_count (ohm/RayMapperNdt.cpp:171-178).
@@ -2759,7 +2787,10 @@ __global__ void __launch_bounds__(1024)
       uint32_t n = miss_counts[base + vi];
       if (n && skip_masked && ((mask[vi >> 5] >> (vi & 31)) & 1u))
       {
-        miss_counts[base + vi] = 0;
+        if (!preserve_masked)
+        {
+          miss_counts[base + vi] = 0;
+        }
         n = 0;
       }
       if (n)
@@ -2775,6 +2806,7 @@ __global__ void __launch_bounds__(1024)
   }
   if (clear_mask)
   {
+    __syncthreads();  // (the loops above read the mask)
     const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
     for (uint32_t i = threadIdx.x; i < mask_words; i += blockDim.x)
     {
@@ -2787,6 +2819,15 @@ __global__ void __launch_bounds__(1024)
     bs.seg_cursor[h] = 0;
     bs.touched_flag[h] = 0;
   }
+}
+
+__global__ void __launch_bounds__(1024)
+  k_apply_counts(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags, uint32_t *__restrict__ miss_counts,
+                 uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy, int clear_mask,
+                 uint32_t *__restrict__ hit_miss_counts, uint32_t direct_chunk_segments, int skip_masked)
+{
+  applyCounts(blockIdx.x, mc, rt, bs, ray_flags, miss_counts, hit_mask, occupancy, clear_mask, hit_miss_counts,
+              direct_chunk_segments, skip_masked, 0);
 }
 
 /// Fill a float layer with a value (pool initialisation: occupancy clears to +inf, ohm/DefaultLayer.cpp:87-91).
