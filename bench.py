@@ -168,13 +168,16 @@ def main():
                       "sort_apply": float(np.mean([t["ms_apply"] for t in timings])), "total": float(np.mean(total_ms))},
     }
     if world == 1 and not args.no_extra:
-        # Secondary figures (not the headline `value`): C2 GpuNdtMap and C3 GpuTsdfMap (first revolution), same harness.
+        # Secondary figures (not the headline `value`): C2 GpuNdtMap (1 M rays) and C3 GpuTsdfMap (its full 4 M rays in one
+        # call), same harness, each with its own roofline block.  Algorithmic bytes per SURVEY.md 8d:
+        #   NDT : 40 B per miss visit (4 + 4 occupancy, 8 mean, 24 covariance) + 72 B per sample + 44 B per ray
+        #   TSDF: 16 B per voxel visit (8 read + 8 write) + 68 B per ray
         extra = {}
-        for name, cls, res, gen, layers in (("C2_ndt_1M_rays_0.2m", ohm_amd.GpuNdtMap, 0.2, synth.rays_c2, ("occupancy",)),
-                                            ("C3_tsdf_1M_rays_0.05m", ohm_amd.GpuTsdfMap, 0.05, synth.rays_c2, ("tsdf",))):
-            r2 = gen(n=n_rays)
+        for name, cls, res, r2, layers, steps2 in (
+                ("C2_ndt_1M_rays_0.2m", ohm_amd.GpuNdtMap, 0.2, synth.rays_c2(n=n_rays), ("occupancy",), 3),
+                ("C3_tsdf_4M_rays_0.05m", ohm_amd.GpuTsdfMap, 0.05, synth.rays_c3(n=4 * n_rays), ("tsdf",), 2)):
             m2 = ohm_amd.OccupancyMap(res, (32, 32, 32), layers=layers)
-            g2 = cls(m2, gpu_mem_size=16 << 30)
+            g2 = cls(m2, gpu_mem_size=24 << 30)
             b2 = L._vp()
             L.check(L.lib.ohmhip_buffer_create(C.byref(b2), r2.nbytes, 3), "buffer_create")
             L.check(L.lib.ohmhip_buffer_write(b2, r2.ctypes.data, r2.nbytes, 0, None, None, None), "buffer_write")
@@ -183,15 +186,32 @@ def main():
             g2.integrateRaysDevice(p2, r2.shape[0])
             g2.wait()
             t1 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(steps2):
                 g2.integrateRaysDevice(p2, r2.shape[0])
             g2.wait()
-            dt = (time.perf_counter() - t1) / 3
+            dt = (time.perf_counter() - t1) / steps2
             st2 = g2.stats()
-            extra[name] = {"rays_per_s": n_rays / dt, "ms_per_step": dt * 1e3, "voxel_visits": int(st2["voxel_visits"]),
-                           "walk_ms": float(st2["ms_walk"])}
+            tm2 = [g2.batchTimings(back) for back in range(steps2)]
+            n2 = int(st2["rays_integrated"])
+            v2 = int(st2["voxel_visits"])
+            if cls is ohm_amd.GpuNdtMap:
+                b_alg2 = 40.0 * (v2 - n2) + 72.0 * n2 + 44.0 * n2
+            else:
+                b_alg2 = 16.0 * v2 + 68.0 * n2
+            dev2 = float(np.mean([t["ms_total"] for t in tm2])) * 1e-3
+            walk2 = float(np.mean([t["ms_walk"] for t in tm2])) * 1e-3
+            extra[name] = {"rays_per_s": (r2.shape[0] // 2) / dt, "ms_per_step": dt * 1e3, "rays": r2.shape[0] // 2,
+                           "voxel_visits": v2, "regions": int(st2["regions_resident"]),
+                           "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": b_alg2, "peak": HBM_PEAK_GBPS,
+                                        "unit": "GB/s", "pipeline_ms": dev2 * 1e3,
+                                        "achieved": b_alg2 / dev2 / 1e9, "frac": b_alg2 / dev2 / 1e9 / HBM_PEAK_GBPS,
+                                        "walk_kernel_ms": walk2 * 1e3,
+                                        "walk_kernel_frac": b_alg2 / walk2 / 1e9 / HBM_PEAK_GBPS,
+                                        "note": "frac is over the whole device pipeline of a batch (walk + event sort + "
+                                                "ordered replay); the walk kernel alone is walk_kernel_frac"}}
             L.lib.ohmhip_buffer_destroy(b2)
             g2.close()
+            del r2
         # C1 variants SURVEY 8d asks to be reported next to the headline (never the headline `value`):
         # (i) the same batch fed as 4096-ray calls (the reference tools' default batch size): launch-latency bound;
         # (ii) end to end from HOST memory: pinned staging + H2D + integrate + syncVoxels into the host MapChunk blocks.

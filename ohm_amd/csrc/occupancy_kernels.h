@@ -1025,6 +1025,10 @@ __global__ void __launch_bounds__(kBinThreads)
             uint32_t tab_mask)
 {
   __shared__ LdsRegionTable tab;
+  if (bs.info->error & (kErrHashFull | kErrSlotsFull))
+  {
+    return;  // the batch's set-up overflowed the pool: the host grows it and repeats the batch
+  }
   for (uint32_t i = threadIdx.x; i <= tab_mask; i += blockDim.x)
   {
     tab.keys[i] = 0;
@@ -1075,8 +1079,10 @@ __global__ void __launch_bounds__(kBinThreads)
       if (e < kLtabSize)
       {
         // The table does not carry the slot; it is in the reserved position's region range, but the key needs it.
+        // (A speculatively launched pass may run on a batch whose region inserts failed -- hash table full -- and then
+        // does not find the key: the host repeats the batch after growing the pool, nothing may be written here.)
         const uint32_t h = regionFind(rt, key);
-        slot = rt.vals[h];
+        slot = (h != 0xffffffffu) ? rt.vals[h] : kSlotUnassigned;
         pos = atomicAdd(&tab.count[e], 1u);
       }
       else
@@ -1124,6 +1130,10 @@ __global__ void __launch_bounds__(kBinThreads)
       else
       {
         const uint32_t h = regionFind(rt, key);  // table overflow: straight to the global cursor
+        if (h == 0xffffffffu)
+        {
+          return;  // (failed insert of a speculated batch, see above)
+        }
         pos = bs.seg_offset[h] + atomicAdd(&bs.seg_cursor[h], 1u);
       }
       if (pos < segment_capacity)
@@ -1722,6 +1732,9 @@ struct WalkArgs
   float *tsdf;       ///< non-null (TSDF mode): single-chunk regions are applied straight from LDS
   uint32_t *chunk_cursor;  ///< device-wide next-chunk cursor (zeroed before the launch)
   uint32_t n_chunks;
+  /// NDT / TSDF: this launch repeats a walk whose event list overflowed.  Regions held by a single chunk had their plain
+  /// counts applied to the layers by the first launch already: the repeat only regenerates their events.
+  int rewalk;
 };
 
 constexpr uint32_t kWalkCursorWords = 24;  ///< l_cursor[]: see k_region_walk
@@ -2411,6 +2424,13 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       }
     }
     uint32_t *g_counts = args.miss_counts + size_t(chunk.slot) * size_t(mc.region_voxels);
+    if (args.rewalk && (chunk.hash_index & 0x80000000u))
+    {
+      __syncthreads();
+      cur = next;
+      next = after_next;
+      continue;
+    }
     if (args.occupancy && (chunk.hash_index & 0x80000000u))
     {
       // This chunk holds ALL of the region's segments for the batch: apply the miss counts to the log-odds layer

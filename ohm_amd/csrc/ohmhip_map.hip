@@ -113,6 +113,7 @@ struct ohmhip_map_s
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
   uint32_t event_demand = 0;
+  uint32_t event_limit = 0;  ///< OHMHIP_EVENT_LIMIT (tests): cap of the NDT / TSDF event list's first sizing
   bool spec_bucket_ok = false;  ///< the previous occupancy batch used the per-region sample sort: bin speculatively
   double segments_per_ray = 10.0;            ///< running estimate (previous batch) used to size the next batch's chunks
   uint32_t bin_rays_per_block = kBinRaysPerBlock;  ///< tunable (OHMHIP_BIN_RAYS): rays per binning workgroup, large batches
@@ -263,123 +264,144 @@ void freePool(ohmhip_map_t m)
   m->d_hit_count = m->d_sort_list = nullptr;
 }
 
-/// (Re)allocate the region pool for `capacity` regions, preserving the first `keep` slots' contents.
+/// (Re)allocate the region pool for `capacity` regions, preserving the first `keep` slots' contents.  Everything new is
+/// allocated before anything old is released: a failed allocation leaves the map exactly as it was.
 int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
 {
   const size_t rv = size_t(m->mc.region_voxels);
   const uint32_t hash_cap = nextPow2(std::max<uint32_t>(1024u, capacity * 2u));
   hipStream_t s = m->stream;
 
+  std::vector<void *> fresh;  // released again if any step fails
+  auto alloc = [&](void **p, size_t bytes) -> int {
+    *p = nullptr;
+    const int err = int(hipMalloc(p, std::max<size_t>(bytes, 4)));
+    if (err == 0)
+    {
+      fresh.push_back(*p);
+    }
+    return err;
+  };
+  auto zalloc = [&](void **p, size_t bytes) -> int {
+    OHMHIP_CHECK(alloc(p, bytes));
+    OHMHIP_CHECK(hipMemsetAsync(*p, 0, std::max<size_t>(bytes, 4), s));
+    return OHMHIP_OK;
+  };
   void *new_layers[OHMHIP_LID_COUNT] = {};
-  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
-  {
-    if (!(m->config.layers & (1u << l)))
-    {
-      continue;
-    }
-    const size_t stride = rv * kLayerBytes[l];
-    OHMHIP_CHECK(hipMalloc(&new_layers[l], stride * capacity));
-    if (keep && m->layers[l])
-    {
-      OHMHIP_CHECK(hipMemcpyAsync(new_layers[l], m->layers[l], stride * keep, hipMemcpyDeviceToDevice, s));
-    }
-    char *tail = static_cast<char *>(new_layers[l]) + stride * keep;
-    const size_t tail_bytes = stride * (capacity - keep);
-    if (l == OHMHIP_LID_OCCUPANCY)
-    {
-      // Occupancy clears to +inf == unobserved (ohm/DefaultLayer.cpp:87-91, ohm/VoxelOccupancy.h:42-45).
-      const size_t count = tail_bytes / 4;
-      if (count)
-      {
-        hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint32_t *>(tail), 0x7f800000u,
-                           count);
-      }
-    }
-    else if (tail_bytes)
-    {
-      OHMHIP_CHECK(hipMemsetAsync(tail, 0, tail_bytes, s));
-    }
-  }
-
   uint64_t *new_slot_keys = nullptr;
-  OHMHIP_CHECK(hipMalloc(&new_slot_keys, sizeof(uint64_t) * capacity));
-  OHMHIP_CHECK(hipMemsetAsync(new_slot_keys, 0, sizeof(uint64_t) * capacity, s));
-  if (keep && m->d_slot_keys)
-  {
-    OHMHIP_CHECK(hipMemcpyAsync(new_slot_keys, m->d_slot_keys, sizeof(uint64_t) * keep, hipMemcpyDeviceToDevice, s));
-  }
+  uint32_t *new_mask = nullptr, *new_dirty = nullptr;
+  unsigned long long *n_keys = nullptr;
+  uint32_t *n_vals = nullptr, *n_seg_count = nullptr, *n_seg_cursor = nullptr, *n_hit_count = nullptr,
+           *n_sort_list = nullptr, *n_seg_offset = nullptr, *n_touched_flag = nullptr, *n_touched = nullptr,
+           *n_first_hit = nullptr, *n_hit_begin = nullptr, *n_hit_end = nullptr, *n_miss_counts = nullptr;
+  Chunk *n_chunks = nullptr;
+  const uint32_t chunk_capacity = capacity + (1u << 16);
   // The per-voxel mask is persistent state for NDT / TSDF (voxels that take the ordered replay path): it moves with
   // the regions it describes.
   const size_t mask_row = ((rv + 31) / 32) * sizeof(uint32_t);
-  uint32_t *new_mask = nullptr;
-  OHMHIP_CHECK(hipMalloc(&new_mask, mask_row * capacity));
-  OHMHIP_CHECK(hipMemsetAsync(new_mask, 0, mask_row * capacity, s));
-  if (keep && m->d_hit_mask)
-  {
-    OHMHIP_CHECK(hipMemcpyAsync(new_mask, m->d_hit_mask, mask_row * keep, hipMemcpyDeviceToDevice, s));
-  }
-  uint32_t *new_dirty = nullptr;
-  OHMHIP_CHECK(hipMalloc(&new_dirty, sizeof(uint32_t) * capacity));
-  OHMHIP_CHECK(hipMemsetAsync(new_dirty, 0, sizeof(uint32_t) * capacity, s));
-  if (keep && m->d_dirty)
-  {
-    OHMHIP_CHECK(hipMemcpyAsync(new_dirty, m->d_dirty, sizeof(uint32_t) * keep, hipMemcpyDeviceToDevice, s));
-  }
-  OHMHIP_CHECK(hipStreamSynchronize(s));
-
-  // Swap in: free everything old except what we carried over.
-  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
-  {
-    if (m->layers[l])
+  auto build = [&]() -> int {
+    for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
     {
-      (void)hipFree(m->layers[l]);
+      if (!(m->config.layers & (1u << l)))
+      {
+        continue;
+      }
+      const size_t stride = rv * kLayerBytes[l];
+      OHMHIP_CHECK(alloc(&new_layers[l], stride * capacity));
+      if (keep && m->layers[l])
+      {
+        OHMHIP_CHECK(hipMemcpyAsync(new_layers[l], m->layers[l], stride * keep, hipMemcpyDeviceToDevice, s));
+      }
+      char *tail = static_cast<char *>(new_layers[l]) + stride * keep;
+      const size_t tail_bytes = stride * (capacity - keep);
+      if (l == OHMHIP_LID_OCCUPANCY)
+      {
+        // Occupancy clears to +inf == unobserved (ohm/DefaultLayer.cpp:87-91, ohm/VoxelOccupancy.h:42-45).
+        const size_t count = tail_bytes / 4;
+        if (count)
+        {
+          hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint32_t *>(tail), 0x7f800000u,
+                             count);
+        }
+      }
+      else if (tail_bytes)
+      {
+        OHMHIP_CHECK(hipMemsetAsync(tail, 0, tail_bytes, s));
+      }
     }
-    m->layers[l] = new_layers[l];
-  }
-  void *old[] = { m->d_keys,       m->d_vals,         m->d_slot_keys, m->d_seg_count, m->d_seg_cursor,
-                  m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_voxel_first_hit, m->d_hit_begin, m->d_hit_end,
-                  m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks,    m->d_hit_count, m->d_sort_list };
-  for (void *p : old)
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&new_slot_keys), sizeof(uint64_t) * capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&new_mask), mask_row * capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&new_dirty), sizeof(uint32_t) * capacity));
+    if (keep && m->d_slot_keys)
+    {
+      OHMHIP_CHECK(hipMemcpyAsync(new_slot_keys, m->d_slot_keys, sizeof(uint64_t) * keep, hipMemcpyDeviceToDevice, s));
+    }
+    if (keep && m->d_hit_mask)
+    {
+      OHMHIP_CHECK(hipMemcpyAsync(new_mask, m->d_hit_mask, mask_row * keep, hipMemcpyDeviceToDevice, s));
+    }
+    if (keep && m->d_dirty)
+    {
+      OHMHIP_CHECK(hipMemcpyAsync(new_dirty, m->d_dirty, sizeof(uint32_t) * keep, hipMemcpyDeviceToDevice, s));
+    }
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_keys), sizeof(unsigned long long) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_vals), sizeof(uint32_t) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_count), sizeof(uint32_t) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_cursor), sizeof(uint32_t) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_count), sizeof(uint32_t) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_sort_list), sizeof(uint32_t) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_offset), sizeof(uint32_t) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_touched_flag), sizeof(uint32_t) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_touched), sizeof(uint32_t) * hash_cap));
+    if (m->config.mode == OHMHIP_MODE_OCCUPANCY)
+    {
+      OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_first_hit), sizeof(uint32_t) * rv * capacity));
+    }
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_begin), sizeof(uint32_t) * capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_end), sizeof(uint32_t) * capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_miss_counts), sizeof(uint32_t) * rv * capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_chunks), sizeof(Chunk) * chunk_capacity));
+    OHMHIP_CHECK(hipStreamSynchronize(s));
+    return OHMHIP_OK;
+  };
+  const int build_err = build();
+  if (build_err)
   {
-    if (p)
+    (void)hipStreamSynchronize(s);
+    for (void *p : fresh)
     {
       (void)hipFree(p);
     }
+    (void)hipGetLastError();
+    return (build_err == int(hipErrorOutOfMemory)) ? int(OHMHIP_ERR_CAPACITY) : build_err;
+  }
+
+  // Swap in.
+  freePool(m);
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    m->layers[l] = new_layers[l];
   }
   m->d_slot_keys = new_slot_keys;
+  m->d_hit_mask = new_mask;
   m->d_dirty = new_dirty;
+  m->d_keys = n_keys;
+  m->d_vals = n_vals;
+  m->d_seg_count = n_seg_count;
+  m->d_seg_cursor = n_seg_cursor;
+  m->d_hit_count = n_hit_count;
+  m->d_sort_list = n_sort_list;
+  m->d_seg_offset = n_seg_offset;
+  m->d_touched_flag = n_touched_flag;
+  m->d_touched = n_touched;
+  m->d_voxel_first_hit = n_first_hit;
+  m->d_hit_begin = n_hit_begin;
+  m->d_hit_end = n_hit_end;
+  m->d_miss_counts = n_miss_counts;
+  m->d_chunks = n_chunks;
+  m->chunk_capacity = chunk_capacity;
   m->slot_capacity = capacity;
   m->hash_capacity = hash_cap;
-
-  auto zalloc = [&](void **p, size_t bytes) -> int {
-    OHMHIP_CHECK(hipMalloc(p, bytes));
-    OHMHIP_CHECK(hipMemsetAsync(*p, 0, bytes, s));
-    return OHMHIP_OK;
-  };
-  int err = OHMHIP_OK;
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_keys), sizeof(unsigned long long) * hash_cap);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_vals), sizeof(uint32_t) * hash_cap);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_count), sizeof(uint32_t) * hash_cap);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_cursor), sizeof(uint32_t) * hash_cap);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_count), sizeof(uint32_t) * hash_cap);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_sort_list), sizeof(uint32_t) * hash_cap);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_seg_offset), sizeof(uint32_t) * hash_cap);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_touched_flag), sizeof(uint32_t) * hash_cap);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_touched), sizeof(uint32_t) * hash_cap);
-  if (m->config.mode == OHMHIP_MODE_OCCUPANCY)
-  {
-    err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_voxel_first_hit), sizeof(uint32_t) * rv * capacity);
-  }
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_begin), sizeof(uint32_t) * capacity);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_hit_end), sizeof(uint32_t) * capacity);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_miss_counts), sizeof(uint32_t) * rv * capacity);
-  m->d_hit_mask = new_mask;
-  m->chunk_capacity = capacity + (1u << 16);
-  err = err ? err : zalloc(reinterpret_cast<void **>(&m->d_chunks), sizeof(Chunk) * m->chunk_capacity);
-  if (err)
-  {
-    return err;
-  }
   OHMHIP_CHECK(hipMemcpyAsync(m->d_n_slots, &keep, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   if (keep)
   {
@@ -390,13 +412,44 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   return OHMHIP_OK;
 }
 
-/// Restore the region table after a batch that overflowed the pool: drop regions the failed batch inserted.
-int rollbackAndGrow(ohmhip_map_t m, uint32_t needed)
+/// Largest region pool the 20-bit slot field of the sample / event sort keys can address.
+constexpr uint32_t kMaxRegionSlots = (1u << 20) - 2u;
+
+/// Pool capacity for `needed` regions: doubling, clamped to what the sort keys can address.  False when `needed` itself
+/// is beyond that (the caller reports OHMHIP_ERR_CAPACITY: a larger slot would be truncated in the keys and alias
+/// another region).
+bool grownCapacity(uint32_t current, uint32_t needed, uint32_t &capacity)
 {
-  uint32_t cap = m->slot_capacity;
+  if (needed > kMaxRegionSlots)
+  {
+    return false;
+  }
+  uint64_t cap = std::max<uint32_t>(current, 1u);
   while (cap < needed)
   {
     cap *= 2;
+  }
+  capacity = uint32_t(std::min<uint64_t>(cap, kMaxRegionSlots));
+  return true;
+}
+
+/// Forget the regions a failed write_regions / ensure_regions call added to the host table.
+void dropHostRegions(ohmhip_map_t m, size_t keep)
+{
+  for (size_t i = keep; i < m->slot_keys_host.size(); ++i)
+  {
+    m->region_slots.erase(m->slot_keys_host[i]);
+  }
+  m->slot_keys_host.resize(keep);
+}
+
+/// Restore the region table after a batch that overflowed the pool: drop regions the failed batch inserted.
+int rollbackAndGrow(ohmhip_map_t m, uint32_t needed)
+{
+  uint32_t cap = 0;
+  if (!grownCapacity(m->slot_capacity, needed, cap))
+  {
+    return OHMHIP_ERR_CAPACITY;
   }
   // Check memory budget: refuse if the new pool cannot fit in free device memory.
   size_t free_b = 0, total_b = 0;
@@ -629,7 +682,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       // Pool exhausted: forget what this batch inserted, grow, retry.
       OHMHIP_CHECK(hipStreamSynchronize(s));
       m->spec_bucket_ok = false;
-      const int err = rollbackAndGrow(m, std::max(info.n_slots, m->slot_capacity * 2u));
+      const int err = rollbackAndGrow(m, std::max(info.n_slots, std::min(m->slot_capacity * 2u, kMaxRegionSlots)));
       if (err)
       {
         return err;
@@ -658,6 +711,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     uint64_t want_events =
       std::max<uint64_t>({ uint64_t(1) << 20, info.visits / 4, uint64_t(m->event_demand) * 5 / 4 });
     want_events = std::min<uint64_t>(want_events, 0xfffffff0ull - n_rays);
+    if (m->event_limit)
+    {
+      want_events = std::min<uint64_t>(want_events, m->event_limit);  // (test knob: forces the overflow path)
+    }
     unsigned long long *keys_a = nullptr;
     unsigned long long *keys_b = nullptr;
     unsigned long long *events = nullptr;
@@ -681,6 +738,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       const size_t cap_a = m->hit_keys_a.bytes / sizeof(unsigned long long) - n_rays;
       const size_t cap_b = m->hit_keys_b.bytes / sizeof(unsigned long long) - n_rays;
       event_capacity = uint32_t(std::min<size_t>(std::min(cap_a, cap_b), 0xfffffff0u - n_rays));
+      if (m->event_limit)
+      {
+        event_capacity = std::min(event_capacity, m->event_limit);
+      }
     }
 
     // Occupancy: sample keys are bucketed per region and ordered by one workgroup per region in LDS, unless some
@@ -757,15 +818,20 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.traversal = sec.traversal;
         wa.chunk_cursor = m->d_event_count + 1;
         wa.n_chunks = info.n_chunks;
+        // A repeated walk (NDT / TSDF event list overflow) must not apply anything twice: single-chunk regions were
+        // applied straight from LDS by the first launch (the repeat only regenerates their events) and the traversal
+        // layer has its sums already.
+        wa.rewalk = (walk_attempt > 0 && (direct_occ || tsdf_mode)) ? 1 : 0;
+        const bool walk_traversal = sec.traversal != nullptr && walk_attempt == 0;
         // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited) or the
         // traversal layer needs the exit range of an end voxel that is part of the walk.  (An end voxel that is walked --
         // kRfEndPointAsFree, clipped rays, TSDF -- is simply one more voxel of the ray's last segment.)
         const bool end_walked = (ray_flags & OHMHIP_RF_END_POINT_AS_FREE) || m->mc.filter_mode == OHMHIP_FILTER_CLIP ||
                                 m->mc.batch_filter_flags != nullptr;
-        const bool special = (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) || (sec.traversal && end_walked);
+        const bool special = (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) || (walk_traversal && end_walked);
         const dim3 wgrid(std::min<uint32_t>(info.n_chunks, m->walk_workgroups)), wblock(kWalkThreads);
         const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments);
-        if (special && sec.traversal)
+        if (special && walk_traversal)
         {
           hipLaunchKernelGGL((k_region_walk<true, true, false>), wgrid, wblock, wlds, s, wa);
         }
@@ -773,7 +839,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         {
           hipLaunchKernelGGL((k_region_walk<true, false, false>), wgrid, wblock, wlds, s, wa);
         }
-        else if (sec.traversal)
+        else if (walk_traversal)
         {
           hipLaunchKernelGGL((k_region_walk<false, true, false>), wgrid, wblock, wlds, s, wa);
         }
@@ -1211,7 +1277,7 @@ try
     const uint64_t budget = m->config.gpu_mem_size ? m->config.gpu_mem_size : (uint64_t(4) << 30);
     capacity = uint32_t(std::max<uint64_t>(64, budget / bytesPerRegionAllLayers(m->config, mc.region_voxels)));
   }
-  capacity = std::min<uint32_t>(capacity, (1u << 20) - 2);  // 20-bit slot field of the hit key
+  capacity = std::min<uint32_t>(capacity, kMaxRegionSlots);  // 20-bit slot field of the hit key
   if ((err = allocPool(m, capacity, 0)) != 0)
   {
     return fail(err);
@@ -1227,6 +1293,10 @@ try
   if (const char *env = std::getenv("OHMHIP_CHUNK_SEGMENTS"))
   {
     m->chunk_segments = uint32_t(std::max(64, std::min(int(kMaxChunkSegments), std::atoi(env))));
+  }
+  if (const char *env = std::getenv("OHMHIP_EVENT_LIMIT"))
+  {
+    m->event_limit = uint32_t(std::max(0, std::atoi(env)));
   }
   if (const char *env = std::getenv("OHMHIP_BIN_RAYS"))
   {
@@ -2043,14 +2113,11 @@ try
     const uint32_t old = m->slots_committed;
     if (total > m->slot_capacity)
     {
-      uint32_t cap = m->slot_capacity;
-      while (cap < total)
-      {
-        cap *= 2;
-      }
-      err = allocPool(m, cap, old);
+      uint32_t cap = 0;
+      err = grownCapacity(m->slot_capacity, total, cap) ? allocPool(m, cap, old) : OHMHIP_ERR_CAPACITY;
       if (err)
       {
+        dropHostRegions(m, old);  // the device never saw them
         return err;
       }
     }
@@ -2136,14 +2203,11 @@ try
   {
     if (total > m->slot_capacity)
     {
-      uint32_t cap = m->slot_capacity;
-      while (cap < total)
-      {
-        cap *= 2;
-      }
-      err = allocPool(m, cap, old);
+      uint32_t cap = 0;
+      err = grownCapacity(m->slot_capacity, total, cap) ? allocPool(m, cap, old) : OHMHIP_ERR_CAPACITY;
       if (err)
       {
+        dropHostRegions(m, old);  // the device never saw them
         return err;
       }
     }

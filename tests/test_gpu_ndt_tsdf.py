@@ -227,3 +227,15 @@ def test_ndt_and_tsdf_survive_pool_growth(gpu):
     gt.syncVoxels()
     assert_parity(compare_maps(on.chunks(), map_n.chunks, list(map_n.layers), rel=1e-5))
     assert_parity(compare_maps(ot.chunks(), map_t.chunks, ["tsdf"], exact_float=True))
+
+
+def test_event_list_overflow_rewalk_applies_nothing_twice(gpu, monkeypatch):
+    # OHMHIP_EVENT_LIMIT (read at map creation) caps the first sizing of the NDT / TSDF event list, so every batch
+    # overflows it and the walk is repeated with a list of the right size.  Single-chunk regions are applied straight
+    # from LDS by the first launch: the repeat must neither apply their counts again nor leave them behind.
+    monkeypatch.setenv("OHMHIP_EVENT_LIMIT", "64")
+    rays = np.concatenate([synth.rays_c2(n=12000, seed=500 + k) for k in range(3)])
+    stats, gm, om = run_ndt(rays, batch=12000)
+    assert_parity(stats)
+    stats, gm, om = run_tsdf(rays[:24000], batch=6000)
+    assert_parity(stats)
