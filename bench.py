@@ -251,15 +251,17 @@ def main():
                                        "integrate_ms": (t2 - t1) * 1e3, "sync_voxels_ms": (t3 - t2) * 1e3,
                                        "note": "host-pointer rays (48 B/ray over PCIe) + all modified regions copied back"}
         g4.close()
-        # the reference tools' pattern: 4096-ray host batches, as presented and with batch coalescing
+        # the reference tools' pattern: 4096-ray host batches -- as presented (the library's defaults: small host batches
+        # are collected into device batches of 64k rays) and with every call launching its own device batch
         host_small = {}
-        for label, min_rays in (("as_presented", 0), ("coalesced_64k", 1 << 16)):
+        for label, min_rays in (("as_presented", None), ("one_device_batch_per_call", 0)):
             m6 = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
             g6 = ohm_amd.GpuMap(m6, gpu_mem_size=8 << 30)
             g6.integrateRays(rays)
             g6.integrateRays(rays)
             g6.wait()
-            g6.setBatchCoalescing(min_rays)
+            if min_rays is not None:
+                g6.setBatchCoalescing(min_rays)
             n_calls = 128
             t1 = time.perf_counter()
             for b in range(n_calls):

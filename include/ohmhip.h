@@ -212,14 +212,15 @@ int ohmhip_map_integrate_rays(ohmhip_map_t map, const double *rays, size_t eleme
 int ohmhip_map_integrate_rays_filtered(ohmhip_map_t map, const double *rays, size_t element_count,
                                        const float *intensities, const double *timestamps, unsigned ray_flags,
                                        const unsigned char *filter_flags, size_t *integrated);
-/* Small host batches (the reference tools present 4096 rays per call, ohmapp/OhmAppGpu.cpp:187-207) cost a full
- * pipeline pass each.  With min_rays > 0, consecutive host-pointer batches with the same flags and the same optional
- * arrays are collected in the pinned staging block and run as ONE device batch once min_rays have accumulated -- or as
- * soon as anything observes the map (sync, stats, region reads, a device-pointer batch ...).  The result is the one
- * the separate calls give: the CPU mappers integrate ray by ray, so call boundaries carry no meaning, except for the
- * traversal layer (its exit range is carried within a call): maps with that layer never merge batches.  A deferred
- * call reports *integrated = element_count; what the ray filter rejected shows in ohmhip_map_last_stats once the batch
- * has run.  0 (the default) launches every call's batch in that call. */
+/* Small host batches (the reference tools present 4096 rays per call, ohmapp/OhmAppGpu.cpp:187-207) would cost a full
+ * pipeline pass each.  Consecutive host-pointer batches with the same flags and the same optional arrays are therefore
+ * collected in the pinned staging block and run as ONE device batch once min_rays have accumulated -- or as soon as
+ * anything observes the map (sync, stats, region reads, a device-pointer batch ...).  The result is the one the
+ * separate calls give: the CPU mappers integrate ray by ray, so call boundaries carry no meaning, except for the
+ * traversal layer (its exit range is carried within a call): maps with that layer never merge batches.  Every call
+ * still reports its own *integrated: the ray filter's verdict is evaluated on the host while the rays are staged, with
+ * the arithmetic the device uses.  An error of a deferred batch (pool exhausted ...) surfaces at the call that launches
+ * it.  Default min_rays: 65536; 0 launches every call's batch in that call. */
 int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
 /* Same with rays (and optional intensities/timestamps) already resident in device memory. */
 int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, size_t element_count,

@@ -654,11 +654,11 @@ __global__ void __launch_bounds__(kBinThreads)
       rw.flags &= ownsRegion(mc, sample_key) ? ~0u : ~unsigned(kRwApplySample);
     }
     walks[ray] = rw;
+    my_ok += (rw.flags & kRwPassed) ? 1u : 0u;
     if (!(rw.flags & kRwValid))
     {
       continue;
     }
-    ++my_ok;
     // Visit accounting: Manhattan extent == number of voxels the walk reports before the end voxel.
     const int manhattan = rw.total[0] + rw.total[1] + rw.total[2];
     if (rw.flags & kRwWalk)

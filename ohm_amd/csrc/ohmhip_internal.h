@@ -113,7 +113,8 @@ enum : unsigned
   kRwIncludeEnd = 1u << 4,    ///< end voxel is visited as part of the ray (clipped end / kRfEndPointAsFree)
   kRwApplySample = 1u << 5,   ///< sample voxel receives the hit update
   kRwExcludeStart = 1u << 6,  ///< kRfExcludeOrigin
-  kRwWalk = 1u << 7           ///< ray part is walked (not kRfExcludeRay)
+  kRwWalk = 1u << 7,          ///< ray part is walked (not kRfExcludeRay)
+  kRwPassed = 1u << 8         ///< the ray passed the ray filter (counted as integrated, like the reference's upload count)
 };
 
 /// One (ray, region) unit of line-walk work: "visit `count` voxels of ray `ray` starting at voxel `vi` of the region".

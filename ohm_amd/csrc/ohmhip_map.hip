@@ -144,7 +144,9 @@ struct ohmhip_map_s
   size_t pending_calls = 0;
   unsigned pending_flags = 0;
   bool pending_intens = false, pending_times = false, pending_fflags = false;
-  size_t coalesce_min_rays = 0;  ///< 0: every host batch is launched by the call that presents it
+  /// Host-pointer batches smaller than this are collected and run as one device batch (0: every host batch is launched
+  /// by the call that presents it).  On by default: the reference tools present 4096 rays per call.
+  size_t coalesce_min_rays = size_t(1) << 16;
 
   // host mirror of the region table
   std::unordered_map<uint64_t, uint32_t> region_slots;
@@ -1550,6 +1552,69 @@ OHMHIP_ABI_CATCH
 
 namespace
 {
+/// What a batch request must satisfy whatever its size: checked when the call is made, also for calls whose rays only
+/// run later with a collected batch.
+int validateBatchRequest(ohmhip_map_t m, unsigned ray_flags)
+{
+  if (ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED)
+  {
+    return OHMHIP_ERR_UNSUPPORTED;
+  }
+  switch (m->config.mode)
+  {
+  case OHMHIP_MODE_OCCUPANCY:
+    return m->layers[OHMHIP_LID_OCCUPANCY] ? OHMHIP_OK : OHMHIP_ERR_INVALID_ARG;
+  case OHMHIP_MODE_NDT_OM:
+  case OHMHIP_MODE_NDT_TM:
+    if (!m->layers[OHMHIP_LID_OCCUPANCY] || !m->layers[OHMHIP_LID_MEAN] || !m->layers[OHMHIP_LID_COVARIANCE])
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+    if (m->config.mode == OHMHIP_MODE_NDT_TM && (!m->layers[OHMHIP_LID_INTENSITY] || !m->layers[OHMHIP_LID_HIT_MISS]))
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+    return OHMHIP_OK;
+  case OHMHIP_MODE_TSDF:
+    if (!m->layers[OHMHIP_LID_TSDF])
+    {
+      return OHMHIP_ERR_INVALID_ARG;
+    }
+    // weight drop-off makes free-space updates value dependent
+    return (m->config.tsdf_dropoff > 0) ? OHMHIP_ERR_UNSUPPORTED : OHMHIP_OK;
+  default:
+    return OHMHIP_ERR_UNSUPPORTED;
+  }
+}
+
+/// Rays of a host batch the map's ray filter accepts: what the device counts as integrated (k_ray_setup, kRwPassed),
+/// computed on the host with the same arithmetic (walk_device.h: filterRay) so that a call can report it without
+/// waiting for the device -- or for a batch that has not even been launched yet.
+size_t hostFilterCount(const MapConst &mc, const double *rays, size_t n_rays, bool caller_filtered)
+{
+  if (caller_filtered || mc.filter_mode == OHMHIP_FILTER_NONE)
+  {
+    return n_rays;
+  }
+  size_t passed = 0;
+  for (size_t i = 0; i < n_rays; ++i)
+  {
+    const double *r = rays + 6 * i;
+    bool good = std::isfinite(r[0]) && std::isfinite(r[1]) && std::isfinite(r[2]) && std::isfinite(r[3]) &&
+                std::isfinite(r[4]) && std::isfinite(r[5]);
+    if (mc.filter_mode == OHMHIP_FILTER_GOOD)
+    {
+      const double rx = r[3] - r[0];
+      const double ry = r[4] - r[1];
+      const double rz = r[5] - r[2];
+      const double len2 = (rx * rx + ry * ry) + rz * rz;
+      good = good && (mc.filter_range <= 0 || len2 <= mc.filter_range * mc.filter_range);
+    }
+    passed += good ? 1u : 0u;
+  }
+  return passed;
+}
+
 int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
                       const double *timestamps, unsigned ray_flags, const unsigned char *filter_flags,
                       size_t *integrated)
@@ -1562,10 +1627,7 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
-  if (ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED)
-  {
-    return OHMHIP_ERR_UNSUPPORTED;
-  }
+  OHMHIP_CHECK(validateBatchRequest(m, ray_flags));
   const size_t n_rays = element_count / 2;
   if (n_rays == 0)
   {
@@ -1623,21 +1685,18 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
   m->pending_times = timestamps != nullptr;
   m->pending_rays += n_rays;
   m->pending_calls += 1;
+  if (integrated)
+  {
+    *integrated = 2 * hostFilterCount(m->mc, rays, n_rays, filter_flags != nullptr);
+  }
   if (coalesce && m->pending_rays < m->coalesce_min_rays)
   {
-    // Deferred: which rays the filter rejects is only known once the batch runs (ohmhip_map_last_stats).
-    if (integrated)
-    {
-      *integrated = n_rays * 2;
-    }
-    return OHMHIP_OK;
+    return OHMHIP_OK;  // deferred: runs with the following calls' rays, or as soon as anything observes the map
   }
-  const bool only_this_call = m->pending_calls == 1;
-  size_t batch_integrated = 0;
-  err = flushPendingRays(m, &batch_integrated);
-  if (err == OHMHIP_OK && integrated)
+  err = flushPendingRays(m);
+  if (err != OHMHIP_OK && integrated)
   {
-    *integrated = only_this_call ? batch_integrated : n_rays * 2;
+    *integrated = 0;
   }
   return err;
 }

@@ -249,6 +249,7 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
   {
     return;
   }
+  rw.flags = kRwPassed;
 
   int r0[3], l0[3], r1[3], l1[3];
   const bool addressable0 = voxelKey(mc, start, r0, l0);
@@ -270,7 +271,7 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
       {
         rw.g0[a] = addressable1 ? (r1[a] * mc.dim[a] + l1[a]) : (-32768 * mc.dim[a]);
       }
-      rw.flags = kRwValid | kRwApplySample;
+      rw.flags = kRwPassed | kRwValid | kRwApplySample;
     }
     return;
   }
@@ -284,7 +285,7 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
   }
   double length = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
   length = (length > 1e-6) ? sqrt(length) : 0;
-  unsigned flags = kRwValid;
+  unsigned flags = kRwValid | kRwPassed;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
   {

@@ -405,7 +405,7 @@ class GpuMap(RayMapper):
 
     def setBatchCoalescing(self, min_rays):
         """Collect consecutive small host batches and run them as one device batch of >= min_rays rays
-        (include/ohmhip.h: ohmhip_map_set_batch_coalescing).  0 turns it off."""
+        (include/ohmhip.h: ohmhip_map_set_batch_coalescing; on by default with 65536).  0 turns it off."""
         L.check(L.lib.ohmhip_map_set_batch_coalescing(self._handle, int(min_rays)), "setBatchCoalescing")
 
     def setRegionOwnership(self, world_size, rank, block_shift=0):

@@ -556,7 +556,7 @@ public:
   }
 
   /// Not in the reference: run consecutive small integrateRays() batches as one device batch of at least @p min_rays
-  /// rays (see ohmhip_map_set_batch_coalescing); 0 turns it off.
+  /// rays (see ohmhip_map_set_batch_coalescing; on by default with 65536); 0 turns it off.
   void setBatchCoalescing(size_t min_rays) { OHMHIP_GPUAPICHECK(ohmhip_map_set_batch_coalescing(handle_, min_rays)); }
 
   /// Not in the reference (single device): owner-computes multi-GPU mode, see ohmhip_map_set_region_ownership.  The

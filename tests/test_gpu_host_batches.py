@@ -134,3 +134,25 @@ def test_soak_mixed_batch_sizes_flags_and_coalescing(gpu):
             assert gm.stats()["rays_in"] > 0  # observing the map mid-stream flushes what is pending
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
+
+
+def test_deferred_calls_report_their_own_filter_count(gpu):
+    """Small host batches are collected by default; every call still returns the number of points ITS rays contribute
+    (the ray filter's verdict, evaluated on the host with the device's arithmetic)."""
+    rays = synth.random_rays(3000, extent=6.0, seed=61)
+    rays[2 * 10 + 1] = np.nan              # rejected: not finite
+    rays[2 * 2500 + 1, 0] = np.inf         # rejected
+    rays[2 * 1500 + 1] = rays[2 * 1500] + np.array([3e10, 0, 0])  # rejected: longer than the default 1e10 filter
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    total = 0
+    for first in range(0, 3000, 1000):
+        part = rays[2 * first:2 * (first + 1000)]
+        got = gm.integrateRays(part)
+        assert got == part.shape[0] - 2  # one bad ray per call
+        total += got
+        om.integrate_occupancy(part)
+    assert gm.stats()["rays_integrated"] * 2 == total  # the three calls ran as one device batch
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
