@@ -300,6 +300,55 @@ int ohmhip_map_set_region_ownership(ohmhip_map_t map, uint32_t world_size, uint3
 int ohmhip_region_owner(const int16_t *keys_xyz, size_t count, int block_shift, uint32_t world_size,
                         uint32_t *owners);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Replica merge (SURVEY 8e mode 1: every GPU integrates the rays of its own sensor origins into its own resident map;
+ * regions touched by more than one GPU are reconciled on demand).  No reference equivalent -- ohm is single device.
+ *
+ * Rule, per voxel of the occupancy layer, relative to the state `base` all replicas shared after the previous merge:
+ *     merged = clamp(base + sum over ranks of (value_r - base), min, max)
+ * (+inf == unobserved counts as 0 and stays unobserved only if no rank observed the voxel).  That equals integrating the
+ * ranks' rays one rank after the other wherever no min / max clamp engaged in between -- log-odds updates commute until
+ * they saturate -- and is the usual order-free map-merge value where one did.  Exact multi-GPU integration is the
+ * region-ownership mode above.  Other layers are not additive and stay per replica.
+ *
+ * ohmhip_map_enable_merge() gives the map a base copy of its occupancy layer (current content == base) and starts
+ * tracking the regions modified since.  The merge itself is either one call over RCCL (ohmhip_map_merge_replicas:
+ * region key lists are all-gathered, the delta tiles of the regions touched by MORE THAN ONE rank are all-reduced --
+ * 5 bytes per voxel: float delta + observer count --, everything on the map's stream) or, for any other transport, the
+ * three steps it is made of: ohmhip_map_merge_keys -> (exchange keys, agree on the ordered shared set) ->
+ * ohmhip_map_merge_pack -> (sum the payloads across ranks) -> ohmhip_map_merge_apply -> ohmhip_map_merge_finish. */
+typedef struct ohmhip_comm_s *ohmhip_comm_t;
+#define OHMHIP_COMM_ID_BYTES 128
+int ohmhip_comm_unique_id(unsigned char id[OHMHIP_COMM_ID_BYTES]);  /* ncclGetUniqueId; hand it to every rank */
+/* ncclCommInitRank on the calling thread's current device (collective: every rank calls it with the same id). */
+int ohmhip_comm_init_rank(ohmhip_comm_t *comm, const unsigned char id[OHMHIP_COMM_ID_BYTES], int world_size, int rank);
+int ohmhip_comm_destroy(ohmhip_comm_t comm);
+
+typedef struct ohmhip_merge_stats
+{
+  uint32_t regions_local;   /* regions this rank modified since the previous merge                     */
+  uint32_t regions_union;   /* ... any rank did                                                       */
+  uint32_t regions_shared;  /* ... more than one rank did: the ones whose tiles travel                */
+  uint64_t payload_bytes;   /* bytes this rank contributed to the tile all-reduce (5 per shared voxel) */
+  uint64_t key_bytes;       /* bytes it contributed to the key all-gather                              */
+  float ms_total;           /* host wall time of the call                                              */
+} ohmhip_merge_stats;
+
+int ohmhip_map_enable_merge(ohmhip_map_t map);
+/* Collective over `comm`.  On return every rank holds the merged values of the shared regions, which -- like every
+ * other region modified since the previous merge -- become the new base. */
+int ohmhip_map_merge_replicas(ohmhip_map_t map, ohmhip_comm_t comm, ohmhip_merge_stats *stats);
+/* The steps, for other transports.  merge_keys: region keys (int16 x 3 each) modified since the previous merge, at most
+ * `capacity` written, *count = how many there are.  merge_pack: for `count` regions in the given order (made resident
+ * if they are not) write count x region_voxels float deltas and uint8 observer flags to the DEVICE buffers.
+ * merge_apply: the same regions with the payloads summed over all ranks.  merge_finish: rebase everything modified. */
+int ohmhip_map_merge_keys(ohmhip_map_t map, int16_t *keys_xyz, size_t capacity, size_t *count);
+int ohmhip_map_merge_pack(ohmhip_map_t map, const int16_t *keys_xyz, size_t count, float *d_delta,
+                          unsigned char *d_observers);
+int ohmhip_map_merge_apply(ohmhip_map_t map, const int16_t *keys_xyz, size_t count, const float *d_delta_sum,
+                           const unsigned char *d_observer_sum);
+int ohmhip_map_merge_finish(ohmhip_map_t map);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,14 @@ class MapConfig(C.Structure):
                 ("region_capacity", C.c_uint32)]
 
 
+class MergeStats(C.Structure):
+    _fields_ = [("regions_local", C.c_uint32), ("regions_union", C.c_uint32), ("regions_shared", C.c_uint32),
+                ("payload_bytes", C.c_uint64), ("key_bytes", C.c_uint64), ("ms_total", C.c_float)]
+
+
+COMM_ID_BYTES = 128
+
+
 class BatchStats(C.Structure):
     _fields_ = [("rays_in", C.c_uint64), ("rays_integrated", C.c_uint64), ("voxel_visits", C.c_uint64),
                 ("ray_region_segments", C.c_uint64), ("regions_touched", C.c_uint32),
@@ -118,6 +126,15 @@ _sigs = {
     "ohmhip_map_set_batch_coalescing": (C.c_int, [_vp, C.c_size_t]),
     "ohmhip_map_set_region_ownership": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_int]),
     "ohmhip_region_owner": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_uint32, _vp]),
+    "ohmhip_comm_unique_id": (C.c_int, [_vp]),
+    "ohmhip_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
+    "ohmhip_comm_destroy": (C.c_int, [_vp]),
+    "ohmhip_map_enable_merge": (C.c_int, [_vp]),
+    "ohmhip_map_merge_replicas": (C.c_int, [_vp, _vp, C.POINTER(MergeStats)]),
+    "ohmhip_map_merge_keys": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ohmhip_map_merge_pack": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    "ohmhip_map_merge_apply": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    "ohmhip_map_merge_finish": (C.c_int, [_vp]),
 }
 
 EXPORTED_SYMBOLS = sorted(_sigs)

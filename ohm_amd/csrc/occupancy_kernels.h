@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(1024)
         // hit_begin + samples.
         bs.hit_begin[slot] = hit_excl;
         bs.hit_end[slot] = hit_excl;
-        bs.dirty[slot] = 1;
+        bs.dirty[slot] |= 3u;  // modified since the last syncVoxels() (bit 0) / the last replica merge (bit 1)
       }
       if (nchk)
       {
@@ -2848,6 +2848,26 @@ __global__ void __launch_bounds__(1024)
 {
   applyCounts(blockIdx.x, mc, rt, bs, ray_flags, miss_counts, hit_mask, occupancy, clear_mask, hit_miss_counts,
               direct_chunk_segments, skip_masked, 0);
+}
+
+/// dst[i] &= mask
+__global__ void k_and_u32(uint32_t *dst, uint32_t mask, size_t count)
+{
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
+  {
+    dst[i] &= mask;
+  }
+}
+
+/// dst[index[i]] |= bits  (indices may repeat)
+__global__ void k_or_at_u32(uint32_t *dst, const uint32_t *__restrict__ index, size_t count, uint32_t bits)
+{
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
+  {
+    atomicOr(&dst[index[i]], bits);
+  }
 }
 
 /// Fill a float layer with a value (pool initialisation: occupancy clears to +inf, ohm/DefaultLayer.cpp:87-91).

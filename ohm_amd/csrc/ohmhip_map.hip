@@ -68,6 +68,8 @@ struct DevBuf
 }  // namespace
 
 constexpr uint32_t kTimingRing = 32;
+constexpr uint32_t kDirtySync = 1u;   ///< d_dirty bit: modified since the last syncVoxels() (ohmhip_map_clear_dirty)
+constexpr uint32_t kDirtyMerge = 2u;  ///< d_dirty bit: modified since the last replica merge (merge_impl.h)
 
 struct ohmhip_map_s
 {
@@ -108,6 +110,9 @@ struct ohmhip_map_s
 
   DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, events;
   DevBuf wg_regions, wg_region_count, group_heads;
+  /// Replica merge (merge_impl.h): base copy of the occupancy layer (null until ohmhip_map_enable_merge) and scratch.
+  float *d_merge_base = nullptr;
+  DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;
   uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
@@ -264,6 +269,11 @@ void freePool(ohmhip_map_t m)
   m->d_miss_counts = m->d_hit_mask = nullptr;
   m->d_chunks = nullptr;
   m->d_hit_count = m->d_sort_list = nullptr;
+  if (m->d_merge_base)
+  {
+    (void)hipFree(m->d_merge_base);
+    m->d_merge_base = nullptr;
+  }
 }
 
 /// (Re)allocate the region pool for `capacity` regions, preserving the first `keep` slots' contents.  Everything new is
@@ -297,6 +307,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
            *n_sort_list = nullptr, *n_seg_offset = nullptr, *n_touched_flag = nullptr, *n_touched = nullptr,
            *n_first_hit = nullptr, *n_hit_begin = nullptr, *n_hit_end = nullptr, *n_miss_counts = nullptr;
   Chunk *n_chunks = nullptr;
+  float *n_merge_base = nullptr;
   const uint32_t chunk_capacity = capacity + (1u << 16);
   // The per-voxel mask is persistent state for NDT / TSDF (voxels that take the ordered replay path): it moves with
   // the regions it describes.
@@ -363,6 +374,20 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_end), sizeof(uint32_t) * capacity));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_miss_counts), sizeof(uint32_t) * rv * capacity));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_chunks), sizeof(Chunk) * chunk_capacity));
+    if (m->d_merge_base)
+    {
+      // replica-merge base (merge_impl.h): moves with the regions; a new region's base is "unobserved"
+      OHMHIP_CHECK(alloc(reinterpret_cast<void **>(&n_merge_base), sizeof(float) * rv * capacity));
+      if (keep)
+      {
+        OHMHIP_CHECK(hipMemcpyAsync(n_merge_base, m->d_merge_base, sizeof(float) * rv * keep, hipMemcpyDeviceToDevice, s));
+      }
+      if (capacity > keep)
+      {
+        hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint32_t *>(n_merge_base + rv * keep),
+                           0x7f800000u, rv * (capacity - keep));
+      }
+    }
     OHMHIP_CHECK(hipStreamSynchronize(s));
     return OHMHIP_OK;
   };
@@ -401,6 +426,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   m->d_hit_end = n_hit_end;
   m->d_miss_counts = n_miss_counts;
   m->d_chunks = n_chunks;
+  m->d_merge_base = n_merge_base;
   m->chunk_capacity = chunk_capacity;
   m->slot_capacity = capacity;
   m->hash_capacity = hash_cap;
@@ -1366,6 +1392,10 @@ try
   m->wg_regions.release();
   m->wg_region_count.release();
   m->group_heads.release();
+  m->merge_slots.release();
+  m->merge_keys_dev.release();
+  m->merge_delta.release();
+  m->merge_observers.release();
   if (m->d_event_count)
   {
     (void)hipFree(m->d_event_count);
@@ -1931,7 +1961,7 @@ try
   size_t n = 0;
   for (size_t i = 0; i < dirty.size(); ++i)
   {
-    if (dirty[i])
+    if (dirty[i] & kDirtySync)
     {
       if (keys_xyz && n < capacity)
       {
@@ -1953,8 +1983,8 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
-  OHMHIP_CHECK(hipMemsetAsync(m->d_dirty, 0, sizeof(uint32_t) * m->slot_capacity, m->stream));
-  return OHMHIP_OK;
+  hipLaunchKernelGGL(k_and_u32, dim3(256), dim3(256), 0, m->stream, m->d_dirty, ~kDirtySync, size_t(m->slot_capacity));
+  return hipGetLastError();
 }
 OHMHIP_ABI_CATCH
 
@@ -2351,6 +2381,11 @@ try
                                 reinterpret_cast<const char *>(m->d_hit_mask) + mask_row * src, mask_row,
                                 hipMemcpyDeviceToDevice, s));
     OHMHIP_CHECK(hipMemcpyAsync(m->d_dirty + dst, m->d_dirty + src, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (m->d_merge_base)
+    {
+      OHMHIP_CHECK(hipMemcpyAsync(m->d_merge_base + rv * dst, m->d_merge_base + rv * src, sizeof(float) * rv,
+                                  hipMemcpyDeviceToDevice, s));
+    }
     m->slot_keys_host[dst] = m->slot_keys_host[src];
     ++src;
   }
@@ -2374,6 +2409,11 @@ try
   }
   OHMHIP_CHECK(hipMemsetAsync(reinterpret_cast<char *>(m->d_hit_mask) + mask_row * new_n, 0, mask_row * k, s));
   OHMHIP_CHECK(hipMemsetAsync(m->d_dirty + new_n, 0, sizeof(uint32_t) * k, s));
+  if (m->d_merge_base)
+  {
+    hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint32_t *>(m->d_merge_base + rv * new_n),
+                       0x7f800000u, rv * k);
+  }
   m->slot_keys_host.resize(new_n);
   m->region_slots.clear();
   for (uint32_t i = 0; i < new_n; ++i)
@@ -2408,17 +2448,22 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
-  const uint32_t one = 1;
   for (size_t i = 0; i < count; ++i)
   {
     if (slots[i] >= m->slot_capacity)
     {
       return OHMHIP_ERR_INVALID_ARG;
     }
-    OHMHIP_CHECK(hipMemcpyAsync(m->d_dirty + slots[i], &one, sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+  }
+  if (count)
+  {
+    OHMHIP_CHECK(m->merge_slots.ensure(sizeof(uint32_t) * count, false, m->stream));
+    OHMHIP_CHECK(hipMemcpyAsync(m->merge_slots.ptr, slots, sizeof(uint32_t) * count, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_or_at_u32, dim3(64), dim3(256), 0, m->stream, m->d_dirty,
+                       static_cast<const uint32_t *>(m->merge_slots.ptr), count, kDirtySync | kDirtyMerge);
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
-  return OHMHIP_OK;
+  return hipGetLastError();
 }
 OHMHIP_ABI_CATCH
 
@@ -2525,3 +2570,5 @@ try
 OHMHIP_ABI_CATCH
 
 }  // extern "C"
+
+#include "merge_impl.h"

@@ -174,47 +174,112 @@ def occupancy_tensor(gpu_map):
     return torch.as_tensor(_DeviceArray(ptr.value, (max(n.value, 1), voxels), "<f4"), device="cuda")
 
 
+class Communicator:
+    """RCCL communicator owned by the library (include/ohmhip.h: ohmhip_comm_*).  The unique id travels over whatever
+    control plane the ranks already share -- here a torch.distributed process group (any backend)."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib as L
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        uid = (C.c_ubyte * L.COMM_ID_BYTES)()
+        if self.rank == 0:
+            L.check(L.lib.ohmhip_comm_unique_id(uid), "comm_unique_id")
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = (C.c_ubyte * L.COMM_ID_BYTES).from_buffer_copy(box[0])
+        self._handle = L._vp()
+        L.check(L.lib.ohmhip_comm_init_rank(C.byref(self._handle), uid, self.world, self.rank), "comm_init_rank")
+
+    def close(self):
+        from . import _lib as L
+        if self._handle:
+            L.lib.ohmhip_comm_destroy(self._handle)
+            self._handle = None
+
+
 class ReplicaMerger:
-    """Keeps the common base state of a GpuMap replica and merges replicas across ranks.
+    """Replica merge of a GpuMap's occupancy layer (include/ohmhip.h "Replica merge"): the map keeps the state all
+    replicas shared after the previous merge and the set of regions modified since; merge() reconciles the regions more
+    than one rank modified.
 
-    usage:  merger = ReplicaMerger(gpu_map); ... integrateRays on every rank ...; merger.merge()
-    After merge() every rank holds the same occupancy values for the union of touched regions and the merged state
-    becomes the new base."""
+    usage:  merger = ReplicaMerger(gpu_map, comm=Communicator())   # RCCL inside the library, everything on device
+            ... integrateRays on every rank ...;  stats = merger.merge()
+    Without `comm` the same steps run over a torch.distributed group of any backend (gloo in the tests): key lists by
+    all_gather_object, payloads by all_reduce on tensors that alias the library's device buffers (or host copies)."""
 
-    def __init__(self, gpu_map, group=None):
+    def __init__(self, gpu_map, group=None, comm=None):
+        from . import _lib as L
         self.gpu_map = gpu_map
         self.group = group
-        self._base = {}  # packed region key -> base tile (device tensor); absent == all unobserved
+        self.comm = comm
+        L.check(L.lib.ohmhip_map_enable_merge(gpu_map._handle), "enable_merge")
 
-    def _slots(self, keys):
+    def local_keys(self):
         import ctypes as C
         from . import _lib as L
-        keys = np.ascontiguousarray(keys, dtype=np.int16).reshape(-1, 3)
-        slots = np.zeros(len(keys), dtype=np.uint32)
-        L.check(L.lib.ohmhip_map_ensure_regions(self.gpu_map._handle, keys.ctypes.data, len(keys), slots.ctypes.data),
-                "ensure_regions")
-        return slots
+        n = C.c_size_t(0)
+        L.check(L.lib.ohmhip_map_merge_keys(self.gpu_map._handle, None, 0, C.byref(n)), "merge_keys")
+        keys = np.zeros((max(n.value, 1), 3), dtype=np.int16)
+        L.check(L.lib.ohmhip_map_merge_keys(self.gpu_map._handle, keys.ctypes.data, n.value, C.byref(n)), "merge_keys")
+        return keys[:n.value]
 
     def merge(self):
+        """Collective.  Returns the merge statistics (regions_local / regions_union / regions_shared / payload_bytes)."""
+        import ctypes as C
+        from . import _lib as L
+        if self.comm is not None:
+            st = L.MergeStats()
+            L.check(L.lib.ohmhip_map_merge_replicas(self.gpu_map._handle, self.comm._handle, C.byref(st)),
+                    "merge_replicas")
+            return {name: getattr(st, name) for name, _ in L.MergeStats._fields_}
+        return self._merge_over_group()
+
+    def _merge_over_group(self):
         import ctypes as C
         import torch
+        import torch.distributed as dist
         from . import _lib as L
         gm = self.gpu_map
-        local_keys = gm.regionKeys(dirty_only=True)
-        union = union_region_keys(local_keys, self.group)
-        if len(union) == 0:
-            return 0
-        slots = self._slots(union)  # may grow the pool: take the tensor afterwards
-        occ = occupancy_tensor(gm)
-        idx = torch.as_tensor(slots.astype(np.int64), device=occ.device)
-        local = occ[idx]
-        packed = _pack_keys(union)
-        base = torch.stack([self._base.get(int(k), torch.full_like(local[0], float("inf"))) for k in packed])
-        merged = merge_occupancy_deltas(base, local, float(gm._map.min_voxel_value), float(gm._map.max_voxel_value),
-                                        self.group)
-        occ[idx] = merged
-        torch.cuda.synchronize()
-        for i, k in enumerate(packed):
-            self._base[int(k)] = merged[i].clone()
-        L.check(L.lib.ohmhip_map_mark_dirty(gm._handle, slots.ctypes.data, len(slots)), "mark_dirty")
-        return len(union)
+        local = self.local_keys()
+        world = dist.get_world_size(self.group)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, _pack_keys(local).tolist(), group=self.group)
+        counts = {}
+        for lst in gathered:
+            for k in lst:
+                counts[k] = counts.get(k, 0) + 1
+        shared = _unpack_keys(np.array(sorted(k for k, c in counts.items() if c > 1), dtype=np.int64)).reshape(-1, 3)
+        shared = np.ascontiguousarray(shared, dtype=np.int16)
+        n = len(shared)
+        voxels = n * int(np.prod(gm._map.region_voxel_dimensions))
+        if n:
+            delta = L._vp()
+            obs = L._vp()
+            L.check(L.lib.ohmhip_buffer_create(C.byref(delta), 4 * voxels, 3), "buffer_create")
+            L.check(L.lib.ohmhip_buffer_create(C.byref(obs), voxels, 3), "buffer_create")
+            d_delta, d_obs = L._vp(), L._vp()
+            L.check(L.lib.ohmhip_buffer_ptr(delta, C.byref(d_delta)))
+            L.check(L.lib.ohmhip_buffer_ptr(obs, C.byref(d_obs)))
+            L.check(L.lib.ohmhip_map_merge_pack(gm._handle, shared.ctypes.data, n, d_delta, d_obs), "merge_pack")
+            # reduce through host tensors: works for every backend (the RCCL path of the library stays on the device)
+            h_delta = np.zeros(voxels, dtype=np.float32)
+            h_obs = np.zeros(voxels, dtype=np.uint8)
+            L.check(L.lib.ohmhip_buffer_read(delta, h_delta.ctypes.data, 4 * voxels, 0, None, None, None))
+            L.check(L.lib.ohmhip_buffer_read(obs, h_obs.ctypes.data, voxels, 0, None, None, None))
+            t_delta = torch.from_numpy(h_delta)
+            t_obs = torch.from_numpy(h_obs.astype(np.int32))
+            dist.all_reduce(t_delta, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(t_obs, op=dist.ReduceOp.SUM, group=self.group)
+            h_obs = np.minimum(t_obs.numpy(), 255).astype(np.uint8)
+            L.check(L.lib.ohmhip_buffer_write(delta, t_delta.numpy().ctypes.data, 4 * voxels, 0, None, None, None))
+            L.check(L.lib.ohmhip_buffer_write(obs, h_obs.ctypes.data, voxels, 0, None, None, None))
+            L.check(L.lib.ohmhip_map_merge_apply(gm._handle, shared.ctypes.data, n, d_delta, d_obs), "merge_apply")
+            L.lib.ohmhip_buffer_destroy(delta)
+            L.lib.ohmhip_buffer_destroy(obs)
+        L.check(L.lib.ohmhip_map_merge_finish(gm._handle), "merge_finish")
+        gm.wait()
+        return {"regions_local": len(local), "regions_union": len(counts), "regions_shared": n,
+                "payload_bytes": 5 * voxels}

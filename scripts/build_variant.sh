@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 TAG=$1; shift
 mkdir -p ohm_amd/lib/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function "$@" \
-  -o ohm_amd/lib/variants/libohmhip_$TAG.so ohm_amd/csrc/ohmhip_device.hip ohm_amd/csrc/ohmhip_map.hip ohm_amd/csrc/ohmhip_transform.hip
+  -o ohm_amd/lib/variants/libohmhip_$TAG.so ohm_amd/csrc/ohmhip_device.hip ohm_amd/csrc/ohmhip_map.hip ohm_amd/csrc/ohmhip_transform.hip -L/opt/rocm/lib -lrccl
 echo built ohm_amd/lib/variants/libohmhip_$TAG.so

@@ -26,16 +26,21 @@ def main():
     try:
         map_ = OccupancyMap(0.1)
         gm = GpuMap(map_)
-        merger = D.ReplicaMerger(gm)
+        comm = D.Communicator()  # RCCL communicator inside libohmhip.so, unique id broadcast over the torch group
+        merger = D.ReplicaMerger(gm, comm=comm)
         rays = synth.rays_c0(n=5000, length=4.0)
         gm.integrateRays(rays)
         view = D.occupancy_tensor(gm)
         assert view.is_cuda and view.shape[1] == 32 ** 3
-        n = merger.merge()
-        assert n == len(gm.regionKeys())
-        # with one rank the merge must be the identity (base + (x - base)); do a second round on a non-trivial base
+        st = merger.merge()
+        n = st["regions_local"]
+        assert n == len(gm.regionKeys()) and st["regions_union"] == n and st["regions_shared"] == 0
+        # with one rank nothing is shared: the merge only rebases; a second round on a non-trivial base
         gm.integrateRays(rays[:2000])
-        merger.merge()
+        st = merger.merge()
+        assert 0 < st["regions_local"] <= n and st["payload_bytes"] == 0
+        assert len(merger.local_keys()) == 0
+        comm.close()
         gm.syncVoxels()
         om = OracleMap(0.1)
         om.integrate_occupancy(rays)
