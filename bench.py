@@ -5,8 +5,10 @@
 
 One "step" = one GpuMap::integrateRays pass over one 1 M-ray synthetic lidar batch (C1) whose rays are already
 resident in HBM when the timed region starts.  At N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank integrates the C4 shard of its own sensor origin into its own resident map (ray shards by sensor origin, no
-data-path collective: "weak" scaling); value = rays of all ranks / max-over-ranks time.
+rank integrates the C4 shard of its own sensor origin into its own resident map and, inside the timed region, the
+replicas are reconciled after every batch: the library's replica merge (include/ohmhip.h) all-gathers the region key
+lists and all-reduces, over RCCL, the occupancy deltas of the regions more than one rank touched ("weak" scaling);
+value = rays of all ranks / max-over-ranks time, bytes moved are reported under "merge".
 
 Prints ONE JSON line on rank 0.
 """
@@ -87,7 +89,8 @@ def main():
     else:
         rays = synth.rays_c4_shard(rank, n=n_rays)
         workload = ("C4: GpuMap occupancy, 0.1 m voxels, 1M-ray lidar batch per sensor origin, one origin per GPU, "
-                    "replicated maps (no merge in the timed region)")
+                    "replicated maps, regions touched by more than one GPU merged by an RCCL delta all-reduce after "
+                    "every batch (inside the timed region)")
 
     map_ = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
     gm = ohm_amd.GpuMap(map_, gpu_mem_size=8 << 30)
@@ -99,6 +102,16 @@ def main():
     dptr = L._vp()
     L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(dptr)), "buffer_ptr")
 
+    merger = None
+    comm = None
+    merge_log = []
+    if world > 1:
+        from ohm_amd import distributed as D
+        # RCCL communicator owned by the library when every rank has its own GPU; otherwise (single-GPU smoke runs with
+        # more ranks than GPUs) the same merge steps run over the gloo group.
+        comm = D.Communicator() if backend == "nccl" else None
+        merger = D.ReplicaMerger(gm, comm=comm)
+
     def barrier():
         gm.wait()
         if dist is not None:
@@ -109,10 +122,13 @@ def main():
 
     def step():
         gm.integrateRaysDevice(dptr, rays.shape[0])
+        if merger is not None:
+            merge_log.append(merger.merge())
 
     for _ in range(args.warmup):
         step()
     barrier()
+    del merge_log[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -167,6 +183,14 @@ def main():
         "device_ms": {"setup_bin": float(np.mean([t["ms_setup"] for t in timings])), "walk": float(np.mean(walk_ms)),
                       "sort_apply": float(np.mean([t["ms_apply"] for t in timings])), "total": float(np.mean(total_ms))},
     }
+    if merge_log:
+        out["merge"] = {"per_step": {"regions_local": int(np.mean([m["regions_local"] for m in merge_log])),
+                                     "regions_union": int(np.mean([m["regions_union"] for m in merge_log])),
+                                     "regions_shared": int(np.mean([m["regions_shared"] for m in merge_log])),
+                                     "payload_bytes_per_rank": int(np.mean([m["payload_bytes"] for m in merge_log])),
+                                     "ms_host": float(np.mean([m.get("ms_total", 0.0) for m in merge_log]))},
+                        "transport": "RCCL (library)" if comm is not None else "gloo (host staged)",
+                        "rule": "merged = clamp(base + sum_r (x_r - base)); exact where no clamp engaged between ranks"}
     if world == 1 and not args.no_extra:
         # Secondary figures (not the headline `value`): C2 GpuNdtMap (1 M rays) and C3 GpuTsdfMap (its full 4 M rays in one
         # call), same harness, each with its own roofline block.  Algorithmic bytes per SURVEY.md 8d:
@@ -299,6 +323,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     L.lib.ohmhip_buffer_destroy(buf)
+    if comm is not None:
+        comm.close()
     gm.close()
     if rank == 0:
         print(json.dumps(out))

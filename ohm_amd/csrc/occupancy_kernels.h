@@ -1728,7 +1728,9 @@ struct WalkArgs
   float *occupancy;  ///< non-null: single-chunk regions are applied straight from LDS
   unsigned ray_flags;
   unsigned long long *dbg_counters;
-  float *traversal;  ///< kTraversal instantiations: per-visit ray length accumulation (global float atomics)
+  /// kTraversal instantiations: per-voxel sum of the ray lengths of this batch's visits, in fixed point
+  /// (kTraversalScale units per metre): integer atomics, so the sum does not depend on the order of the adds.
+  unsigned long long *traversal_acc;
   float *tsdf;       ///< non-null (TSDF mode): single-chunk regions are applied straight from LDS
   uint32_t *chunk_cursor;  ///< device-wide next-chunk cursor (zeroed before the launch)
   uint32_t n_chunks;
@@ -1737,6 +1739,7 @@ struct WalkArgs
   int rewalk;
 };
 
+constexpr double kTraversalScale = 1099511627776.0;  ///< 2^40 fixed-point units per metre of traversal
 constexpr uint32_t kWalkCursorWords = 24;  ///< l_cursor[]: see k_region_walk
 #ifndef OHMHIP_WALK_UNROLL
 #define OHMHIP_WALK_UNROLL 2
@@ -1748,7 +1751,9 @@ constexpr int kWalkUnroll = OHMHIP_WALK_UNROLL;  ///< walk steps per loop trip (
 /// of an active lane is a miss.
 /// kTraversal: also accumulate the ray length inside every visited voxel (traversal layer, ohm/RayMapperOccupancy.cpp:
 /// 166-173).  That needs the exact fp64 time of every step, so these instantiations run the reference's fp64 step for
-/// every lane instead of the fixed-point predictor.
+/// every lane instead of the fixed-point predictor.  The lengths of a batch are summed exactly (integer atomics on a
+/// fixed-point accumulator, applied by applyCounts): deterministic, and equal to the CPU's ray-by-ray float sum up to
+/// that sum's own rounding (the tests hold it to 1e-5 relative).
 /// kTrace: development instrumentation (OHMHIP_DEBUG_FLAGS 64 / 128): per-chunk time stamps and loop counters.  Compiled
 /// out of the production instantiations.
 template <bool kSpecial, bool kTraversal, bool kTrace>
@@ -2249,8 +2254,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           }
           if (visit)
           {
-            atomicAdd(&args.traversal[size_t(chunk.slot) * size_t(mc.region_voxels) + (va >> 1)],
-                      float(t_exit - t_enter));
+            // (the CPU mapper adds float(exit - enter), ohm/RayMapperOccupancy.cpp:166-173: that float is what is summed)
+            atomicAdd(&args.traversal_acc[size_t(chunk.slot) * size_t(mc.region_voxels) + (va >> 1)],
+                      (unsigned long long)(double(float(t_exit - t_enter)) * kTraversalScale));
           }
           t_enter = active ? t_exit : t_enter;
           // ---- the reference's fp64 step, branch free, taken by every lane (an idle lane's state is dead, and the
@@ -2741,7 +2747,8 @@ __device__ inline void applyCounts(uint32_t region_index, const MapConst &mc, co
                                    const BatchScratch &bs, unsigned ray_flags, uint32_t *__restrict__ miss_counts,
                                    uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy, int clear_mask,
                                    uint32_t *__restrict__ hit_miss_counts, uint32_t direct_chunk_segments,
-                                   int skip_masked, int preserve_masked)
+                                   int skip_masked, int preserve_masked, float *__restrict__ traversal = nullptr,
+                                   unsigned long long *__restrict__ traversal_acc = nullptr)
 {
   const uint32_t h = bs.touched[region_index];
   const uint32_t slot = rt.vals[h];
@@ -2824,6 +2831,19 @@ __device__ inline void applyCounts(uint32_t region_index, const MapConst &mc, co
       }
     }
   }
+  if (traversal_acc)
+  {
+    // This batch's ray lengths through the region's voxels (k_region_walk<.., kTraversal>), summed exactly.
+    for (uint32_t vi = threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
+    {
+      const unsigned long long sum = traversal_acc[base + vi];
+      if (sum)
+      {
+        traversal[base + vi] = float(double(traversal[base + vi]) + double(sum) * (1.0 / kTraversalScale));
+        traversal_acc[base + vi] = 0;
+      }
+    }
+  }
   if (clear_mask)
   {
     __syncthreads();  // (the loops above read the mask)
@@ -2844,10 +2864,11 @@ __device__ inline void applyCounts(uint32_t region_index, const MapConst &mc, co
 __global__ void __launch_bounds__(1024)
   k_apply_counts(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags, uint32_t *__restrict__ miss_counts,
                  uint32_t *__restrict__ hit_mask, float *__restrict__ occupancy, int clear_mask,
-                 uint32_t *__restrict__ hit_miss_counts, uint32_t direct_chunk_segments, int skip_masked)
+                 uint32_t *__restrict__ hit_miss_counts, uint32_t direct_chunk_segments, int skip_masked,
+                 float *__restrict__ traversal, unsigned long long *__restrict__ traversal_acc)
 {
   applyCounts(blockIdx.x, mc, rt, bs, ray_flags, miss_counts, hit_mask, occupancy, clear_mask, hit_miss_counts,
-              direct_chunk_segments, skip_masked, 0);
+              direct_chunk_segments, skip_masked, 0, traversal, traversal_acc);
 }
 
 /// dst[i] &= mask

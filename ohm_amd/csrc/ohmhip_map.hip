@@ -112,6 +112,8 @@ struct ohmhip_map_s
   DevBuf wg_regions, wg_region_count, group_heads;
   /// Replica merge (merge_impl.h): base copy of the occupancy layer (null until ohmhip_map_enable_merge) and scratch.
   float *d_merge_base = nullptr;
+  /// Traversal layer only: per-voxel fixed-point sum of a batch's ray lengths (zero between batches).
+  unsigned long long *d_traversal_acc = nullptr;
   DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;
   uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
@@ -274,6 +276,11 @@ void freePool(ohmhip_map_t m)
     (void)hipFree(m->d_merge_base);
     m->d_merge_base = nullptr;
   }
+  if (m->d_traversal_acc)
+  {
+    (void)hipFree(m->d_traversal_acc);
+    m->d_traversal_acc = nullptr;
+  }
 }
 
 /// (Re)allocate the region pool for `capacity` regions, preserving the first `keep` slots' contents.  Everything new is
@@ -308,6 +315,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
            *n_first_hit = nullptr, *n_hit_begin = nullptr, *n_hit_end = nullptr, *n_miss_counts = nullptr;
   Chunk *n_chunks = nullptr;
   float *n_merge_base = nullptr;
+  unsigned long long *n_traversal_acc = nullptr;
   const uint32_t chunk_capacity = capacity + (1u << 16);
   // The per-voxel mask is persistent state for NDT / TSDF (voxels that take the ordered replay path): it moves with
   // the regions it describes.
@@ -374,6 +382,10 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_end), sizeof(uint32_t) * capacity));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_miss_counts), sizeof(uint32_t) * rv * capacity));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_chunks), sizeof(Chunk) * chunk_capacity));
+    if (m->config.layers & (1u << OHMHIP_LID_TRAVERSAL))
+    {
+      OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_traversal_acc), sizeof(unsigned long long) * rv * capacity));
+    }
     if (m->d_merge_base)
     {
       // replica-merge base (merge_impl.h): moves with the regions; a new region's base is "unobserved"
@@ -427,6 +439,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   m->d_miss_counts = n_miss_counts;
   m->d_chunks = n_chunks;
   m->d_merge_base = n_merge_base;
+  m->d_traversal_acc = n_traversal_acc;
   m->chunk_capacity = chunk_capacity;
   m->slot_capacity = capacity;
   m->hash_capacity = hash_cap;
@@ -843,7 +856,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.ray_flags = ray_flags;
         const bool trace = (m->debug_flags & (16u | 64u | 128u)) != 0;
         wa.dbg_counters = trace ? m->d_dbg : nullptr;
-        wa.traversal = sec.traversal;
+        wa.traversal_acc = sec.traversal ? m->d_traversal_acc : nullptr;
         wa.chunk_cursor = m->d_event_count + 1;
         wa.n_chunks = info.n_chunks;
         // A repeated walk (NDT / TSDF event list overflow) must not apply anything twice: single-chunk regions were
@@ -938,7 +951,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
                            batchScratch(m), ray_flags, m->d_miss_counts, m->d_hit_mask,
                            static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]), 1,
-                           static_cast<uint32_t *>(nullptr), direct_segments, 0);
+                           static_cast<uint32_t *>(nullptr), direct_segments, 0, sec.traversal,
+                           sec.traversal ? m->d_traversal_acc : nullptr);
       }
     }
     else
@@ -980,7 +994,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
           hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
                              batchScratch(m), 0u, m->d_miss_counts, m->d_hit_mask,
                              static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]), 0,
-                             tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr, direct_segments, 1);
+                             tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr, direct_segments, 1,
+                             sec.traversal, sec.traversal ? m->d_traversal_acc : nullptr);
         }
       }
       else

@@ -1,7 +1,8 @@
 """-m gpu: secondary voxel layers -- traversal, touch time, incident normal -- for GpuMap and GpuNdtMap
 vs the CPU oracle.  Mirrors tests/ohmtestgpu/GpuTraversalTests / GpuTouchTimeTests / GpuIncidentsTests.
-Touch time and the packed incident normal are integer fields: bit exact.  Traversal is a float accumulated in a
-different order on the device: compared to summation-order rounding (1e-3 relative), documented in DESIGN.md."""
+Touch time and the packed incident normal are integer fields: bit exact.  Traversal: the device sums a batch's ray
+lengths per voxel exactly (fixed-point integer atomics, deterministic) where the CPU adds them to a float one ray at a
+time: equal to the rounding of the CPU's own running sum, held to 1e-5 relative here, and bit-identical run to run."""
 import numpy as np
 import pytest
 
@@ -26,7 +27,7 @@ def _check(om, map_, layers):
         nz = c != 0
         if nz.any():
             worst = max(worst, float(np.max(np.abs(g[nz] - c[nz]) / np.maximum(np.abs(c[nz]), 1e-3))))
-    assert worst < 1e-3, worst
+    assert worst < 1e-5, worst
 
 
 def test_occupancy_secondary_layers(gpu):
@@ -74,3 +75,19 @@ def test_ndt_secondary_layers(gpu):
         om.integrate_ndt(chunk, timestamps=tchunk)
     gm.syncVoxels()
     _check(om, map_, list(map_.layers))
+
+
+def test_traversal_is_deterministic(gpu):
+    rays = synth.rays_c1(n=40000, max_range=8.0, seed=77)
+    results = []
+    for _ in range(3):
+        map_ = OccupancyMap(0.1, layers=("occupancy", "traversal"))
+        gm = GpuMap(map_)
+        gm.integrateRays(rays)
+        gm.integrateRays(rays[:30000])
+        gm.syncVoxels()
+        results.append({k: v["traversal"].copy() for k, v in map_.chunks.items()})
+    for other in results[1:]:
+        assert other.keys() == results[0].keys()
+        for key, tile in results[0].items():
+            assert np.array_equal(tile.view(np.uint32), other[key].view(np.uint32))
