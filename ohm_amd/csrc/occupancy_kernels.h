@@ -1737,6 +1737,9 @@ struct WalkArgs
   /// NDT / TSDF: this launch repeats a walk whose event list overflowed.  Regions held by a single chunk had their plain
   /// counts applied to the layers by the first launch already: the repeat only regenerates their events.
   int rewalk;
+  /// TSDF with weight drop-off: a free-space visit changes the weight by a value that depends on the voxel and the
+  /// ray, so no voxel can be counted -- every visit of the batch is an event for the ordered replay.
+  int flag_all;
 };
 
 constexpr double kTraversalScale = 1099511627776.0;  ///< 2^40 fixed-point units per metre of traversal
@@ -1934,7 +1937,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // of the row's XOR constant, the words inside a group by its low two bits.
     for (uint32_t w = threadIdx.x; w < mask_words; w += kWalkThreads)
     {
-      const uint32_t mword = (w == threadIdx.x) ? my_mask : g_mask[w];
+      const uint32_t mword = args.flag_all ? 0xffffffffu : ((w == threadIdx.x) ? my_mask : g_mask[w]);
       const uint32_t swizzle = tileWord(w * 16u) ^ (w * 16u);
 #pragma unroll
       for (uint32_t q = 0; q < 4; ++q)

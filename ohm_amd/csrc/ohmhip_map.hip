@@ -863,6 +863,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         // applied straight from LDS by the first launch (the repeat only regenerates their events) and the traversal
         // layer has its sums already.
         wa.rewalk = (walk_attempt > 0 && (direct_occ || tsdf_mode)) ? 1 : 0;
+        wa.flag_all = (tsdf_mode && m->mc.tsdf_dropoff > 0) ? 1 : 0;
         const bool walk_traversal = sec.traversal != nullptr && walk_attempt == 0;
         // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited) or the
         // traversal layer needs the exit range of an end voxel that is part of the walk.  (An end voxel that is walked --
@@ -1560,10 +1561,6 @@ int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_cou
     {
       return OHMHIP_ERR_INVALID_ARG;
     }
-    if (m->config.tsdf_dropoff > 0)
-    {
-      return OHMHIP_ERR_UNSUPPORTED;  // weight drop-off makes free-space updates value dependent
-    }
     err = integrateBatch(m, d_rays, d_intensities, d_timestamps, uint32_t(n_rays), ray_flags);
     break;
   default:
@@ -1625,8 +1622,7 @@ int validateBatchRequest(ohmhip_map_t m, unsigned ray_flags)
     {
       return OHMHIP_ERR_INVALID_ARG;
     }
-    // weight drop-off makes free-space updates value dependent
-    return (m->config.tsdf_dropoff > 0) ? OHMHIP_ERR_UNSUPPORTED : OHMHIP_OK;
+    return OHMHIP_OK;
   default:
     return OHMHIP_ERR_UNSUPPORTED;
   }

@@ -140,11 +140,15 @@ def test_tsdf_sparsity_and_weight_cap(gpu):
     assert_parity(stats)
 
 
-def test_tsdf_dropoff_is_reported_unsupported(gpu):
-    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("tsdf",))
-    gm = GpuTsdfMap(map_, dropoff_epsilon=0.05)
-    with pytest.raises(ohm_amd.OhmHipError):
-        gm.integrateRays(synth.rays_c2(n=64))
+def test_tsdf_weight_dropoff(gpu):
+    # ohm/VoxelTsdfCompute.h:103-107: with dropoff_epsilon > 0 a free-space visit adds a weight that depends on the
+    # voxel's sdf, so nothing can be counted: every visit of the batch goes through the ordered replay.  Bit exact.
+    rays = np.concatenate([synth.rays_c2(n=3000, seed=450 + k) for k in range(3)])
+    stats, gm, om = run_tsdf(rays, batch=3000, dropoff_epsilon=0.05)
+    assert_parity(stats)
+    stats, gm, om = run_tsdf(rays[:6000], resolution=0.2, trunc=0.5, batch=1500, dropoff_epsilon=0.2,
+                             sparsity_compensation_factor=1.5)
+    assert_parity(stats)
 
 
 def test_ndt_and_tsdf_soak_mixed_batch_sizes(gpu):
