@@ -72,8 +72,16 @@ try
   hipDeviceProp_t prop;
   OHMHIP_CHECK(hipGetDeviceProperties(&prop, device));
   std::memset(info, 0, sizeof(*info));
-  std::snprintf(info->name, sizeof(info->name), "%s", prop.name);
   std::snprintf(info->arch, sizeof(info->arch), "%s", prop.gcnArchName);
+  if (prop.name[0])
+  {
+    std::snprintf(info->name, sizeof(info->name), "%s", prop.name);
+  }
+  else
+  {
+    // (some driver / runtime combinations leave the marketing name empty: fall back to the architecture)
+    std::snprintf(info->name, sizeof(info->name), "AMD GPU (%s, %d CUs)", prop.gcnArchName, prop.multiProcessorCount);
+  }
   info->total_memory = prop.totalGlobalMem;
   info->max_allocation = prop.totalGlobalMem;
   info->compute_units = prop.multiProcessorCount;

@@ -439,3 +439,133 @@ def test_transform_samples_round_trip():
     keep = np.ones(n, dtype=bool)
     keep[[3, 7]] = False
     assert np.array_equal(rays2[1::2], rays[1::2][keep])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Hand-derived exact pins (round 2): values worked out on paper from the reference's rules, with inputs chosen so every
+# intermediate is exact in binary floating point -- no tolerance anywhere.
+# ---------------------------------------------------------------------------------------------------------------------
+def _global_seq(m, start, end, flags=0):
+    keys, _, _ = m.walk(start, end, flags)
+    return [tuple(int(v) for v in _global_voxel(k)) for k in keys]
+
+
+def test_walk_tie_breaking_exact_key_sequences():
+    """walkSelectNextAxis (ohm/LineWalkCompute.h:282-289): `axis = (t[axis] < t[1]) ? axis : 1; axis = (t[axis] < t[2]) ?
+    axis : 2` -- equal times go to the HIGHER axis.  1 m voxels with the map origin at 0 put every voxel face on an
+    integer, so a ray from a voxel centre along a diagonal crosses exact corners; its direction components are bitwise
+    equal, hence so are the competing times.  Voxel g covers [g, g + 1) (region 0 spans [-16, 16))."""
+    m = OracleMap(1.0)
+    off = 16  # global voxel index of the voxel [0, 1)
+
+    def seq(*pts):
+        return [(x + off, y + off, z + off) for x, y, z in pts]
+
+    # x-y diagonal: at every corner y steps before x
+    assert _global_seq(m, (0.5, 0.5, 0.5), (3.5, 3.5, 0.5)) == seq((0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 2, 0), (2, 2, 0),
+                                                                   (2, 3, 0), (3, 3, 0))
+    # space diagonal: z, then y, then x
+    assert _global_seq(m, (0.5, 0.5, 0.5), (2.5, 2.5, 2.5)) == seq((0, 0, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1), (1, 1, 2),
+                                                                   (1, 2, 2), (2, 2, 2))
+    # the rule is about the axis index, not the direction of travel
+    assert _global_seq(m, (0.5, 0.5, 0.5), (-2.5, -2.5, 0.5)) == seq((0, 0, 0), (0, -1, 0), (-1, -1, 0), (-1, -2, 0),
+                                                                     (-2, -2, 0), (-2, -3, 0), (-3, -3, 0))
+    assert _global_seq(m, (0.5, 0.5, 0.5), (2.5, 0.5, -1.5)) == seq((0, 0, 0), (0, 0, -1), (1, 0, -1), (1, 0, -2),
+                                                                    (2, 0, -2))
+    # x-z tie with y fixed: z first
+    assert _global_seq(m, (0.5, 0.5, 0.5), (2.5, 0.5, 2.5)) == seq((0, 0, 0), (0, 0, 1), (1, 0, 1), (1, 0, 2), (2, 0, 2))
+    # kExcludeEndVoxel (2) drops exactly the last voxel, kExcludeStartVoxel (1) the first
+    assert _global_seq(m, (0.5, 0.5, 0.5), (2.5, 2.5, 2.5), 2) == seq((0, 0, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1),
+                                                                      (1, 1, 2), (1, 2, 2))
+    assert _global_seq(m, (0.5, 0.5, 0.5), (2.5, 2.5, 2.5), 1)[0] == (off, off, off + 1)
+    # a 2:1 slope (no ties): x crosses at t = 0.5, 1.5, 2.5 (in units of the x extent), y at 1, 3 -> x, y, x, x, y, x...
+    assert _global_seq(m, (0.5, 0.5, 0.5), (4.5, 2.5, 0.5)) == seq((0, 0, 0), (1, 0, 0), (1, 1, 0), (2, 1, 0), (3, 1, 0),
+                                                                   (3, 2, 0), (4, 2, 0))
+    # and across a region boundary (region 0 ends at voxel 15): the sequence is unaffected by the region split
+    assert _global_seq(m, (14.5, 14.5, 0.5), (17.5, 17.5, 0.5)) == seq((14, 14, 0), (14, 15, 0), (15, 15, 0),
+                                                                       (15, 16, 0), (16, 16, 0), (16, 17, 0), (17, 17, 0))
+    keys, _, _ = m.walk((14.5, 14.5, 0.5), (17.5, 17.5, 0.5), 0)
+    assert keys[2] == ((0, 0, 0), (31, 31, 16)) and keys[3] == ((0, 1, 0), (31, 0, 16)) and keys[4] == ((1, 1, 0), (0, 0, 16))
+
+
+def test_walk_axis_aligned_exact_sequences_and_ranges():
+    m = OracleMap(1.0)
+    keys, enter, exit_ = m.walk((0.5, 0.5, 0.5), (3.5, 0.5, 0.5), 0)
+    assert [tuple(int(v) for v in _global_voxel(k)) for k in keys] == [(16 + i, 16, 16) for i in range(4)]
+    assert enter == [0.0, 0.5, 1.5, 2.5] and exit_ == [0.5, 1.5, 2.5, 3.0]  # the end voxel's exit is the ray length
+    keys, enter, exit_ = m.walk((0.5, 0.5, 0.5), (0.5, 0.5, -1.5), 0)
+    assert [tuple(int(v) for v in _global_voxel(k)) for k in keys] == [(16, 16, 16), (16, 16, 15), (16, 16, 14)]
+    assert enter == [0.0, 0.5, 1.5] and exit_ == [0.5, 1.5, 2.0]
+
+
+def test_voxel_mean_exact_patterns():
+    """subVoxelCoord / subVoxelUpdate (ohm/VoxelMeanCompute.h:69-92, 134-152) with a 1023 m voxel: the mean grid step is
+    exactly 1 m and the offset exactly 511.5 m, so positions are plain integers: pos = floor(v + 511.5 + 0.5)."""
+    res = 1023.0
+    used = 1 << 31
+
+    def pattern(px, py, pz):
+        return used | (pz << 20) | (py << 10) | px
+
+    v = (C.c_double * 3)(-511.5, 0.0, 511.5)
+    assert O.lib.oracle_sub_voxel_coord(v, res) == pattern(0, 512, 1023) == 0xBFF80000
+    v = (C.c_double * 3)(0.25, -100.75, 300.49)
+    assert O.lib.oracle_sub_voxel_coord(v, res) == pattern(512, 411, 812)
+    v = (C.c_double * 3)(-600.0, 600.0, 0.0)  # outside the voxel: clamped to the grid's ends
+    assert O.lib.oracle_sub_voxel_coord(v, res) == pattern(0, 1023, 512)
+    # first sample of a voxel: the update IS the sample (count 0 -> mean + (v - mean) / 1)
+    v = (C.c_double * 3)(0.5, -100.5, 300.5)
+    first = O.lib.oracle_sub_voxel_update(0, 0, v, res)
+    assert first == pattern(512, 411, 812)
+    # second sample: decoded mean (0.5, -100.5, 300.5) moves half way to (10.5, -90.5, 290.5) = (5.5, -95.5, 295.5)
+    v = (C.c_double * 3)(10.5, -90.5, 290.5)
+    assert O.lib.oracle_sub_voxel_update(first, 1, v, res) == pattern(517, 416, 807)
+    # third sample with count 2: mean (5.5, -95.5, 295.5) + ((35.5, -95.5, 265.5) - mean) / 3 = (15.5, -95.5, 285.5)
+    v = (C.c_double * 3)(35.5, -95.5, 265.5)
+    assert O.lib.oracle_sub_voxel_update(pattern(517, 416, 807), 2, v, res) == pattern(527, 416, 797)
+    out = (C.c_double * 3)()
+    O.lib.oracle_sub_voxel_to_local(pattern(527, 416, 797), res, out)
+    assert tuple(out) == (15.5, -95.5, 285.5)
+
+
+def test_ndt_hit_satisfies_the_covariance_recursion_to_float_rounding():
+    """calculateHitWithCovariance (ohm/CovarianceVoxelCompute.h:301-375) implements, through a square-root factor,
+        P_new = n / (n + 1) * P + n / (n + 1)^2 * (z - mu)(z - mu)^T          (its own comment, :323-331)
+    Checked here as an identity in float64 on the oracle's single-step output -- C_new C_new^T against the formula
+    applied to C C^T -- to 1e-6 relative (the factor is stored in float32), for random factors, means, samples and
+    counts; the reference's own test only holds the end result of 10 000 steps to 1e-2."""
+    rng = np.random.default_rng(1153297050)
+    worst = 0.0
+    for trial in range(400):
+        L_ = np.tril(rng.uniform(-0.5, 0.5, (3, 3)))
+        L_[np.diag_indices(3)] = rng.uniform(0.05, 0.8, 3)
+        cov = np.array([L_[0, 0], L_[1, 0], L_[1, 1], L_[2, 0], L_[2, 1], L_[2, 2]], dtype=np.float32)
+        n = int(rng.integers(1, 5000))
+        mean = rng.uniform(-1, 1, 3)
+        z = mean + rng.normal(0, 0.3, 3)
+        Cm = np.array([[cov[0], 0, 0], [cov[1], cov[2], 0], [cov[3], cov[4], cov[5]]], dtype=np.float64)
+        P = Cm @ Cm.T
+        d = (z - mean).reshape(3, 1)
+        expected = n / (n + 1.0) * P + n / (n + 1.0) ** 2 * (d @ d.T)
+        covc = (C.c_float * 6)(*cov)
+        value = C.c_float(1.0)
+        reinit = O.lib.oracle_calculate_hit_with_covariance(covc, C.byref(value), (C.c_double * 3)(*z),
+                                                            (C.c_double * 3)(*mean), n, 0.4, float("inf"), 2.0, -1.386,
+                                                            100)
+        assert reinit == 0 and abs(value.value - 1.4) < 1e-6
+        out = np.array(list(covc), dtype=np.float64)
+        Cn = np.array([[out[0], 0, 0], [out[1], out[2], 0], [out[3], out[4], out[5]]])
+        assert out[0] > 0 and out[2] > 0 and out[5] > 0
+        got = Cn @ Cn.T
+        worst = max(worst, float(np.max(np.abs(got - expected)) / np.max(np.abs(expected))))
+    assert worst < 1e-6, worst
+    # (re)initialisation: count 0 starts from 0.1 * resolution * I and a zero sample-to-mean (:309-316, :333-341; :90-98)
+    covc = (C.c_float * 6)(*([9.0] * 6))
+    value = C.c_float(float("inf"))
+    reinit = O.lib.oracle_calculate_hit_with_covariance(covc, C.byref(value), (C.c_double * 3)(0.3, 0.2, 0.1),
+                                                        (C.c_double * 3)(0, 0, 0), 0, 0.4, float("inf"), 2.0, -1.386, 100)
+    assert reinit == 1 and value.value == np.float32(0.4)
+    # n = 0: unpackCovariance scales the fresh factor by 1, not sqrt(n / (n + 1)) (:157), and the sample-to-mean term by
+    # 0: the first sample leaves the initial factor 0.1 * resolution * I exactly
+    d = float(np.float32(0.1 * 2.0))
+    assert list(covc) == [d, 0.0, d, 0.0, 0.0, d]
