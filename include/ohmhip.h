@@ -226,6 +226,29 @@ int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
 int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, size_t element_count,
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
                                      size_t *integrated);
+/* Residency accounting, the counterpart of ohm::GpuCacheStats (ohmgpu/GpuCacheStats.h, GpuLayerCache::queryStats,
+ * ohmgpu/GpuLayerCache.h:334-339).  The whole map is resident, so the figures read: hits = regions a batch touched that
+ * were resident already, misses = regions a batch (or an upload) created, full = times the pool was exhausted and had to
+ * be re-allocated at twice the size (the reference evicts its least recently used region instead,
+ * ohmgpu/GpuLayerCache.cpp:530-584).  Cumulative since creation or the last reset. */
+typedef struct ohmhip_cache_stats
+{
+  uint64_t hits;
+  uint64_t misses;
+  uint64_t full;
+  uint32_t regions_resident;
+  uint32_t region_capacity;   /* regions the pool holds without growing                                   */
+  uint64_t bytes_per_region;  /* all enabled layers + per-region scratch                                    */
+  uint64_t memory_limit;      /* see ohmhip_map_set_memory_limit (0 = device memory is the limit)           */
+} ohmhip_cache_stats;
+int ohmhip_map_cache_stats(ohmhip_map_t map, ohmhip_cache_stats *stats, int reset);
+/* RESIDENCY LIMIT.  There is no eviction: a map that outgrows what it may allocate fails the batch that needs the
+ * extra regions with OHMHIP_ERR_CAPACITY and stays exactly as it was before that batch (the batch's region inserts are
+ * rolled back), so the caller can cull regions (ohmhip_map_remove_regions after reading them back) and present the
+ * batch again.  The limit is free device memory -- 288 GB of HBM3E hold about 2 million 32^3 occupancy regions -- or,
+ * when set, `bytes` for this map's region pool (the reference's gpu_mem_size, ohmgpu/GpuCache.h:90, bounds its cache
+ * the same way).  0 removes the limit. */
+int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
 /* Wait for all queued work (GpuMap::syncVoxels fence half, ohmgpu/GpuMap.cpp:308-324). */
 int ohmhip_map_sync(ohmhip_map_t map);
 int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);

@@ -59,6 +59,11 @@ class MergeStats(C.Structure):
                 ("payload_bytes", C.c_uint64), ("key_bytes", C.c_uint64), ("ms_total", C.c_float)]
 
 
+class CacheStats(C.Structure):
+    _fields_ = [("hits", C.c_uint64), ("misses", C.c_uint64), ("full", C.c_uint64), ("regions_resident", C.c_uint32),
+                ("region_capacity", C.c_uint32), ("bytes_per_region", C.c_uint64), ("memory_limit", C.c_uint64)]
+
+
 COMM_ID_BYTES = 128
 
 
@@ -126,6 +131,8 @@ _sigs = {
     "ohmhip_map_set_batch_coalescing": (C.c_int, [_vp, C.c_size_t]),
     "ohmhip_map_set_region_ownership": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_int]),
     "ohmhip_region_owner": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_uint32, _vp]),
+    "ohmhip_map_cache_stats": (C.c_int, [_vp, C.POINTER(CacheStats), C.c_int]),
+    "ohmhip_map_set_memory_limit": (C.c_int, [_vp, C.c_uint64]),
     "ohmhip_comm_unique_id": (C.c_int, [_vp]),
     "ohmhip_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
     "ohmhip_comm_destroy": (C.c_int, [_vp]),

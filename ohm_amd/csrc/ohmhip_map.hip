@@ -161,6 +161,8 @@ struct ohmhip_map_s
 
   ohmhip_batch_stats stats = {};
   bool stats_pending = false;
+  uint64_t cache_hits = 0, cache_misses = 0, cache_full = 0;  ///< ohmhip_map_cache_stats
+  uint64_t memory_limit = 0;                                   ///< ohmhip_map_set_memory_limit
 };
 
 namespace
@@ -240,6 +242,9 @@ size_t bytesPerRegionAllLayers(const ohmhip_map_config &c, int region_voxels)
   }
   // + miss count layer + hit mask
   b += 4 * size_t(region_voxels) + size_t((region_voxels + 31) / 32) * 4;
+  // + first-sample table (occupancy mode), traversal accumulator (traversal layer)
+  b += (c.mode == OHMHIP_MODE_OCCUPANCY) ? 4 * size_t(region_voxels) : 0;
+  b += (c.layers & (1u << OHMHIP_LID_TRAVERSAL)) ? 8 * size_t(region_voxels) : 0;
   return b;
 }
 
@@ -484,6 +489,37 @@ void dropHostRegions(ohmhip_map_t m, size_t keep)
   m->slot_keys_host.resize(keep);
 }
 
+/// Forget what a failed batch's set-up pass left in the region table and the per-batch scratch, without touching the
+/// pool: the hash is rebuilt from the committed slots.  (Used when the pool may not grow.)
+int rollbackTable(ohmhip_map_t m)
+{
+  hipStream_t s = m->stream;
+  const size_t hash_words = m->hash_capacity;
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+  OHMHIP_CHECK(hipMemsetAsync(m->d_keys, 0, sizeof(unsigned long long) * hash_words, s));
+  uint32_t *per_hash[] = { m->d_vals,       m->d_seg_count,    m->d_seg_cursor, m->d_hit_count,
+                           m->d_seg_offset, m->d_touched_flag, m->d_touched,    m->d_sort_list };
+  for (uint32_t *p : per_hash)
+  {
+    OHMHIP_CHECK(hipMemsetAsync(p, 0, sizeof(uint32_t) * hash_words, s));
+  }
+  const uint32_t keep = m->slots_committed;
+  if (m->slot_capacity > keep)
+  {
+    OHMHIP_CHECK(hipMemsetAsync(m->d_slot_keys + keep, 0, sizeof(uint64_t) * (m->slot_capacity - keep), s));
+  }
+  OHMHIP_CHECK(hipMemcpyAsync(m->d_n_slots, &keep, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  if (keep)
+  {
+    hipLaunchKernelGGL(k_rehash, dim3((keep + 255) / 256), dim3(256), 0, s, regionTable(m), keep);
+  }
+  OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, 2 * sizeof(BatchInfo), s));
+  m->info_clean = false;
+  m->spec_bucket_ok = false;
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+  return hipGetLastError();
+}
+
 /// Restore the region table after a batch that overflowed the pool: drop regions the failed batch inserted.
 int rollbackAndGrow(ohmhip_map_t m, uint32_t needed)
 {
@@ -492,14 +528,25 @@ int rollbackAndGrow(ohmhip_map_t m, uint32_t needed)
   {
     return OHMHIP_ERR_CAPACITY;
   }
-  // Check memory budget: refuse if the new pool cannot fit in free device memory.
+  // Check memory budget: refuse if the new pool cannot fit in free device memory, or in the map's own limit (the
+  // largest pool the limit allows is still tried when doubling overshoots it).
+  const size_t per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
+  if (m->memory_limit)
+  {
+    const uint64_t allowed = m->memory_limit / per_region;
+    if (allowed < needed)
+    {
+      return OHMHIP_ERR_CAPACITY;
+    }
+    cap = uint32_t(std::min<uint64_t>(cap, allowed));
+  }
   size_t free_b = 0, total_b = 0;
   OHMHIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-  const size_t need_b = bytesPerRegionAllLayers(m->config, m->mc.region_voxels) * size_t(cap);
-  if (need_b > free_b)
+  if (per_region * size_t(cap) > free_b)
   {
     return OHMHIP_ERR_CAPACITY;
   }
+  ++m->cache_full;
   return allocPool(m, cap, m->slots_committed);
 }
 
@@ -726,11 +773,15 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       const int err = rollbackAndGrow(m, std::max(info.n_slots, std::min(m->slot_capacity * 2u, kMaxRegionSlots)));
       if (err)
       {
-        return err;
+        // The pool may not grow (memory limit / device memory / slot field): the batch fails, the map stays as it was.
+        const int rollback_err = rollbackTable(m);
+        return rollback_err ? rollback_err : err;
       }
       continue;
     }
 
+    m->cache_misses += info.n_slots - m->slots_committed;
+    m->cache_hits += info.n_touched - std::min(info.n_touched, info.n_slots - m->slots_committed);
     m->slots_committed = info.n_slots;
     if (speculated && (info.n_segments > spec_seg_cap || info.max_region_hits > kSortRegionHits))
     {
@@ -1885,6 +1936,41 @@ try
   OHMHIP_CHECK(hipEventElapsedTime(&sort_ms, tev[1], tev[2]));
   OHMHIP_CHECK(hipEventElapsedTime(&apply_ms, tev[3], tev[4]));
   ms[3] = sort_ms + apply_ms;
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_cache_stats(ohmhip_map_t m, ohmhip_cache_stats *stats, int reset)
+try
+{
+  OHMHIP_SETTLE(m);
+  if (!m || !stats)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  stats->hits = m->cache_hits;
+  stats->misses = m->cache_misses;
+  stats->full = m->cache_full;
+  stats->regions_resident = m->slots_committed;
+  stats->region_capacity = m->slot_capacity;
+  stats->bytes_per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
+  stats->memory_limit = m->memory_limit;
+  if (reset)
+  {
+    m->cache_hits = m->cache_misses = m->cache_full = 0;
+  }
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_set_memory_limit(ohmhip_map_t m, uint64_t bytes)
+try
+{
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  m->memory_limit = bytes;
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH

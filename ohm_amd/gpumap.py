@@ -403,6 +403,18 @@ class GpuMap(RayMapper):
             L.check(L.lib.ohmhip_map_clear_dirty(self._handle), "clear_dirty")
         self.wait()
 
+    def cacheStats(self, reset=False):
+        """GpuLayerCache::queryStats (ohmgpu/GpuLayerCache.h:334-339) for the resident region pool: hits / misses / full
+        plus the pool's size (include/ohmhip.h: ohmhip_cache_stats)."""
+        st = L.CacheStats()
+        L.check(L.lib.ohmhip_map_cache_stats(self._handle, C.byref(st), 1 if reset else 0), "cache_stats")
+        return {name: getattr(st, name) for name, _ in L.CacheStats._fields_}
+
+    def setMemoryLimit(self, nbytes):
+        """Bound the region pool (include/ohmhip.h "RESIDENCY LIMIT"): a batch that needs more fails with
+        OHMHIP_ERR_CAPACITY and leaves the map as it was.  0 removes the bound."""
+        L.check(L.lib.ohmhip_map_set_memory_limit(self._handle, int(nbytes)), "set_memory_limit")
+
     def setBatchCoalescing(self, min_rays):
         """Collect consecutive small host batches and run them as one device batch of >= min_rays rays
         (include/ohmhip.h: ohmhip_map_set_batch_coalescing; on by default with 65536).  0 turns it off."""

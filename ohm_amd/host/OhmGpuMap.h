@@ -555,6 +555,19 @@ public:
     return removed;
   }
 
+  /// GpuLayerCache::queryStats (ohmgpu/GpuLayerCache.h:334-339): hits / misses / full of the resident region pool
+  /// (ohmhip_cache_stats); @p reset clears the counters as GpuLayerCache::resetStats() does.
+  ohmhip_cache_stats queryStats(bool reset = false) const
+  {
+    ohmhip_cache_stats st{};
+    OHMHIP_GPUAPICHECK(ohmhip_map_cache_stats(handle_, &st, reset ? 1 : 0));
+    return st;
+  }
+
+  /// Bound the region pool in bytes (include/ohmhip.h "RESIDENCY LIMIT"; the reference's gpu_mem_size): a batch that
+  /// needs more fails -- integrateRays() returns 0 -- and leaves the map as it was.  0 removes the bound.
+  void setMemoryLimit(uint64_t bytes) { OHMHIP_GPUAPICHECK(ohmhip_map_set_memory_limit(handle_, bytes)); }
+
   /// Not in the reference: run consecutive small integrateRays() batches as one device batch of at least @p min_rays
   /// rays (see ohmhip_map_set_batch_coalescing; on by default with 65536); 0 turns it off.
   void setBatchCoalescing(size_t min_rays) { OHMHIP_GPUAPICHECK(ohmhip_map_set_batch_coalescing(handle_, min_rays)); }

@@ -273,3 +273,38 @@ def test_non_default_probabilities_clamps_and_saturation(gpu, sat_min, sat_max):
     gm.syncVoxels()
     stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
     assert_parity(stats)
+
+
+def test_cache_stats_and_memory_limit(gpu):
+    """ohmhip_map_cache_stats (the GpuCacheStats counterpart) and the residency limit: a batch that would outgrow the
+    map's memory limit fails with OHMHIP_ERR_CAPACITY and leaves the map exactly as it was."""
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm = GpuMap(map_, region_capacity=64)
+    gm.setBatchCoalescing(0)
+    om = make_oracle(map_)
+    near = synth.rays_c0(n=4000, length=3.0, seed=11)
+    assert gm.integrateRays(near) == near.shape[0]
+    om.integrate_occupancy(near)
+    st = gm.cacheStats()
+    n_first = gm.stats()["regions_resident"]
+    assert st["misses"] == n_first and st["hits"] == 0 and st["full"] == 0 and st["region_capacity"] == 64
+    assert gm.integrateRays(near) == near.shape[0]
+    om.integrate_occupancy(near)
+    st = gm.cacheStats(reset=True)
+    assert st["misses"] == n_first and st["hits"] == n_first  # second pass: every region was resident
+    assert gm.cacheStats()["hits"] == 0
+    # a limit that holds the current pool but not a doubled one
+    gm.setMemoryLimit(st["bytes_per_region"] * 100)
+    far = synth.rays_c0(n=6000, length=12.0, seed=12)  # needs far more than 100 regions
+    assert gm.integrateRays(far) == 0  # GpuMap::integrateRays reports failure as 0 points
+    assert gm._last_error == ohm_amd._lib.ERR_CAPACITY
+    assert gm.cacheStats()["regions_resident"] == n_first
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))  # untouched by the failed batch
+    # lifting the limit lets the same batch through (the pool grows: "full" counts it)
+    gm.setMemoryLimit(0)
+    assert gm.integrateRays(far) == far.shape[0]
+    om.integrate_occupancy(far)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+    assert gm.cacheStats()["full"] >= 1
