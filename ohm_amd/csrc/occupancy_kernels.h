@@ -267,6 +267,10 @@ __device__ inline void waveMatch(bool has, uint32_t value, unsigned lane, int &l
 // the per-region counters of the regions around a sensor are otherwise hit by every wave of the launch, and atomics on
 // one address serialise at the memory side (that, not arithmetic, dominated the first version of these kernels).
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef OHMHIP_BIN_WAVES_PER_EU
+#define OHMHIP_BIN_WAVES_PER_EU 4
+#endif
+#define OHMHIP_BIN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(OHMHIP_BIN_WAVES_PER_EU, 8)))
 constexpr int kBinThreads = 512;        ///< workgroup size of the binning kernels for large batches (launch bound)
 constexpr int kBinRaysPerBlock = 1024;  ///< rays per binning workgroup for large batches; small batches use fewer so the
                                         ///< launch still spreads over the CUs (the host picks both per batch)
@@ -608,7 +612,7 @@ __device__ inline void buildRayOrder(RayOrder &order, uint32_t n_local, BinOf bi
 // ---------------------------------------------------------------------------------------------------------------------
 // k_ray_setup: per-ray line-walk set-up + per-region segment counts.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBinThreads)
+__global__ void __launch_bounds__(kBinThreads) OHMHIP_BIN_OCCUPANCY
   k_ray_setup(MapConst mc, RegionTable rt, BatchScratch bs, const double *__restrict__ rays, uint32_t n_rays,
               unsigned ray_flags, RayWalk *__restrict__ walks, uint32_t rays_per_block, uint32_t tab_mask)
 {
@@ -1018,7 +1022,7 @@ __global__ void __launch_bounds__(1024)
 // Three steps per workgroup: count its segments per region in LDS, reserve one contiguous range per region with a
 // single returning atomic, then re-enumerate and scatter through LDS cursors.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBinThreads)
+__global__ void __launch_bounds__(kBinThreads) OHMHIP_BIN_OCCUPANCY
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
             uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits, uint32_t rays_per_block,
@@ -1452,13 +1456,19 @@ __device__ inline uint32_t subVoxelUpdate(uint32_t coord, uint32_t point_count, 
 constexpr int kWalkThreads = 1024;
 constexpr int kWalkWaves = kWalkThreads / 64;
 constexpr int kQueueCap = 128;     ///< deferred events per wave (8 B each)
-constexpr int kLdsHits = 6144;     ///< a region's sample list is staged in LDS when it has at most this many samples
+#ifndef OHMHIP_LDS_HITS
+#define OHMHIP_LDS_HITS 6144
+#endif
+constexpr int kLdsHits = OHMHIP_LDS_HITS;     ///< a region's sample list is staged in LDS when it has at most this many samples
 constexpr uint32_t kIndexShift = 5;  ///< staged samples are indexed by voxel index >> kIndexShift ...
 constexpr uint32_t kIndexBuckets = (1u << kHitVoxelBits) >> kIndexShift;  ///< ... in this many buckets (+ 1 end entry)
 constexpr int kRefillMinIdle = 20; ///< refill a wave once this many lanes are idle
 constexpr uint32_t kTileFlag = 0x8000u;       ///< mask flag inside a u16 tile entry
 constexpr uint32_t kTileCountMask = 0x7fffu;  ///< count bits of a u16 tile entry (a chunk adds <= kMaxChunkSegments)
-constexpr uint32_t kMaxChunkSegments = 8192;  ///< bounded by the 15-bit counters and by the LDS order array
+#ifndef OHMHIP_MAX_CHUNK_SEGMENTS
+#define OHMHIP_MAX_CHUNK_SEGMENTS 8192
+#endif
+constexpr uint32_t kMaxChunkSegments = OHMHIP_MAX_CHUNK_SEGMENTS;  ///< bounded by the 15-bit counters and by the LDS order array
 constexpr uint32_t kTraceChunks = 4096;  ///< debug trace: records kept per launch
 constexpr uint32_t kTraceWords = 32;     ///< debug trace: u64 words per record
 constexpr uint32_t kLengthClasses = 128;      ///< segment length histogram bins (lengths above the last bin share it)

@@ -178,7 +178,11 @@ struct BatchInfo
   uint32_t n_hit_regions;    ///< regions receiving samples (length of the sort list)
 };
 
+#ifdef OHMHIP_MAX_CHUNK_SEGMENTS
+constexpr uint32_t kChunkSegments = OHMHIP_MAX_CHUNK_SEGMENTS;
+#else
 constexpr uint32_t kChunkSegments = 8192;
+#endif
 constexpr uint64_t kKeyOccupied = 1ull << 63;
 constexpr uint32_t kSlotUnassigned = 0xffffffffu;
 
