@@ -120,3 +120,14 @@ def test_cpp_set_ray_filter_clip_box(gpu):
         kept[1::2] = ends[keep]
         om.integrate_occupancy(kept, filter_flags=flags[keep])
     assert_parity(compare_maps(om.chunks(), gpu_chunks, ["occupancy"], exact_float=True))
+
+
+def test_gputil_hip_backend_through_the_reference_headers(gpu):
+    """ohm_amd/host/ref_adaptor/gputil_hip: gputil::Device / Queue / Event as the REFERENCE's headers declare them,
+    implemented over the C ABI.  The check program is compiled (in the build container, where the reference checkout
+    is) against those headers in place and runs here: device enumeration and selection, queue creation, event
+    marking, reference counting, waits and callbacks."""
+    binary = os.path.join(os.path.dirname(DRIVER), "gputil_hip_check")
+    assert os.path.exists(binary), "gputil_hip_check missing: run __graft_entry__.build() where /root/reference exists"
+    res = subprocess.run([binary], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "GPUTIL_HIP_OK" in res.stdout, (res.returncode, res.stdout, res.stderr)
