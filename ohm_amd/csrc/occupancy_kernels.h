@@ -267,10 +267,6 @@ __device__ inline void waveMatch(bool has, uint32_t value, unsigned lane, int &l
 // the per-region counters of the regions around a sensor are otherwise hit by every wave of the launch, and atomics on
 // one address serialise at the memory side (that, not arithmetic, dominated the first version of these kernels).
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef OHMHIP_BIN_WAVES_PER_EU
-#define OHMHIP_BIN_WAVES_PER_EU 4
-#endif
-#define OHMHIP_BIN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(OHMHIP_BIN_WAVES_PER_EU, 8)))
 constexpr int kBinThreads = 512;        ///< workgroup size of the binning kernels for large batches (launch bound)
 constexpr int kBinRaysPerBlock = 1024;  ///< rays per binning workgroup for large batches; small batches use fewer so the
                                         ///< launch still spreads over the CUs (the host picks both per batch)
@@ -612,7 +608,9 @@ __device__ inline void buildRayOrder(RayOrder &order, uint32_t n_local, BinOf bi
 // ---------------------------------------------------------------------------------------------------------------------
 // k_ray_setup: per-ray line-walk set-up + per-region segment counts.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBinThreads) OHMHIP_BIN_OCCUPANCY
+// (6 waves per SIMD: the kernel sits at 80-odd VGPRs, right at an allocation step -- 80 registers give a wave per SIMD
+// more than 88 do, and the kernel is latency bound)
+__global__ void __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
   k_ray_setup(MapConst mc, RegionTable rt, BatchScratch bs, const double *__restrict__ rays, uint32_t n_rays,
               unsigned ray_flags, RayWalk *__restrict__ walks, uint32_t rays_per_block, uint32_t tab_mask)
 {
@@ -1022,7 +1020,7 @@ __global__ void __launch_bounds__(1024)
 // Three steps per workgroup: count its segments per region in LDS, reserve one contiguous range per region with a
 // single returning atomic, then re-enumerate and scatter through LDS cursors.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBinThreads) OHMHIP_BIN_OCCUPANCY
+__global__ void __launch_bounds__(kBinThreads)
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
             uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits, uint32_t rays_per_block,
