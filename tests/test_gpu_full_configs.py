@@ -1,10 +1,10 @@
 """-m gpu: the BASELINE.json configurations at FULL size.
 
 C1 (1 M lidar rays, 0.1 m) and C2 (NDT, 1 M rays, 0.2 m) are compared voxel-for-voxel with the CPU oracle (a few
-seconds of CPU each).  C3 (TSDF, 0.05 m, 4 M rays) is checked against the oracle on its first revolution (1 M rays) and
-at full size through size-independent properties: the exact voxel-visit count (closed form from the voxel keys), and
-batch-split invariance (integrating in one call or in four must give bit-identical maps because the device applies
-every voxel's events in ray order)."""
+seconds of CPU each).  C3 (TSDF, 0.05 m, 4 M rays, 2.7 x 10^9 voxel visits) is compared voxel-for-voxel with the oracle
+too (about a minute of CPU) and additionally checked through size-independent properties: the exact voxel-visit count
+(closed form from the voxel keys), and batch-split invariance (integrating in one call or in four must give
+bit-identical maps because the device applies every voxel's events in ray order)."""
 import numpy as np
 import pytest
 
@@ -49,27 +49,22 @@ def test_c2_ndt_full_vs_oracle(gpu):
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean", "covariance"], rel=1e-5))
 
 
-def test_c3_tsdf_first_revolution_vs_oracle_and_full_properties(gpu):
+def test_c3_tsdf_full_vs_oracle_and_properties(gpu):
     rays = synth.rays_c3()
     assert rays.shape[0] == 8_000_000
-    first = rays[:2_000_000]
-    map_ = OccupancyMap(0.05, layers=("tsdf",))
-    gm = GpuTsdfMap(map_, gpu_mem_size=16 << 30)
-    assert gm.integrateRays(first) == first.shape[0]
-    gm.syncVoxels()
-    om = make_oracle(map_)
-    om.integrate_tsdf(first)
-    assert om.visit_count() == gm.stats()["voxel_visits"]
-    assert_parity(compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True))
-    del om
-
-    # full size: one call vs four calls must agree bit for bit, and the visit count must match the closed form
+    # full size, one call: bit exact against the CPU oracle, visit count equal to the closed form
     map_a = OccupancyMap(0.05, layers=("tsdf",))
     gm_a = GpuTsdfMap(map_a, gpu_mem_size=16 << 30)
     assert gm_a.integrateRays(rays) == rays.shape[0]
     assert gm_a.stats()["voxel_visits"] == expected_visits(rays, 0.05, True)
     gm_a.syncVoxels()
     gm_a.close()
+    om = make_oracle(map_a)
+    om.integrate_tsdf(rays)
+    assert om.visit_count() == expected_visits(rays, 0.05, True)
+    assert_parity(compare_maps(om.chunks(), map_a.chunks, ["tsdf"], exact_float=True))
+    del om
+    # one call vs four calls must agree bit for bit
     map_b = OccupancyMap(0.05, layers=("tsdf",))
     gm_b = GpuTsdfMap(map_b, gpu_mem_size=16 << 30)
     for i in range(0, rays.shape[0], 2_000_000):
