@@ -120,7 +120,8 @@ enum ohmhip_map_mode
 /* Ray flags, bit-compatible with ohm::RayFlag (ohm/RayFlag.h:16-60). */
 #define OHMHIP_RF_DEFAULT 0u
 #define OHMHIP_RF_END_POINT_AS_FREE (1u << 0)
-#define OHMHIP_RF_STOP_ON_FIRST_OCCUPIED (1u << 1) /* order-dependent across voxels: OHMHIP_ERR_UNSUPPORTED */
+#define OHMHIP_RF_STOP_ON_FIRST_OCCUPIED (1u << 1) /* exact, via per-ray stop iteration over the sorted visits of the
+                                                      batch (slow path); refused with a traversal layer */
 #define OHMHIP_RF_EXCLUDE_ORIGIN (1u << 2)
 #define OHMHIP_RF_EXCLUDE_SAMPLE (1u << 3)
 #define OHMHIP_RF_EXCLUDE_RAY (1u << 4)

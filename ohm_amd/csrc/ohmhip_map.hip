@@ -115,6 +115,7 @@ struct ohmhip_map_s
   /// Traversal layer only: per-voxel fixed-point sum of a batch's ray lengths (zero between batches).
   unsigned long long *d_traversal_acc = nullptr;
   DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;
+  DevBuf stop_a, stop_b;  ///< kRfStopOnFirstOccupied: per-ray stop positions (current / candidate)
   uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
@@ -688,7 +689,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     batch_chunk_segments /= 2;
   }
   const int mode = m->config.mode;
-  const bool occupancy_mode = mode == OHMHIP_MODE_OCCUPANCY;
+  // kRfStopOnFirstOccupied: no counting shortcut exists (replay_kernels.h, k_stop_replay): such a batch takes the
+  // general event route of NDT / TSDF -- every visit an event, sorted per voxel -- with its own replay.
+  const bool stop_mode = mode == OHMHIP_MODE_OCCUPANCY && (ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED) != 0;
+  const bool occupancy_mode = mode == OHMHIP_MODE_OCCUPANCY && !stop_mode;
   const bool ndt_mode = mode == OHMHIP_MODE_NDT_OM || mode == OHMHIP_MODE_NDT_TM;
   const bool tsdf_mode = mode == OHMHIP_MODE_TSDF;
   if (ndt_mode)
@@ -914,7 +918,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         // applied straight from LDS by the first launch (the repeat only regenerates their events) and the traversal
         // layer has its sums already.
         wa.rewalk = (walk_attempt > 0 && (direct_occ || tsdf_mode)) ? 1 : 0;
-        wa.flag_all = (tsdf_mode && m->mc.tsdf_dropoff > 0) ? 1 : 0;
+        wa.flag_all = ((tsdf_mode && m->mc.tsdf_dropoff > 0) || stop_mode) ? 1 : 0;
         const bool walk_traversal = sec.traversal != nullptr && walk_attempt == 0;
         // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited) or the
         // traversal layer needs the exit range of an end voxel that is part of the walk.  (An end voxel that is walked --
@@ -1030,7 +1034,47 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                            sorted, uint32_t(total), heads, n_heads);
         replay_blocks = uint32_t(std::min<size_t>(replay_blocks, size_t(m->walk_workgroups) * 32u));
       }
-      if (ndt_mode)
+      if (stop_mode)
+      {
+        // Per-ray stop positions by iteration (k_stop_replay): a scan that moves no ray's stop is the sequential result.
+        OHMHIP_CHECK(m->stop_a.ensure(sizeof(uint32_t) * size_t(n_rays), false, s));
+        OHMHIP_CHECK(m->stop_b.ensure(sizeof(uint32_t) * size_t(n_rays), false, s));
+        uint32_t *stop = static_cast<uint32_t *>(m->stop_a.ptr);
+        uint32_t *stop_next = static_cast<uint32_t *>(m->stop_b.ptr);
+        OHMHIP_CHECK(hipMemsetAsync(stop, 0xff, sizeof(uint32_t) * size_t(n_rays), s));
+        OHMHIP_CHECK(hipMemsetAsync(stop_next, 0xff, sizeof(uint32_t) * size_t(n_rays), s));
+        uint32_t *d_changed = m->d_event_count + 3;
+        const RayWalk *walks = static_cast<const RayWalk *>(m->walks.ptr);
+        float *occ = static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]);
+        uint32_t *mean_layer = static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]);
+        bool settled = false;
+        for (uint64_t scan = 0; scan <= uint64_t(n_rays) && !settled; ++scan)
+        {
+          OHMHIP_CHECK(hipMemsetAsync(d_changed, 0, sizeof(uint32_t), s));
+          hipLaunchKernelGGL((k_stop_replay<false>), dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
+                             uint32_t(total), ray_flags, walks, stop, stop_next, d_rays, occ, mean_layer, sec);
+          hipLaunchKernelGGL(k_stop_advance, dim3(ray_blocks), dim3(256), 0, s, stop, stop_next, n_rays, d_changed);
+          uint32_t changed = 0;
+          OHMHIP_CHECK(hipMemcpyAsync(&changed, d_changed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+          OHMHIP_CHECK(hipStreamSynchronize(s));
+          settled = changed == 0;
+        }
+        if (!settled)
+        {
+          return OHMHIP_ERR_INTERNAL;  // (cannot happen: every scan fixes at least one more ray)
+        }
+        hipLaunchKernelGGL((k_stop_replay<true>), dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
+                           uint32_t(total), ray_flags, walks, stop, stop_next, d_rays, occ, mean_layer, sec);
+        if (info.n_touched)
+        {
+          // nothing was counted (every visit was an event): this clears the sample mask and the per-batch scratch
+          hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
+                             batchScratch(m), ray_flags, m->d_miss_counts, m->d_hit_mask, occ, 1,
+                             static_cast<uint32_t *>(nullptr), 0u, 1, static_cast<float *>(nullptr),
+                             static_cast<unsigned long long *>(nullptr));
+        }
+      }
+      else if (ndt_mode)
       {
         const bool tm = mode == OHMHIP_MODE_NDT_TM;
         hipLaunchKernelGGL(k_replay_ndt, dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
@@ -1141,6 +1185,7 @@ int growRaySlot(ohmhip_map_t m, ohmhip_map_s::RaySlot &sl, size_t rays)
 int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_count, const float *d_intensities,
                         const double *d_timestamps, unsigned ray_flags, size_t *integrated,
                         const unsigned char *d_filter_flags = nullptr);
+int validateBatchRequest(ohmhip_map_t m, unsigned ray_flags);
 
 /// Launch what the filling slot holds: H2D on the copy stream, the batch on the compute stream behind it.
 int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
@@ -1459,6 +1504,8 @@ try
   m->wg_regions.release();
   m->wg_region_count.release();
   m->group_heads.release();
+  m->stop_a.release();
+  m->stop_b.release();
   m->merge_slots.release();
   m->merge_keys_dev.release();
   m->merge_delta.release();
@@ -1564,10 +1611,7 @@ int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_cou
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
-  if (ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED)
-  {
-    return OHMHIP_ERR_UNSUPPORTED;
-  }
+  OHMHIP_CHECK(validateBatchRequest(m, ray_flags));
   const size_t n_rays = element_count / 2;
   if (n_rays == 0)
   {
@@ -1649,8 +1693,11 @@ namespace
 /// run later with a collected batch.
 int validateBatchRequest(ohmhip_map_t m, unsigned ray_flags)
 {
-  if (ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED)
+  if ((ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED) && m->config.mode == OHMHIP_MODE_OCCUPANCY &&
+      m->layers[OHMHIP_LID_TRAVERSAL])
   {
+    // A stopped ray keeps adding its path lengths to the traversal layer on the CPU (ohm/RayMapperOccupancy.cpp:
+    // 166-173 runs for null updates too); the stop replay carries no ray ranges.  Not combined here.
     return OHMHIP_ERR_UNSUPPORTED;
   }
   switch (m->config.mode)

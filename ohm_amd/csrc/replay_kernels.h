@@ -320,6 +320,159 @@ __global__ void __launch_bounds__(256)
 /// float rounding of (sdf + trunc * w) / (w + 1) for w <= 1e4 (needs > 2e-3 relative margin; 1 % is used).
 constexpr float kTsdfFreeMargin = 1.01f;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// kRfStopOnFirstOccupied (ohm/RayFlag.h:28; ohm/RayMapperOccupancy.cpp:105-193, 222-239).
+//
+// CPU semantics: a ray is walked from its origin; every voxel gets its miss update until a voxel is met whose value
+// BEFORE this ray's update is occupied (observed and >= the threshold): that voxel still gets its miss, every later
+// voxel of the ray a null update, and the ray's sample is not applied.  Whether a voxel is occupied when ray r
+// reaches it depends on what the rays before r did to it -- which depends on where THOSE rays stopped.  There is no
+// per-voxel counting shortcut, so such a batch takes the fully general route: every visit of the batch is an event
+// (WalkArgs::flag_all), events and samples are sorted per voxel in ray order, and the per-ray stop positions are found
+// by iteration:
+//   scan (k_stop_replay<false>): replay every voxel with the current stop estimates deciding which visits are live;
+//     for every visit -- live or not -- of ray r to a voxel that is occupied at that moment, r's stop candidate is
+//     lowered to the visit's position along the ray (the Manhattan distance of the voxel from the ray's start voxel,
+//     which is the visit's index in the walk).
+//   A ray's stop depends only on the stops of rays before it, so after k scans the first k rays are final and a scan
+//   that changes nothing has produced the sequential result; real batches settle in a handful of scans.
+//   commit (k_stop_replay<true>): the same replay with the final stops, writing the layers.
+// Slow next to the counting path (every visit is sorted), bit-identical to the CPU mapper.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kNoStop = 0xffffffffu;
+
+template <bool kCommit>
+__global__ void __launch_bounds__(128)
+  k_stop_replay(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
+                unsigned ray_flags, const RayWalk *__restrict__ walks, const uint32_t *__restrict__ stop,
+                uint32_t *__restrict__ stop_next, const double *__restrict__ rays, float *__restrict__ occupancy,
+                uint32_t *__restrict__ mean, SecondaryLayers sec)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_events; i += gridDim.x * blockDim.x)
+  {
+    const unsigned long long key = sorted[i];
+    const unsigned long long group = key >> kHitRayBits;
+    if (key == kHitInvalid || (i > 0 && (sorted[i - 1] >> kHitRayBits) == group))
+    {
+      continue;  // not the head of its voxel group
+    }
+    const uint32_t slot = uint32_t(key >> kHitSlotShift);
+    const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
+    const size_t gi = size_t(slot) * size_t(mc.region_voxels) + vi;
+    int16_t rk[3];
+    unpackRegionKey(rt.slot_keys[slot], rk);
+    const int lx = int(vi % uint32_t(mc.dim[0]));
+    const int ly = int((vi / uint32_t(mc.dim[0])) % uint32_t(mc.dim[1]));
+    const int lz = int(vi / uint32_t(mc.dim[0] * mc.dim[1]));
+    const int gx = int(rk[0]) * mc.dim[0] + lx;
+    const int gy = int(rk[1]) * mc.dim[1] + ly;
+    const int gz = int(rk[2]) * mc.dim[2] + lz;
+    const float inf = __int_as_float(0x7f800000);
+    float x = occupancy[gi];
+    uint32_t mcoord = 0, mcount = 0;
+    double centre[3] = { 0, 0, 0 };
+    uint32_t packed_normal = 0;
+    uint32_t last_sample_ray = kNoStop;
+    if (kCommit)
+    {
+      if (mean)
+      {
+        mcoord = mean[2 * gi];
+        mcount = mean[2 * gi + 1];
+        centre[0] = voxelCentreAxis(mc, 0, rk[0], lx);
+        centre[1] = voxelCentreAxis(mc, 1, rk[1], ly);
+        centre[2] = voxelCentreAxis(mc, 2, rk[2], lz);
+      }
+      packed_normal = sec.incident ? sec.incident[gi] : 0u;
+    }
+    for (uint32_t j = i; j < n_events; ++j)
+    {
+      const unsigned long long kj = sorted[j];
+      if ((kj >> kHitRayBits) != group)
+      {
+        break;
+      }
+      const uint32_t ray = uint32_t((kj & kEvRayMask) >> kEvRayShift);
+      const bool is_sample = (kj & 1ull) != 0;
+      const uint32_t ray_stop = stop[ray];
+      if (is_sample)
+      {
+        if (ray_stop != kNoStop)
+        {
+          continue;  // the ray stopped on its way: no sample update (ohm/RayMapperOccupancy.cpp:234)
+        }
+        x = occHit(mc, ray_flags, x);
+        if (kCommit)
+        {
+          last_sample_ray = ray;
+          if (sec.incident)
+          {
+            const float dir[3] = { float(rays[size_t(ray) * 6 + 0] - rays[size_t(ray) * 6 + 3]),
+                                   float(rays[size_t(ray) * 6 + 1] - rays[size_t(ray) * 6 + 4]),
+                                   float(rays[size_t(ray) * 6 + 2] - rays[size_t(ray) * 6 + 5]) };
+            packed_normal = updateIncidentNormal(packed_normal, dir, mean ? mcount : 0u);
+          }
+          if (mean)
+          {
+            const double local[3] = { rays[size_t(ray) * 6 + 3] - centre[0], rays[size_t(ray) * 6 + 4] - centre[1],
+                                      rays[size_t(ray) * 6 + 5] - centre[2] };
+            mcoord = subVoxelUpdate(mcoord, mcount, local, mc.resolution);
+            ++mcount;
+          }
+        }
+        continue;
+      }
+      // a visit of the ray part: its index in the ray's walk
+      const int *g0 = walks[ray].g0;
+      const uint32_t position = uint32_t(abs(gx - g0[0]) + abs(gy - g0[1]) + abs(gz - g0[2]));
+      const bool occupied = x != inf && x >= mc.threshold_value;
+      if (!kCommit && occupied)
+      {
+        atomicMin(&stop_next[ray], position);
+      }
+      if (position <= ray_stop)
+      {
+        x = occMiss(mc, ray_flags, x);  // live: at or before the ray's stopping voxel
+      }
+    }
+    if (kCommit)
+    {
+      occupancy[gi] = x;
+      if (mean)
+      {
+        mean[2 * gi] = mcoord;
+        mean[2 * gi + 1] = mcount;
+      }
+      if (sec.incident)
+      {
+        sec.incident[gi] = packed_normal;
+      }
+      if (sec.touch_time && sec.timestamps && last_sample_ray != kNoStop)
+      {
+        sec.touch_time[gi] = encodeVoxelTouchTime(sec.time_base, sec.timestamps[last_sample_ray]);
+      }
+    }
+  }
+}
+
+/// stop <- stop_next, stop_next <- "no stop"; *changed is set when any ray's stop moved.
+__global__ void __launch_bounds__(256)
+  k_stop_advance(uint32_t *__restrict__ stop, uint32_t *__restrict__ stop_next, uint32_t n_rays,
+                 uint32_t *__restrict__ changed)
+{
+  const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray < n_rays)
+  {
+    const uint32_t next = stop_next[ray];
+    if (next != stop[ray])
+    {
+      stop[ray] = next;
+      *changed = 1u;
+    }
+    stop_next[ray] = kNoStop;
+  }
+}
+
 /// TSDF pre-pass, one lane per ray: flag every voxel near the ray's end whose sdf is below the free-space margin.
 /// Those voxels (and, persistently, every voxel ever flagged) take the ordered replay path.
 __global__ void __launch_bounds__(256)

@@ -308,3 +308,39 @@ def test_cache_stats_and_memory_limit(gpu):
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
     assert gm.cacheStats()["full"] >= 1
+
+
+@pytest.mark.parametrize("extra", [0, int(RayFlag.kRfEndPointAsFree), int(RayFlag.kRfExcludeOrigin)])
+def test_stop_on_first_occupied(gpu, extra):
+    """kRfStopOnFirstOccupied (ohm/RayMapperOccupancy.cpp:105-193): a ray stops adjusting voxels after the first voxel
+    that is occupied when the ray reaches it, and then does not apply its sample.  Whether a voxel is occupied at that
+    moment depends on where the earlier rays of the batch stopped: the device finds the stops by iteration
+    (replay_kernels.h, k_stop_replay).  Bit exact, over several batches so that walls built by earlier batches -- and by
+    earlier rays of the same batch -- stop later rays."""
+    flags = int(RayFlag.kRfStopOnFirstOccupied) | extra
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    # a room scanned from two positions: rays from the second position run into the walls the first one built, and
+    # within a batch rays graze voxels that earlier rays of the same batch have just made occupied
+    batches = [synth.rays_c2(n=6000, seed=31), synth.rays_c2(n=6000, seed=32, origin=(3.05, -2.95, 0.55)),
+               synth.random_rays(3000, extent=8.0, seed=33, origin_spread=4.0), synth.rays_c2(n=6000, seed=31)]
+    for k, rays in enumerate(batches):
+        f = flags if k else 0  # first batch builds the scene without the flag
+        assert gm.integrateRays(rays, ray_update_flags=f) == rays.shape[0]
+        om.integrate_occupancy(rays, flags=f)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
+    # the flag did something: the same rays without it give another map
+    plain = make_oracle(map_)
+    for rays in batches:
+        plain.integrate_occupancy(rays, flags=extra)
+    assert any(not np.array_equal(plain.chunks()[key]["occupancy"].view(np.uint32), c["occupancy"].view(np.uint32))
+               for key, c in om.chunks().items() if key in plain.chunks())
+
+
+def test_stop_on_first_occupied_with_traversal_layer_is_refused(gpu):
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "traversal"))
+    gm = GpuMap(map_)
+    with pytest.raises(ohm_amd.OhmHipError):
+        gm.integrateRays(synth.rays_c0(n=100, length=2.0), ray_update_flags=int(RayFlag.kRfStopOnFirstOccupied))
