@@ -246,8 +246,8 @@ int ohmhip_map_cache_stats(ohmhip_map_t map, ohmhip_cache_stats *stats, int rese
 /* RESIDENCY LIMIT.  There is no eviction: a map that outgrows what it may allocate fails the batch that needs the
  * extra regions with OHMHIP_ERR_CAPACITY and stays exactly as it was before that batch (the batch's region inserts are
  * rolled back), so the caller can cull regions (ohmhip_map_remove_regions after reading them back) and present the
- * batch again.  The limit is free device memory -- 288 GB of HBM3E hold about 2 million 32^3 occupancy regions -- or,
- * when set, `bytes` for this map's region pool (the reference's gpu_mem_size, ohmgpu/GpuCache.h:90, bounds its cache
+ * batch again.  The limit is free device memory -- 288 GB of HBM3E hold about 1 million 32^3 occupancy-only regions
+ * (8.1 B per voxel with scratch) -- or, when set, `bytes` for this map's region pool (the reference's gpu_mem_size, ohmgpu/GpuCache.h:90, bounds its cache
  * the same way).  0 removes the limit. */
 int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
 /* Wait for all queued work (GpuMap::syncVoxels fence half, ohmgpu/GpuMap.cpp:308-324). */

@@ -1124,31 +1124,6 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   return OHMHIP_ERR_CAPACITY;
 }
 
-/// memcpy split over a few host threads for large blocks (a single core copies ~10 GB/s, PCIe Gen5 moves ~55).
-void parallelCopy(void *dst, const void *src, size_t bytes)
-{
-  constexpr size_t kPerThread = size_t(4) << 20;
-  const unsigned n = unsigned(std::min<size_t>(4, bytes / kPerThread));
-  if (n <= 1)
-  {
-    std::memcpy(dst, src, bytes);
-    return;
-  }
-  std::vector<std::thread> workers;
-  const size_t part = (bytes / n + 63) & ~size_t(63);
-  for (unsigned t = 1; t < n; ++t)
-  {
-    const size_t off = std::min(bytes, t * part);
-    const size_t len = std::min(bytes - off, part);
-    workers.emplace_back([=] { std::memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len); });
-  }
-  std::memcpy(dst, src, std::min(bytes, part));
-  for (auto &w : workers)
-  {
-    w.join();
-  }
-}
-
 inline char *slotRays(ohmhip_map_s::RaySlot &sl) { return sl.h; }
 inline char *slotTimes(ohmhip_map_s::RaySlot &sl) { return sl.h + sl.capacity * 48; }
 inline char *slotIntens(ohmhip_map_s::RaySlot &sl) { return sl.h + sl.capacity * 56; }
@@ -1754,6 +1729,50 @@ size_t hostFilterCount(const MapConst &mc, const double *rays, size_t n_rays, bo
   return passed;
 }
 
+/// Stage a host ray block into the pinned slot and count the rays the filter accepts in the same sweep: the block is
+/// cut into pieces that stay in the core's L2 between the copy and the count, and large blocks are shared between a
+/// few threads (one core copies ~10 GB/s; PCIe Gen5 takes ~55).
+size_t stageRaysAndCount(const MapConst &mc, char *dst, const double *rays, size_t n_rays, bool caller_filtered)
+{
+  static constexpr size_t kPiece = 4096;            // rays per copy+count piece (192 KiB)
+  static constexpr size_t kPerThread = size_t(1) << 16;  // rays before another thread is worth starting
+  auto run = [&mc, dst, rays, caller_filtered](size_t first, size_t last) {
+    size_t passed = 0;
+    for (size_t at = first; at < last; at += kPiece)
+    {
+      const size_t n = std::min<size_t>(kPiece, last - at);
+      std::memcpy(dst + at * 48, rays + at * 6, n * 48);
+      passed += hostFilterCount(mc, rays + at * 6, n, caller_filtered);
+    }
+    return passed;
+  };
+  const unsigned n_threads = unsigned(std::min<size_t>(4, n_rays / kPerThread));
+  if (n_threads <= 1)
+  {
+    return run(0, n_rays);
+  }
+  const size_t part = (n_rays + n_threads - 1) / n_threads;
+  std::vector<size_t> counts(n_threads, 0);
+  std::vector<std::thread> workers;
+  for (unsigned t = 1; t < n_threads; ++t)
+  {
+    workers.emplace_back([&counts, &run, t, part, n_rays] {
+      counts[t] = run(std::min(n_rays, t * part), std::min(n_rays, (t + 1) * part));
+    });
+  }
+  counts[0] = run(0, std::min(n_rays, part));
+  size_t passed = 0;
+  for (unsigned t = 0; t < n_threads; ++t)
+  {
+    if (t)
+    {
+      workers[t - 1].join();
+    }
+    passed += counts[t];
+  }
+  return passed;
+}
+
 int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
                       const double *timestamps, unsigned ray_flags, const unsigned char *filter_flags,
                       size_t *integrated)
@@ -1801,7 +1820,11 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
   {
     return err;
   }
-  parallelCopy(slotRays(sl) + m->pending_rays * 48, rays, n_rays * 48);
+  // A call that is a device batch on its own gets the count from the device (k_ray_setup counts what its filter passes
+  // and the batch summary reaches the host inside this call anyway); calls that share a batch are counted here.
+  const bool device_counts = m->pending_rays == 0 && (!coalesce || n_rays >= m->coalesce_min_rays);
+  const size_t passed = stageRaysAndCount(m->mc, slotRays(sl) + m->pending_rays * 48, rays, n_rays,
+                                          filter_flags != nullptr || device_counts);
   if (timestamps)
   {
     std::memcpy(slotTimes(sl) + m->pending_rays * 8, timestamps, n_rays * 8);
@@ -1826,13 +1849,13 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
   m->pending_calls += 1;
   if (integrated)
   {
-    *integrated = 2 * hostFilterCount(m->mc, rays, n_rays, filter_flags != nullptr);
+    *integrated = 2 * passed;
   }
   if (coalesce && m->pending_rays < m->coalesce_min_rays)
   {
     return OHMHIP_OK;  // deferred: runs with the following calls' rays, or as soon as anything observes the map
   }
-  err = flushPendingRays(m);
+  err = flushPendingRays(m, device_counts ? integrated : nullptr);
   if (err != OHMHIP_OK && integrated)
   {
     *integrated = 0;
