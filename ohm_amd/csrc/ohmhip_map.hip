@@ -749,7 +749,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     auto launchBin = [&](bool bucket, uint32_t seg_capacity, unsigned long long *hit_keys) {
       hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m),
                          static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
-                         seg_capacity, hit_keys, m->d_hit_mask, ray_shift, bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
+                         seg_capacity, hit_keys, m->d_hit_mask, ray_shift, bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask, (m->debug_flags & 64u) ? m->d_dbg : nullptr);
     };
     auto launchRegionSort = [&]() {
       hipLaunchKernelGGL(k_sort_region_hits, dim3(4 * m->walk_workgroups), dim3(kSortThreads), 0, s, regionTable(m),
@@ -1729,6 +1729,32 @@ size_t hostFilterCount(const MapConst &mc, const double *rays, size_t n_rays, bo
   return passed;
 }
 
+/// Copy rays and count those of at most `range` length in one loop (the map's default filter, goodRay with a range).
+/// A ray with a non-finite coordinate has a NaN or infinite squared length, which fails the comparison against the
+/// finite range^2 -- the test for finite coordinates of hostFilterCount is implied and the loop stays at copy speed.
+size_t copyRaysCountInRange(double *dst, const double *rays, size_t n_rays, double range2)
+{
+  size_t passed = 0;
+  for (size_t i = 0; i < n_rays; ++i)
+  {
+    const double *r = rays + 6 * i;
+    double *d = dst + 6 * i;
+    const double x0 = r[0], y0 = r[1], z0 = r[2], x1 = r[3], y1 = r[4], z1 = r[5];
+    d[0] = x0;
+    d[1] = y0;
+    d[2] = z0;
+    d[3] = x1;
+    d[4] = y1;
+    d[5] = z1;
+    const double rx = x1 - x0;
+    const double ry = y1 - y0;
+    const double rz = z1 - z0;
+    const double len2 = (rx * rx + ry * ry) + rz * rz;
+    passed += (len2 <= range2) ? 1u : 0u;
+  }
+  return passed;
+}
+
 /// Stage a host ray block into the pinned slot and count the rays the filter accepts in the same sweep: the block is
 /// cut into pieces that stay in the core's L2 between the copy and the count, and large blocks are shared between a
 /// few threads (one core copies ~10 GB/s; PCIe Gen5 takes ~55).
@@ -1736,7 +1762,14 @@ size_t stageRaysAndCount(const MapConst &mc, char *dst, const double *rays, size
 {
   static constexpr size_t kPiece = 4096;            // rays per copy+count piece (192 KiB)
   static constexpr size_t kPerThread = size_t(1) << 16;  // rays before another thread is worth starting
-  auto run = [&mc, dst, rays, caller_filtered](size_t first, size_t last) {
+  const double range2 = mc.filter_range * mc.filter_range;
+  const bool in_range_only =
+    !caller_filtered && mc.filter_mode == OHMHIP_FILTER_GOOD && mc.filter_range > 0 && std::isfinite(range2);
+  auto run = [&mc, dst, rays, caller_filtered, in_range_only, range2](size_t first, size_t last) {
+    if (in_range_only)
+    {
+      return copyRaysCountInRange(reinterpret_cast<double *>(dst + first * 48), rays + first * 6, last - first, range2);
+    }
     size_t passed = 0;
     for (size_t at = first; at < last; at += kPiece)
     {
@@ -1969,7 +2002,7 @@ try
             continue;
           }
           std::fprintf(f, "%zu", b);
-          for (int k = 0; k < 25; ++k)
+          for (int k = 0; k < 32; ++k)
           {
             std::fprintf(f, " %llu", rec[k]);
           }
