@@ -223,7 +223,8 @@ int ohmhip_map_integrate_rays_filtered(ohmhip_map_t map, const double *rays, siz
  * the arithmetic the device uses.  An error of a deferred batch (pool exhausted ...) surfaces at the call that launches
  * it.  Default min_rays: 65536; 0 launches every call's batch in that call. */
 int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
-/* Same with rays (and optional intensities/timestamps) already resident in device memory. */
+/* Same with rays (and optional intensities/timestamps) already resident in device memory.  The arrays must be COMPLETE
+ * when the call is made (not merely enqueued on some stream): the map reads them on streams of its own. */
 int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, size_t element_count,
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
                                      size_t *integrated);
@@ -254,10 +255,13 @@ int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
 int ohmhip_map_sync(ohmhip_map_t map);
 int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);
 
-/* Device phase times of one of the last 32 batches (batches_back = 0: the latest): ms[0] first kernel start -> last kernel
- * end, ms[1] ray setup + binning, ms[2] the region walk kernel, ms[3] sample ordering + ordered apply.  hipEvents on the
- * map's stream (the gputil::Event / Queue::mark() bookkeeping of ohmgpu/GpuMap.cpp:1036-1191 serves the same purpose);
- * waits for that batch only.  Lets a caller time a run of batches without synchronising after each one. */
+/* Device phase times of one of the last 32 batches (batches_back = 0: the latest): ms[0] the device time the batch cost
+ * -- first kernel start -> last kernel end, or, for batches presented back to back, the interval between the previous
+ * batch's last kernel and this one's (a batch's set-up pass runs on a second stream under the previous batch's last
+ * kernels) --, ms[1] ray setup + binning (the set-up pass is timed from the moment it may start: queued behind a running
+ * walk kernel it mostly waits for CUs), ms[2] the region walk kernel, ms[3] sample ordering + ordered apply.
+ * hipEvents on the map's streams (the gputil::Event / Queue::mark() bookkeeping of ohmgpu/GpuMap.cpp:1036-1191 serves
+ * the same purpose); waits for that batch only.  Lets a caller time a run of batches without synchronising after each. */
 int ohmhip_map_batch_timings(ohmhip_map_t map, uint32_t batches_back, float ms[4]);
 
 /* Region table (replaces GpuLayerCache::lookup, ohmgpu/GpuLayerCache.cpp:104-119). keys = int16 xyz triples. */

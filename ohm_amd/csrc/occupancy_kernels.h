@@ -1024,11 +1024,9 @@ __global__ void __launch_bounds__(kBinThreads)
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
             uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits, uint32_t rays_per_block,
-            uint32_t tab_mask, unsigned long long *dbg)
+            uint32_t tab_mask)
 {
   __shared__ LdsRegionTable tab;
-#define BIN_STAMP(k) if (dbg && threadIdx.x == 0 && blockIdx.x < 4096) dbg[16 + size_t(blockIdx.x) * 32 + 26 + (k)] = wall_clock64();
-  BIN_STAMP(0)
   if (bs.info->error & (kErrHashFull | kErrSlotsFull))
   {
     return;  // the batch's set-up overflowed the pool: the host grows it and repeats the batch
@@ -1066,7 +1064,6 @@ __global__ void __launch_bounds__(kBinThreads)
     }
   }
   __syncthreads();
-  BIN_STAMP(1)
   // Step 2: sample keys and mask bits.  bucket_hits: the keys go straight into their region's range of the sample
   // list (k_sort_region_hits orders each range); otherwise they are written in ray order for a device-wide sort.
   for (uint32_t ray = first + threadIdx.x; ray < last; ray += blockDim.x)
@@ -1112,8 +1109,6 @@ __global__ void __launch_bounds__(kBinThreads)
       hit_keys[pos] = hk;
     }
   }
-  __syncthreads();
-  BIN_STAMP(2)
   // Step 3: scatter, rays visited by descending extent (see RayOrder).
   __shared__ RayOrder order;
   const uint32_t n_local = last - first;
@@ -1122,13 +1117,11 @@ __global__ void __launch_bounds__(kBinThreads)
     const int total[3] = { w->total[0], w->total[1], w->total[2] };
     return rayExtentBin(mc, w->flags, total);
   });
-  BIN_STAMP(3)
   for (uint32_t idx = threadIdx.x; idx < n_local; idx += blockDim.x)
   {
     const uint32_t ray = first + order.perm[idx];
     const RayWalk rw = walks[ray];
     const RayFix rf = rayFix(mc, rw);
-    if (idx == threadIdx.x) { BIN_STAMP(4) }
     forEachSegment(mc, rw, true, [&](uint64_t key, const SegmentEntry &entry) {
       const uint32_t e = ltabFind(tab, key, tab_mask);
       uint32_t pos;
@@ -1151,8 +1144,6 @@ __global__ void __launch_bounds__(kBinThreads)
       }
     });
   }
-  __syncthreads();
-  BIN_STAMP(5)
 }
 
 /// Rewrite only the sample (hit) keys of a batch (used when the NDT / TSDF key buffer had to be re-allocated).

@@ -78,10 +78,21 @@ struct ohmhip_map_s
   int device = 0;
   hipStream_t stream = nullptr;       ///< compute stream
   hipStream_t copy_stream = nullptr;  ///< side stream for region upload/download
+  /// Stream of a batch's set-up pass (k_ray_setup, k_plan).  It reads the rays and the region table only, and writes
+  /// per-batch scratch that exists twice (see `parity`), so the set-up of batch N+1 runs while the walk kernel of batch N
+  /// drains and its apply kernels run.  It is idle whenever no batch call is in progress: every call waits for its own
+  /// plan summary.
+  hipStream_t front_stream = nullptr;
+  hipEvent_t ev_batch_done[2] = { nullptr, nullptr };  ///< per parity: the batch that last used this scratch copy is done
+  bool batch_done_recorded[2] = { false, false };
+  hipEvent_t ev_bin_done = nullptr;  ///< the latest k_ray_bin has finished
+  bool bin_done_recorded = false;
+  uint32_t parity = 0;  ///< which copy of the doubled per-batch scratch (RayWalk array, per-hash / per-slot counters,
+                        ///< chunk list, event counters) the current batch uses
   hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   /// Timing events of the last kTimingRing batches (start, binned, samples ordered, walked, done): reading a batch's
   /// phase times does not have to synchronise the host with every batch.
-  hipEvent_t tev[kTimingRing][5] = {};
+  hipEvent_t tev[kTimingRing][7] = {};  // ([5]: set-up pass done, [6]: binning starts)
   uint64_t batch_seq = 0;
 
   uint32_t slot_capacity = 0;
@@ -98,25 +109,25 @@ struct ohmhip_map_s
   uint32_t *d_seg_count = nullptr, *d_seg_cursor = nullptr, *d_seg_offset = nullptr, *d_touched_flag = nullptr,
            *d_touched = nullptr;
   uint32_t *d_voxel_first_hit = nullptr, *d_hit_begin = nullptr, *d_hit_end = nullptr, *d_dirty = nullptr;
-  BatchInfo *d_info = nullptr;   ///< two summaries used alternately: k_plan of one batch zeroes the next batch's
+  BatchInfo *d_info = nullptr;   ///< three summaries used in turn: k_plan of one batch zeroes the next batch's
   BatchInfo *h_info = nullptr;   ///< pinned, device visible: [0] batch summary (written by k_plan), [1] event count
   BatchInfo *h_info_dev = nullptr;  ///< device address of h_info
   uint32_t info_index = 0;
-  bool info_clean = false;       ///< d_info[info_index ^ 1] was zeroed by the previous batch's k_plan
+  bool info_clean = false;       ///< d_info[next index] was zeroed by the previous batch's k_plan
   uint32_t *d_miss_counts = nullptr;
   uint32_t *d_hit_mask = nullptr;
   Chunk *d_chunks = nullptr;
   uint32_t chunk_capacity = 0;
 
-  DevBuf walks, hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, events;
-  DevBuf wg_regions, wg_region_count, group_heads;
+  DevBuf walks_buf[2], hit_keys_a, hit_keys_b, interval_counts, segments, sort_temp, events;
+  DevBuf wg_regions[2], wg_region_count[2], group_heads;  // (workgroup region lists: per parity)
   /// Replica merge (merge_impl.h): base copy of the occupancy layer (null until ohmhip_map_enable_merge) and scratch.
   float *d_merge_base = nullptr;
   /// Traversal layer only: per-voxel fixed-point sum of a batch's ray lengths (zero between batches).
   unsigned long long *d_traversal_acc = nullptr;
   DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;
   DevBuf stop_a, stop_b;  ///< kRfStopOnFirstOccupied: per-ray stop positions (current / candidate)
-  uint32_t *d_event_count = nullptr;  ///< [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count
+  uint32_t *d_event_count = nullptr;  ///< per parity: [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count, [3] stop iteration flag
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
@@ -182,23 +193,31 @@ RegionTable regionTable(ohmhip_map_t m)
 
 BatchScratch batchScratch(ohmhip_map_t m)
 {
+  // The counters a batch's set-up pass writes exist twice (allocPool makes the arrays twice as long): batch N+1 sets up
+  // in the other half while batch N's walk / apply kernels still read theirs.
+  const size_t h = size_t(m->parity) * m->hash_capacity;
+  const size_t c = size_t(m->parity) * m->slot_capacity;
   BatchScratch bs;
-  bs.seg_count = m->d_seg_count;
-  bs.seg_cursor = m->d_seg_cursor;
-  bs.seg_offset = m->d_seg_offset;
-  bs.touched_flag = m->d_touched_flag;
-  bs.touched = m->d_touched;
-  bs.hit_count = m->d_hit_count;
-  bs.sort_list = m->d_sort_list;
+  bs.seg_count = m->d_seg_count + h;
+  bs.seg_cursor = m->d_seg_cursor + h;
+  bs.seg_offset = m->d_seg_offset + h;
+  bs.touched_flag = m->d_touched_flag + h;
+  bs.touched = m->d_touched + h;
+  bs.hit_count = m->d_hit_count + h;
+  bs.sort_list = m->d_sort_list + h;
   bs.voxel_first_hit = m->d_voxel_first_hit;
-  bs.hit_begin = m->d_hit_begin;
-  bs.hit_end = m->d_hit_end;
+  bs.hit_begin = m->d_hit_begin + c;
+  bs.hit_end = m->d_hit_end + c;
   bs.dirty = m->d_dirty;
   bs.info = m->d_info + m->info_index;
-  bs.wg_regions = static_cast<WgRegion *>(m->wg_regions.ptr);
-  bs.wg_region_count = static_cast<uint32_t *>(m->wg_region_count.ptr);
+  bs.wg_regions = static_cast<WgRegion *>(m->wg_regions[m->parity].ptr);
+  bs.wg_region_count = static_cast<uint32_t *>(m->wg_region_count[m->parity].ptr);
   return bs;
 }
+
+inline Chunk *batchChunks(ohmhip_map_t m) { return m->d_chunks + size_t(m->parity) * m->chunk_capacity; }
+inline uint32_t *batchEventCount(ohmhip_map_t m) { return m->d_event_count + 4u * m->parity; }
+inline DevBuf &batchWalks(ohmhip_map_t m) { return m->walks_buf[m->parity]; }
 
 __global__ void k_rehash(RegionTable rt, uint32_t n)
 {
@@ -373,21 +392,21 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
     }
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_keys), sizeof(unsigned long long) * hash_cap));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_vals), sizeof(uint32_t) * hash_cap));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_count), sizeof(uint32_t) * hash_cap));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_cursor), sizeof(uint32_t) * hash_cap));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_count), sizeof(uint32_t) * hash_cap));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_sort_list), sizeof(uint32_t) * hash_cap));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_offset), sizeof(uint32_t) * hash_cap));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_touched_flag), sizeof(uint32_t) * hash_cap));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_touched), sizeof(uint32_t) * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_count), sizeof(uint32_t) * 2 * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_cursor), sizeof(uint32_t) * 2 * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_count), sizeof(uint32_t) * 2 * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_sort_list), sizeof(uint32_t) * 2 * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_offset), sizeof(uint32_t) * 2 * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_touched_flag), sizeof(uint32_t) * 2 * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_touched), sizeof(uint32_t) * 2 * hash_cap));
     if (m->config.mode == OHMHIP_MODE_OCCUPANCY)
     {
       OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_first_hit), sizeof(uint32_t) * rv * capacity));
     }
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_begin), sizeof(uint32_t) * capacity));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_end), sizeof(uint32_t) * capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_begin), sizeof(uint32_t) * 2 * capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_end), sizeof(uint32_t) * 2 * capacity));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_miss_counts), sizeof(uint32_t) * rv * capacity));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_chunks), sizeof(Chunk) * chunk_capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_chunks), sizeof(Chunk) * 2 * chunk_capacity));
     if (m->config.layers & (1u << OHMHIP_LID_TRAVERSAL))
     {
       OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_traversal_acc), sizeof(unsigned long long) * rv * capacity));
@@ -498,11 +517,12 @@ int rollbackTable(ohmhip_map_t m)
   const size_t hash_words = m->hash_capacity;
   OHMHIP_CHECK(hipStreamSynchronize(s));
   OHMHIP_CHECK(hipMemsetAsync(m->d_keys, 0, sizeof(unsigned long long) * hash_words, s));
-  uint32_t *per_hash[] = { m->d_vals,       m->d_seg_count,    m->d_seg_cursor, m->d_hit_count,
-                           m->d_seg_offset, m->d_touched_flag, m->d_touched,    m->d_sort_list };
+  OHMHIP_CHECK(hipMemsetAsync(m->d_vals, 0, sizeof(uint32_t) * hash_words, s));
+  uint32_t *per_hash[] = { m->d_seg_count,  m->d_seg_cursor,   m->d_hit_count, m->d_seg_offset,
+                           m->d_touched_flag, m->d_touched,    m->d_sort_list };
   for (uint32_t *p : per_hash)
   {
-    OHMHIP_CHECK(hipMemsetAsync(p, 0, sizeof(uint32_t) * hash_words, s));
+    OHMHIP_CHECK(hipMemsetAsync(p, 0, sizeof(uint32_t) * 2 * hash_words, s));  // (both parities)
   }
   const uint32_t keep = m->slots_committed;
   if (m->slot_capacity > keep)
@@ -514,7 +534,7 @@ int rollbackTable(ohmhip_map_t m)
   {
     hipLaunchKernelGGL(k_rehash, dim3((keep + 255) / 256), dim3(256), 0, s, regionTable(m), keep);
   }
-  OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, 2 * sizeof(BatchInfo), s));
+  OHMHIP_CHECK(hipMemsetAsync(m->d_info, 0, 3 * sizeof(BatchInfo), s));
   m->info_clean = false;
   m->spec_bucket_ok = false;
   OHMHIP_CHECK(hipStreamSynchronize(s));
@@ -661,11 +681,17 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                    uint32_t n_rays, unsigned ray_flags)
 {
   hipStream_t s = m->stream;
+  hipStream_t f = m->front_stream;
   hipEvent_t *tev = m->tev[m->batch_seq % kTimingRing];
-  // This batch's summary block: the other one of the pair, zeroed by the previous batch's k_plan if that ran.
-  m->info_index ^= 1u;
+  // This batch's summary block: the next of the three, zeroed by the previous batch's k_plan if that ran.  (Three: the
+  // set-up pass of this batch runs under the previous batch's apply kernels, which still read theirs, and zeroes the
+  // following batch's.)
+  m->info_index = (m->info_index + 1u) % 3u;
+  const uint32_t next_info_index = (m->info_index + 1u) % 3u;
   const bool info_clean = m->info_clean;
   m->info_clean = false;
+  // The other copy of the doubled per-batch scratch.
+  m->parity ^= 1u;
   const uint32_t ray_blocks = (n_rays + 255) / 256;
   // Binning launch shape: 1024 rays per 512-thread workgroup for large batches; small batches use smaller workgroups
   // with as many rays as threads so they still cover the CUs.
@@ -713,9 +739,9 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   sec.timestamps = d_timestamps;
   sec.time_base = m->first_ray_time;
 
-  OHMHIP_CHECK(m->walks.ensure(sizeof(RayWalk) * size_t(n_rays), false, s));
-  OHMHIP_CHECK(m->wg_regions.ensure(sizeof(WgRegion) * size_t(bin_blocks) * kLtabSize, false, s));
-  OHMHIP_CHECK(m->wg_region_count.ensure(sizeof(uint32_t) * size_t(bin_blocks), false, s));
+  OHMHIP_CHECK(batchWalks(m).ensure(sizeof(RayWalk) * size_t(n_rays), false, s));
+  OHMHIP_CHECK(m->wg_regions[m->parity].ensure(sizeof(WgRegion) * size_t(bin_blocks) * kLtabSize, false, s));
+  OHMHIP_CHECK(m->wg_region_count[m->parity].ensure(sizeof(uint32_t) * size_t(bin_blocks), false, s));
   if (occupancy_mode)
   {
     OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
@@ -730,26 +756,45 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
 
   for (int attempt = 0; attempt < 8; ++attempt)
   {
+    // The set-up pass goes to the front stream.  It has to wait for the batch that last used this parity's scratch
+    // copy, RayWalk array and workgroup region lists -- the batch before the previous one.  It is also held back until
+    // the previous batch's binning pass is done: beside that pass it would only compete for the vector ALUs (measured:
+    // no gain), whereas started then it queues behind the previous batch's walk kernel and fills the CUs that kernel
+    // vacates as it drains (C1: 1.06 -> 1.03 ms per batch; holding it until the walk has ended loses the gain again,
+    // and so does a stream priority above the compute stream's).
+    if (m->batch_done_recorded[m->parity])
+    {
+      OHMHIP_CHECK(hipStreamWaitEvent(f, m->ev_batch_done[m->parity], 0));
+    }
+    if (m->bin_done_recorded)
+    {
+      OHMHIP_CHECK(hipStreamWaitEvent(f, m->ev_bin_done, 0));
+    }
     if (attempt > 0 || !info_clean)
     {
-      OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), s));
+      OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), f));
     }
-    OHMHIP_CHECK(hipEventRecord(tev[0], s));
-    hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m), d_rays,
-                       n_rays, ray_flags, static_cast<RayWalk *>(m->walks.ptr), bin_rays_per_block, bin_tab_mask);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, regionTable(m), batchScratch(m), m->d_chunks,
-                       m->chunk_capacity, batch_chunk_segments, m->h_info_dev, m->d_info + (m->info_index ^ 1u),
-                       m->d_event_count);
+    OHMHIP_CHECK(hipEventRecord(tev[0], f));
+    hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(bin_threads), 0, f, m->mc, regionTable(m), batchScratch(m), d_rays,
+                       n_rays, ray_flags, static_cast<RayWalk *>(batchWalks(m).ptr), bin_rays_per_block, bin_tab_mask);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, f, regionTable(m), batchScratch(m), batchChunks(m),
+                       m->chunk_capacity, batch_chunk_segments, m->h_info_dev, m->d_info + next_info_index,
+                       batchEventCount(m));
     m->info_clean = true;
-    OHMHIP_CHECK(hipEventRecord(m->ev[7], s));
+    OHMHIP_CHECK(hipEventRecord(tev[5], f));
+    OHMHIP_CHECK(hipEventRecord(m->ev[7], f));
+    OHMHIP_CHECK(hipStreamWaitEvent(s, m->ev[7], 0));
+    OHMHIP_CHECK(hipEventRecord(tev[6], s));
     // The host needs the batch summary (segment count, sample distribution, pool state) before it can size and launch
     // the rest -- a round trip during which the device would idle.  In steady state (occupancy, previous batch sorted
     // its samples per region) the binning and the sample sort are launched right away with the buffers of the previous
     // batch; the summary then only confirms the guess, and a wrong guess costs a repeat of the two passes.
     auto launchBin = [&](bool bucket, uint32_t seg_capacity, unsigned long long *hit_keys) {
       hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m),
-                         static_cast<const RayWalk *>(m->walks.ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
-                         seg_capacity, hit_keys, m->d_hit_mask, ray_shift, bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask, (m->debug_flags & 64u) ? m->d_dbg : nullptr);
+                         static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
+                         seg_capacity, hit_keys, m->d_hit_mask, ray_shift, bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
+      (void)hipEventRecord(m->ev_bin_done, s);
+      m->bin_done_recorded = true;
     };
     auto launchRegionSort = [&]() {
       hipLaunchKernelGGL(k_sort_region_hits, dim3(4 * m->walk_workgroups), dim3(kSortThreads), 0, s, regionTable(m),
@@ -851,7 +896,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       if (tsdf_mode)
       {
         hipLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
-                           static_cast<const RayWalk *>(m->walks.ptr), d_rays, n_rays, m->d_hit_mask);
+                           static_cast<const RayWalk *>(batchWalks(m).ptr), d_rays, n_rays, m->d_hit_mask);
       }
       OHMHIP_CHECK(hipEventRecord(tev[1], s));
       if (bucket_hits)
@@ -886,14 +931,14 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       {
         if (walk_attempt > 0)
         {
-          OHMHIP_CHECK(hipMemsetAsync(m->d_event_count, 0, 2 * sizeof(uint32_t), s));  // (k_plan zeroed them for the first)
+          OHMHIP_CHECK(hipMemsetAsync(batchEventCount(m), 0, 2 * sizeof(uint32_t), s));  // (k_plan zeroed them for the first)
         }
         WalkArgs wa;
         wa.mc = m->mc;
         wa.bs = batchScratch(m);
-        wa.chunks = m->d_chunks;
+        wa.chunks = batchChunks(m);
         wa.segments = static_cast<const Segment *>(m->segments.ptr);
-        wa.walks = static_cast<const RayWalk *>(m->walks.ptr);
+        wa.walks = static_cast<const RayWalk *>(batchWalks(m).ptr);
         wa.slot_keys = m->d_slot_keys;
         wa.sorted_hits = sorted;
         wa.hit_mask = m->d_hit_mask;
@@ -901,7 +946,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         wa.interval_counts = static_cast<uint32_t *>(m->interval_counts.ptr);
         wa.events = events;
         wa.event_capacity = event_capacity;
-        wa.event_count = m->d_event_count;
+        wa.event_count = batchEventCount(m);
         wa.refill_min_idle = m->refill_min_idle;
         wa.dbg = m->debug_flags;
         wa.ray_shift = ray_shift;
@@ -912,7 +957,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         const bool trace = (m->debug_flags & (16u | 64u | 128u)) != 0;
         wa.dbg_counters = trace ? m->d_dbg : nullptr;
         wa.traversal_acc = sec.traversal ? m->d_traversal_acc : nullptr;
-        wa.chunk_cursor = m->d_event_count + 1;
+        wa.chunk_cursor = batchEventCount(m) + 1;
         wa.n_chunks = info.n_chunks;
         // A repeated walk (NDT / TSDF event list overflow) must not apply anything twice: single-chunk regions were
         // applied straight from LDS by the first launch (the repeat only regenerates their events) and the traversal
@@ -952,13 +997,13 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         if (occupancy_mode)
         {
           hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m), events, event_capacity,
-                             m->d_event_count, sorted, m->d_miss_counts,
+                             batchEventCount(m), sorted, m->d_miss_counts,
                              static_cast<uint32_t *>(m->interval_counts.ptr), m->mc.region_voxels,
                              reinterpret_cast<uint32_t *>(m->h_info_dev + 1));
           break;
         }
         // NDT / TSDF: the host needs the event count to size the sort; an overflowing list is re-walked.
-        OHMHIP_CHECK(hipMemcpyAsync(&m->h_info[1], m->d_event_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        OHMHIP_CHECK(hipMemcpyAsync(&m->h_info[1], batchEventCount(m), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         OHMHIP_CHECK(hipStreamSynchronize(s));
         n_events = *reinterpret_cast<const uint32_t *>(&m->h_info[1]);
         m->event_demand = n_events;
@@ -980,7 +1025,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         // k_ray_bin also fills the segment buckets: only the sample keys are rewritten here (cursors already reset).
         OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), s));
         hipLaunchKernelGGL(k_rekey_samples, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
-                           static_cast<const RayWalk *>(m->walks.ptr), n_rays, keys_a, ray_shift);
+                           static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays, keys_a, ray_shift);
         if (walk_attempt == 3)
         {
           return OHMHIP_ERR_INTERNAL;
@@ -1001,7 +1046,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                          ray_flags, sorted, static_cast<uint32_t *>(m->interval_counts.ptr), m->d_miss_counts, d_rays,
                          static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
                          static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]), sec,
-                         static_cast<const RayWalk *>(m->walks.ptr));
+                         static_cast<const RayWalk *>(batchWalks(m).ptr));
       if (info.n_touched)
       {
         hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
@@ -1023,7 +1068,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       // list is long there and the maths heavy; a lane per event with the non-heads exiting ran at a few live lanes
       // per wave).
       uint32_t *heads = nullptr;
-      uint32_t *n_heads = m->d_event_count + 2;
+      uint32_t *n_heads = batchEventCount(m) + 2;
       uint32_t replay_blocks = uint32_t((total + 127) / 128);
       if (ndt_mode)
       {
@@ -1043,8 +1088,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         uint32_t *stop_next = static_cast<uint32_t *>(m->stop_b.ptr);
         OHMHIP_CHECK(hipMemsetAsync(stop, 0xff, sizeof(uint32_t) * size_t(n_rays), s));
         OHMHIP_CHECK(hipMemsetAsync(stop_next, 0xff, sizeof(uint32_t) * size_t(n_rays), s));
-        uint32_t *d_changed = m->d_event_count + 3;
-        const RayWalk *walks = static_cast<const RayWalk *>(m->walks.ptr);
+        uint32_t *d_changed = batchEventCount(m) + 3;
+        const RayWalk *walks = static_cast<const RayWalk *>(batchWalks(m).ptr);
         float *occ = static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]);
         uint32_t *mean_layer = static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]);
         bool settled = false;
@@ -1084,7 +1129,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                            static_cast<float *>(m->layers[OHMHIP_LID_COVARIANCE]),
                            tm ? static_cast<float *>(m->layers[OHMHIP_LID_INTENSITY]) : nullptr,
                            tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr, sec,
-                           static_cast<const RayWalk *>(m->walks.ptr), heads, n_heads);
+                           static_cast<const RayWalk *>(batchWalks(m).ptr), heads, n_heads);
         if (info.n_touched)
         {
           hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
@@ -1107,6 +1152,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       }
     }
     OHMHIP_CHECK(hipEventRecord(tev[4], s));
+    OHMHIP_CHECK(hipEventRecord(m->ev_batch_done[m->parity], s));
+    m->batch_done_recorded[m->parity] = true;
     OHMHIP_CHECK(hipGetLastError());
 
     m->stats = {};
@@ -1198,6 +1245,7 @@ int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
   }
   OHMHIP_CHECK(hipEventRecord(sl.uploaded, m->copy_stream));
   OHMHIP_CHECK(hipStreamWaitEvent(m->stream, sl.uploaded, 0));
+  OHMHIP_CHECK(hipStreamWaitEvent(m->front_stream, sl.uploaded, 0));  // (the set-up pass reads the rays first)
   const int err = integrateRaysDevice(m, static_cast<const double *>(sl.d_rays.ptr), n * 2, d_int, d_ts,
                                       m->pending_flags, integrated, d_ff);
   OHMHIP_CHECK(hipEventRecord(sl.done, m->stream));
@@ -1336,6 +1384,13 @@ try
   {
     return fail(err);
   }
+  if ((err = hipStreamCreateWithFlags(&m->front_stream, hipStreamNonBlocking)) != 0 ||
+      (err = hipEventCreateWithFlags(&m->ev_batch_done[0], hipEventDisableTiming)) != 0 ||
+      (err = hipEventCreateWithFlags(&m->ev_batch_done[1], hipEventDisableTiming)) != 0 ||
+      (err = hipEventCreateWithFlags(&m->ev_bin_done, hipEventDisableTiming)) != 0)
+  {
+    return fail(err);
+  }
   for (auto &e : m->ev)
   {
     if ((err = hipEventCreate(&e)) != 0)
@@ -1365,11 +1420,11 @@ try
   {
     return fail(err);
   }
-  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_info), 2 * sizeof(BatchInfo))) != 0)
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_info), 3 * sizeof(BatchInfo))) != 0)
   {
     return fail(err);
   }
-  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_event_count), 4 * sizeof(uint32_t))) != 0)
+  if ((err = hipMalloc(reinterpret_cast<void **>(&m->d_event_count), 8 * sizeof(uint32_t))) != 0)
   {
     return fail(err);
   }
@@ -1468,16 +1523,24 @@ try
   {
     (void)hipStreamSynchronize(m->copy_stream);
   }
+  if (m->front_stream)
+  {
+    (void)hipStreamSynchronize(m->front_stream);
+  }
   freePool(m);
-  m->walks.release();
+  m->walks_buf[0].release();
+  m->walks_buf[1].release();
   m->hit_keys_a.release();
   m->hit_keys_b.release();
   m->interval_counts.release();
   m->segments.release();
   m->sort_temp.release();
   m->events.release();
-  m->wg_regions.release();
-  m->wg_region_count.release();
+  for (int i = 0; i < 2; ++i)
+  {
+    m->wg_regions[i].release();
+    m->wg_region_count[i].release();
+  }
   m->group_heads.release();
   m->stop_a.release();
   m->stop_b.release();
@@ -1548,6 +1611,17 @@ try
   if (m->copy_stream)
   {
     (void)hipStreamDestroy(m->copy_stream);
+  }
+  if (m->front_stream)
+  {
+    (void)hipStreamDestroy(m->front_stream);
+  }
+  for (hipEvent_t e : { m->ev_batch_done[0], m->ev_batch_done[1], m->ev_bin_done })
+  {
+    if (e)
+    {
+      (void)hipEventDestroy(e);
+    }
   }
   delete m;
   return OHMHIP_OK;
@@ -1982,6 +2056,7 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
+  OHMHIP_CHECK(hipStreamSynchronize(m->front_stream));
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   if (m->debug_flags & (64u | 128u))
   {
@@ -2002,7 +2077,7 @@ try
             continue;
           }
           std::fprintf(f, "%zu", b);
-          for (int k = 0; k < 32; ++k)
+          for (int k = 0; k < 25; ++k)
           {
             std::fprintf(f, " %llu", rec[k]);
           }
@@ -2032,9 +2107,22 @@ try
   }
   hipEvent_t *tev = m->tev[(m->batch_seq - 1 - batches_back) % kTimingRing];
   OHMHIP_CHECK(hipEventSynchronize(tev[4]));
-  float sort_ms = 0, apply_ms = 0;
+  float sort_ms = 0, apply_ms = 0, front_ms = 0, bin_ms = 0;
   OHMHIP_CHECK(hipEventElapsedTime(&ms[0], tev[0], tev[4]));
-  OHMHIP_CHECK(hipEventElapsedTime(&ms[1], tev[0], tev[1]));
+  // The set-up pass of a batch runs on its own stream under the previous batch's last kernels, so back-to-back batches
+  // complete at intervals shorter than first start -> last end; that interval is the device time the batch cost.
+  if (uint64_t(batches_back) + 1 < m->batch_seq && batches_back + 1 < kTimingRing)
+  {
+    hipEvent_t *prev = m->tev[(m->batch_seq - 2 - batches_back) % kTimingRing];
+    float period = 0;
+    if (hipEventElapsedTime(&period, prev[4], tev[4]) == hipSuccess && period > 0 && period < ms[0])
+    {
+      ms[0] = period;
+    }
+  }
+  OHMHIP_CHECK(hipEventElapsedTime(&front_ms, tev[0], tev[5]));
+  OHMHIP_CHECK(hipEventElapsedTime(&bin_ms, tev[6], tev[1]));
+  ms[1] = front_ms + bin_ms;
   OHMHIP_CHECK(hipEventElapsedTime(&ms[2], tev[2], tev[3]));
   OHMHIP_CHECK(hipEventElapsedTime(&sort_ms, tev[1], tev[2]));
   OHMHIP_CHECK(hipEventElapsedTime(&apply_ms, tev[3], tev[4]));
