@@ -152,12 +152,17 @@ def main():
     b_alg = 44.0 * rays_ok + 8.0 * visits
     # Measured HBM traffic of the dominant kernel: from the committed PMC profile of this same command (separate
     # rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); bench.py itself cannot run the profiler.
-    traffic = None
+    traffic = traffic_lower = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            traffic = json.load(fh)["traffic_bytes_per_launch"] if world == 1 and n_rays == 1_000_000 else None
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+            tj = json.load(fh)
+        if world == 1 and n_rays == 1_000_000:
+            # FETCH_SIZE counts 64-byte requests: x2 for coalesced streams (the guide's correction), x1 for the kernel's
+            # 32-byte record gathers (profiles/r02_fetch_calibration.txt) -- the two figures bracket the bytes moved.
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_lower = tj["traffic_bytes_per_launch_lower"]
     except Exception:
-        traffic = None
+        traffic = traffic_lower = None
     t_walk = float(np.mean(walk_ms)) * 1e-3
     t_dev = float(np.mean(total_ms)) * 1e-3
     achieved = b_alg / t_walk / 1e9
@@ -178,10 +183,14 @@ def main():
                    "regions": int(st["regions_resident"]), "ray_region_segments": int(st["ray_region_segments"])},
         "roofline": {"bound": "hbm", "kernel": "k_region_walk", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_lower": traffic_lower,
                      "algorithmic_bytes_per_launch": b_alg, "kernel_ms": t_walk * 1e3,
                      "pipeline_ms": t_dev * 1e3, "pipeline_frac": b_alg / t_dev / 1e9 / HBM_PEAK_GBPS},
         "device_ms": {"setup_bin": float(np.mean([t["ms_setup"] for t in timings])), "walk": float(np.mean(walk_ms)),
-                      "sort_apply": float(np.mean([t["ms_apply"] for t in timings])), "total": float(np.mean(total_ms))},
+                      "sort_apply": float(np.mean([t["ms_apply"] for t in timings])), "total": float(np.mean(total_ms)),
+                      "note": "total = completion interval of back-to-back batches; setup_bin counts the set-up pass from "
+                              "the moment it may start on its own stream -- queued behind the previous batch's walk "
+                              "kernel it mostly waits for CUs -- so the parts overlap and do not add up to total"},
     }
     if merge_log:
         out["merge"] = {"per_step": {"regions_local": int(np.mean([m["regions_local"] for m in merge_log])),

@@ -79,9 +79,9 @@ struct ohmhip_map_s
   hipStream_t stream = nullptr;       ///< compute stream
   hipStream_t copy_stream = nullptr;  ///< side stream for region upload/download
   /// Stream of a batch's set-up pass (k_ray_setup, k_plan).  It reads the rays and the region table only, and writes
-  /// per-batch scratch that exists twice (see `parity`), so the set-up of batch N+1 runs while the walk kernel of batch N
-  /// drains and its apply kernels run.  It is idle whenever no batch call is in progress: every call waits for its own
-  /// plan summary.
+  /// per-batch scratch that exists twice (see `parity`), so the set-up of batch N+1 runs beside the sample sort of batch
+  /// N and in the CUs its walk kernel vacates.  It is idle whenever no batch call is in progress: every call waits for
+  /// its own plan summary.
   hipStream_t front_stream = nullptr;
   hipEvent_t ev_batch_done[2] = { nullptr, nullptr };  ///< per parity: the batch that last used this scratch copy is done
   bool batch_done_recorded[2] = { false, false };
@@ -759,9 +759,11 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
     // The set-up pass goes to the front stream.  It has to wait for the batch that last used this parity's scratch
     // copy, RayWalk array and workgroup region lists -- the batch before the previous one.  It is also held back until
     // the previous batch's binning pass is done: beside that pass it would only compete for the vector ALUs (measured:
-    // no gain), whereas started then it queues behind the previous batch's walk kernel and fills the CUs that kernel
-    // vacates as it drains (C1: 1.06 -> 1.03 ms per batch; holding it until the walk has ended loses the gain again,
-    // and so does a stream priority above the compute stream's).
+    // no gain), whereas started then k_ray_setup runs beside the previous batch's sample sort (LDS bound, few
+    // registers) and k_plan -- one workgroup -- queues behind the persistent walk kernel and runs on the first CU that
+    // kernel vacates (C1: 1.06 -> 1.03 ms per batch; holding the pass until the walk has ended loses the gain again,
+    // and so does a stream priority above the compute stream's).  In a kernel trace k_plan therefore shows the walk's
+    // duration: its dispatch waits for a CU.
     if (m->batch_done_recorded[m->parity])
     {
       OHMHIP_CHECK(hipStreamWaitEvent(f, m->ev_batch_done[m->parity], 0));

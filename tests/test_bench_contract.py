@@ -1,4 +1,4 @@
-"""CPU: the committed default bench line (profiles/r01_bench_default.json, produced by `python bench.py` on an MI355X)
+"""CPU: the committed default bench line (profiles/r02_bench_default.json, produced by `python bench.py` on an MI355X)
 carries every field the bench contract names, with consistent arithmetic."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_default.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r02_bench_default.json")) as fh:
         line = json.load(fh)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -18,8 +18,14 @@ def test_committed_bench_line_has_the_contract_fields():
     rays = line["config"]["rays_per_step_per_gpu"]
     assert abs(line["value"] - rays / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
     roof = line["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_lower"):
         assert key in roof, key
+    with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+        traffic = json.load(fh)
+    assert roof["traffic"] == traffic["traffic_bytes_per_launch"]
+    assert roof["traffic_lower"] == traffic["traffic_bytes_per_launch_lower"]
+    # north_star: the dominant kernel at >= 0.40 of the HBM roofline
+    assert roof["frac"] >= 0.40
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     # achieved = algorithmic bytes per launch / the kernel's average duration (HIP events)
@@ -33,10 +39,18 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_traffic_file_matches_the_profile_it_cites():
-    with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
         traffic = json.load(fh)
     expect = (traffic["fetch_size_kb"] * traffic["fetch_correction"] + traffic["write_size_kb"]) * 1024.0
     assert abs(traffic["traffic_bytes_per_launch"] - expect) < 1.0
-    summary = open(os.path.join(ROOT, "profiles", "r01_profile_final.txt")).read()
+    lower = (traffic["fetch_size_kb"] * traffic["fetch_correction_lower"] + traffic["write_size_kb"]) * 1024.0
+    assert abs(traffic["traffic_bytes_per_launch_lower"] - lower) < 1.0
+    summary = open(os.path.join(ROOT, "profiles", "r02_profile_final.txt")).read()
     assert "k_region_walk" in summary and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary
+    # the profile's average duration of the dominant kernel agrees with the bench line's HIP-event figure
+    with open(os.path.join(ROOT, "profiles", "r02_bench_default.json")) as fh:
+        line = json.load(fh)
+    row = [ln for ln in summary.splitlines() if ln.strip().startswith("k_region_walk")][0].split()
+    avg_us = float(row[3])
+    assert abs(avg_us * 1e-3 - line["roofline"]["kernel_ms"]) / line["roofline"]["kernel_ms"] < 0.05
     assert f"{traffic['fetch_size_kb']:.1f}" in summary and f"{traffic['write_size_kb']:.1f}" in summary
