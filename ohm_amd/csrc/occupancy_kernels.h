@@ -1796,8 +1796,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   // the next one while the other waves are still finishing their loop, so a trip does not start with a chain of
   // dependent global loads.
   const int defer_all = args.defer_all;
-  auto fetchNextChunk = [&](uint32_t *record) {
-    const uint32_t next = atomicAdd(args.chunk_cursor, 1u);
+  // A workgroup's first chunk is the one with its own index (the list is ordered largest first, so the launch starts on
+  // the gridDim.x largest chunks, one per workgroup, whatever order the workgroups arrive in); the shared cursor hands
+  // out the chunks behind those.
+  auto fetchNextChunk = [&](uint32_t *record, bool first = false) {
+    const uint32_t next = first ? blockIdx.x : gridDim.x + atomicAdd(args.chunk_cursor, 1u);
     record[1] = next;
     if (next < args.n_chunks)
     {
@@ -1862,10 +1865,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       pf_vox[j] = args.segments[r.seg_begin + min(threadIdx.x + uint32_t(j) * kWalkThreads, n - 1u)].vox;
     }
   };
-  // The first two records: claimed by two waves at once (which of them gets the earlier chunk does not matter).
+  // The first two records, fetched by two waves at once.
   if (threadIdx.x == 0 || threadIdx.x == 64)
   {
-    fetchNextChunk(l_cursor + (threadIdx.x ? kWalkCursorWords / 2 : 0));
+    fetchNextChunk(l_cursor + (threadIdx.x ? kWalkCursorWords / 2 : 0), threadIdx.x == 0);
   }
   __syncthreads();
   ChunkRecord cur = readRecord(l_cursor);
