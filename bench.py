@@ -109,7 +109,12 @@ def main():
         from ohm_amd import distributed as D
         # RCCL communicator owned by the library when every rank has its own GPU; otherwise (single-GPU smoke runs with
         # more ranks than GPUs) the same merge steps run over the gloo group.
-        comm = D.Communicator() if backend == "nccl" else None
+        merge_note = None
+        try:
+            comm = D.Communicator() if backend == "nccl" else None
+        except Exception as exc:  # the library's RCCL communicator could not be made: merge over the torch group
+            comm = None
+            merge_note = "library RCCL communicator unavailable (%s): merge staged over the torch group" % (exc,)
         merger = D.ReplicaMerger(gm, comm=comm)
 
     def barrier():
@@ -120,10 +125,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    merge_state = {"merger": merger, "error": None}
+
     def step():
         gm.integrateRaysDevice(dptr, rays.shape[0])
-        if merger is not None:
-            merge_log.append(merger.merge())
+        if merge_state["merger"] is not None:
+            try:
+                merge_log.append(merge_state["merger"].merge())
+            except Exception as exc:  # reported in the output line; the ranks keep integrating their own maps
+                merge_state["error"] = repr(exc)
+                merge_state["merger"] = None
 
     for _ in range(args.warmup):
         step()
@@ -192,13 +203,16 @@ def main():
                               "the moment it may start on its own stream -- queued behind the previous batch's walk "
                               "kernel it mostly waits for CUs -- so the parts overlap and do not add up to total"},
     }
-    if merge_log:
+    if world > 1 and (merge_state["error"] or not merge_log):
+        out["merge"] = {"error": merge_state["error"] or "no merge ran", "note": "replicas not reconciled in this run"}
+    elif merge_log:
         out["merge"] = {"per_step": {"regions_local": int(np.mean([m["regions_local"] for m in merge_log])),
                                      "regions_union": int(np.mean([m["regions_union"] for m in merge_log])),
                                      "regions_shared": int(np.mean([m["regions_shared"] for m in merge_log])),
                                      "payload_bytes_per_rank": int(np.mean([m["payload_bytes"] for m in merge_log])),
                                      "ms_host": float(np.mean([m.get("ms_total", 0.0) for m in merge_log]))},
-                        "transport": "RCCL (library)" if comm is not None else "gloo (host staged)",
+                        "transport": "RCCL (library)" if comm is not None else "torch.distributed group (staged)",
+                        "note": merge_note,
                         "rule": "merged = clamp(base + sum_r (x_r - base)); exact where no clamp engaged between ranks"}
     if world == 1 and not args.no_extra:
         # Secondary figures (not the headline `value`): C2 GpuNdtMap (1 M rays) and C3 GpuTsdfMap (its full 4 M rays in one
