@@ -1027,6 +1027,7 @@ __global__ void __launch_bounds__(kBinThreads)
             uint32_t tab_mask)
 {
   __shared__ LdsRegionTable tab;
+  __shared__ uint32_t s_slot[kLtabSize];  // region slot per table entry (kSlotUnassigned: not handed over by the set-up)
   if (bs.info->error & (kErrHashFull | kErrSlotsFull))
   {
     return;  // the batch's set-up overflowed the pool: the host grows it and repeats the batch
@@ -1036,6 +1037,7 @@ __global__ void __launch_bounds__(kBinThreads)
     tab.keys[i] = 0;
     tab.count[i] = 0;
     tab.cursor[i] = 0;
+    s_slot[i] = kSlotUnassigned;
   }
   __syncthreads();
 
@@ -1054,10 +1056,12 @@ __global__ void __launch_bounds__(kBinThreads)
     {
       tab.cursor[wr.entry] = bs.seg_offset[wr.hash] + atomicAdd(&bs.seg_cursor[wr.hash], wr.count);
     }
-    if (bucket_hits && wr.hits)
+    if (wr.hits)
     {
+      // The samples' keys need the region's slot: looked up once per (workgroup, region) here, not once per ray.
       const uint32_t slot = rt.vals[wr.hash];
-      if (slot < rt.slot_capacity)  // (a speculatively launched pass may see a batch whose slots ran out)
+      s_slot[wr.entry] = slot;
+      if (bucket_hits && slot < rt.slot_capacity)  // (a speculatively launched pass may see a batch whose slots ran out)
       {
         tab.count[wr.entry] = atomicAdd(&bs.hit_end[slot], wr.hits);
       }
@@ -1076,16 +1080,17 @@ __global__ void __launch_bounds__(kBinThreads)
       uint64_t key;
       uint32_t vi;
       sampleVoxel(mc, rw, key, vi);
-      const uint32_t e = bucket_hits ? ltabFind(tab, key, tab_mask) : kLtabSize;
+      const uint32_t e = ltabFind(tab, key, tab_mask);
       uint32_t slot;
       if (e < kLtabSize)
       {
-        // The table does not carry the slot; it is in the reserved position's region range, but the key needs it.
-        // (A speculatively launched pass may run on a batch whose region inserts failed -- hash table full -- and then
-        // does not find the key: the host repeats the batch after growing the pool, nothing may be written here.)
-        const uint32_t h = regionFind(rt, key);
-        slot = (h != 0xffffffffu) ? rt.vals[h] : kSlotUnassigned;
-        pos = atomicAdd(&tab.count[e], 1u);
+        // (A speculatively launched pass may run on a batch whose region inserts failed -- hash table full: the slot is
+        // then unassigned, the host repeats the batch after growing the pool, nothing may be written here.)
+        slot = s_slot[e];
+        if (bucket_hits)
+        {
+          pos = atomicAdd(&tab.count[e], 1u);
+        }
       }
       else
       {
