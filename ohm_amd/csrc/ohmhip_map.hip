@@ -609,16 +609,19 @@ int ensureStage(ohmhip_map_t m, size_t bytes)
   return OHMHIP_OK;
 }
 
-/// Highest key bit the sorts need: the slot field only uses log2(capacity) + 1 bits (invalid keys are all ones).
-unsigned sortEndBit(ohmhip_map_t m)
+/// Highest key bit the sorts need: the slot field only uses log2(slots) + 1 bits (invalid keys are all ones).  `slots`:
+/// the pool's capacity when sizing buffers, the slots actually in use when sorting (fewer 8-bit passes for a map that
+/// occupies a small part of a large pool).
+unsigned sortEndBit(uint32_t slots)
 {
   unsigned bits = 1;
-  while ((1u << bits) <= m->slot_capacity)
+  while ((1u << bits) <= slots)
   {
     ++bits;
   }
   return std::min<unsigned>(64u, unsigned(kHitSlotShift) + bits + 1u);
 }
+unsigned sortEndBit(ohmhip_map_t m) { return sortEndBit(m->slot_capacity); }
 
 /// rocPRIM falls back to a 20-launch merge sort for up to 2^20 keys by default; the one-sweep radix path is several
 /// times faster on the 1M-key sample lists of a typical batch.
@@ -914,7 +917,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         // Sample keys are emitted in ray order and the radix sort is stable: sorting on the (slot, voxel) bits alone
         // leaves each voxel's samples in ray order.
         OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays),
-                                                          kHitRayBits, sortEndBit(m), s));
+                                                          kHitRayBits, sortEndBit(info.n_slots), s));
         hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m),
                            m->mc.region_voxels);
       }
@@ -1065,7 +1068,8 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(nullptr, sort_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
       OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
       size_t temp_bytes = m->sort_temp.bytes;
-      OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
+      OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, total, 0,
+                                                        sortEndBit(info.n_slots), s));
       // NDT: one lane per voxel group -- compact the group heads, then replay grid-stride over them (a voxel's event
       // list is long there and the maths heavy; a lane per event with the non-heads exiting ran at a few live lanes
       // per wave).
