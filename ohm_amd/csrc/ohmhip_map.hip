@@ -742,9 +742,14 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
   sec.timestamps = d_timestamps;
   sec.time_base = m->first_ray_time;
 
-  OHMHIP_CHECK(batchWalks(m).ensure(sizeof(RayWalk) * size_t(n_rays), false, s));
-  OHMHIP_CHECK(m->wg_regions[m->parity].ensure(sizeof(WgRegion) * size_t(bin_blocks) * kLtabSize, false, s));
-  OHMHIP_CHECK(m->wg_region_count[m->parity].ensure(sizeof(uint32_t) * size_t(bin_blocks), false, s));
+  for (int p = 0; p < 2; ++p)
+  {
+    // (both parities at once: the next batch's copies would otherwise be allocated -- and the stream drained -- in the
+    // middle of a run of batches)
+    OHMHIP_CHECK(m->walks_buf[p].ensure(sizeof(RayWalk) * size_t(n_rays), false, s));
+    OHMHIP_CHECK(m->wg_regions[p].ensure(sizeof(WgRegion) * size_t(bin_blocks) * kLtabSize, false, s));
+    OHMHIP_CHECK(m->wg_region_count[p].ensure(sizeof(uint32_t) * size_t(bin_blocks), false, s));
+  }
   if (occupancy_mode)
   {
     OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * size_t(n_rays), false, s));
