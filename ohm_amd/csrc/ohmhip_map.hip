@@ -140,7 +140,8 @@ struct ohmhip_map_s
   uint32_t chunk_segments = kChunkSegments;  ///< tunable (OHMHIP_CHUNK_SEGMENTS), <= kMaxChunkSegments (15-bit LDS counters)
   /// OHMHIP_DEBUG_FLAGS (development only): 16 = walk kernel refills lanes but does not walk (timing experiments,
   /// breaks results); 64 = per-chunk timing trace of the walk kernel (OHMHIP_DEBUG_TRACE=<file>, scripts/
-  /// analyse_trace.py); 128 = iteration / visit / refill counters (hot-address atomics: distorts timing).
+  /// analyse_trace.py); 128 = iteration / visit / refill counters (hot-address atomics: distorts timing); 256 = phase
+  /// timeline of the last three batches printed by ohmhip_map_sync.
   unsigned debug_flags = 0;
   int refill_min_idle = kRefillMinIdle;      ///< tunable (OHMHIP_REFILL_MIN_IDLE)  ///< events the previous batch produced (sizes the next batch's list)
   void *h_stage = nullptr;  ///< pinned staging for region copies
@@ -2100,6 +2101,26 @@ try
     OHMHIP_CHECK(hipMemset(m->d_dbg, 0, sizeof(c)));
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
+  if ((m->debug_flags & 256u) && m->batch_seq >= 4)
+  {
+    // Development aid: when the phases of the last three batches started / ended, relative to the first of them
+    // (set-up start, set-up + plan end, bin start, bin end, sort end, walk end, batch end).
+    static const int order[7] = { 0, 5, 6, 1, 2, 3, 4 };
+    static const char *const names[7] = { "setup>", "plan<", "bin>", "bin<", "sort<", "walk<", "end" };
+    hipEvent_t origin = m->tev[(m->batch_seq - 3) % kTimingRing][0];
+    for (uint64_t back = 3; back >= 1; --back)
+    {
+      hipEvent_t *tev = m->tev[(m->batch_seq - back) % kTimingRing];
+      std::fprintf(stderr, "[ohmhip timeline] batch -%llu:", (unsigned long long)back);
+      for (int k = 0; k < 7; ++k)
+      {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, origin, tev[order[k]]);
+        std::fprintf(stderr, " %s %.0f", names[k], ms * 1e3f);
+      }
+      std::fprintf(stderr, "\n");
+    }
+  }
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH
