@@ -1753,7 +1753,16 @@ struct WalkArgs
   /// TSDF with weight drop-off: a free-space visit changes the weight by a value that depends on the voxel and the
   /// ray, so no voxel can be counted -- every visit of the batch is an event for the ordered replay.
   int flag_all;
+  /// Occupancy maps without mean / secondary layers: a region held by a single chunk whose samples are all staged in
+  /// LDS has its samples replayed by the walk's epilogue itself (the ordered sample list, the interval counters and the
+  /// trailing counts are all in LDS at that point); the region is marked kSamplesApplied for k_apply_hits.
+  int inline_hits;
 };
+
+/// Top bit of BatchScratch::hit_begin[slot], set by the walk kernel once it has replayed the region's samples itself
+/// (the array is this batch's own copy -- see ohmhip_map.hip: parity -- and k_plan rewrites the entry of every region a
+/// batch touches, so the mark lives exactly from the walk to the end of the batch).
+constexpr uint32_t kSamplesApplied = 0x80000000u;
 
 constexpr double kTraversalScale = 1099511627776.0;  ///< 2^40 fixed-point units per metre of traversal
 constexpr uint32_t kWalkCursorWords = 24;  ///< l_cursor[]: see k_region_walk
@@ -2437,7 +2446,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 24] = wall_clock64();  // epilogue start
     }
 
-    if (lds_resolve)
+    const bool inline_hits = args.inline_hits && lds_resolve && n_region_hits > 0u && args.occupancy && !args.rewalk &&
+                             (chunk.hash_index & 0x80000000u);
+    if (lds_resolve && !inline_hits)
     {
       for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
       {
@@ -2480,7 +2491,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         // Keep only the entries applied here: unflagged voxels with a count.
         w = (w & kTileFlag) ? (w & 0xffff0000u) : w;
         w = (w & (kTileFlag << 16)) ? (w & 0x0000ffffu) : w;
-        if (!defer_all)
+        if (!defer_all && !inline_hits)
         {
           // Voxels which also receive samples keep their count for the ordered replay (k_apply_hits).
           if ((flagged_w & kTileFlag) && (flagged_w & kTileCountMask))
@@ -2527,6 +2538,35 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         }
       }
       }  // halves
+      if (inline_hits)
+      {
+        // Ordered replay of the region's samples, one lane per voxel with samples (the head of its run in the sorted
+        // list): misses before each sample from the interval counters, the sample, the trailing misses from the tile.
+        // These voxels are disjoint from the ones the passes above wrote.
+        for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
+        {
+          const unsigned long long key = l_hits[i];
+          const unsigned long long group = key >> kHitRayBits;
+          if (i > 0u && (l_hits[i - 1u] >> kHitRayBits) == group)
+          {
+            continue;
+          }
+          const uint32_t vi = uint32_t(group) & ((1u << kHitVoxelBits) - 1u);
+          float x = g_occ[vi];
+          for (uint32_t j = i; j < n_region_hits && (l_hits[j] >> kHitRayBits) == group; ++j)
+          {
+            x = occMissN(mc, args.ray_flags, x, (l_intervals[j >> 1] >> ((j & 1u) * 16u)) & 0xffffu);
+            x = occHit(mc, args.ray_flags, x);
+          }
+          const uint32_t w = l_counts[tileWord(vi >> 1)];
+          x = occMissN(mc, args.ray_flags, x, (w >> ((vi & 1u) * 16u)) & kTileCountMask);
+          g_occ[vi] = x;
+        }
+        if (threadIdx.x == 0)
+        {
+          atomicOr(&args.bs.hit_begin[chunk.slot], kSamplesApplied);
+        }
+      }
       if (stamp && chunk_index < kTraceChunks)
       {
         args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 19] = wall_clock64();
@@ -2664,6 +2704,10 @@ __device__ inline void applyHits(uint32_t i, const MapConst &mc, const RegionTab
     return;  // not the head of its voxel group
   }
   const uint32_t slot = uint32_t(key >> kHitSlotShift);
+  if (bs.hit_begin[slot] & kSamplesApplied)
+  {
+    return;  // the walk kernel replayed this region's samples itself (WalkArgs::inline_hits)
+  }
   const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
   const size_t gi = size_t(slot) * size_t(mc.region_voxels) + vi;
   float x = occupancy[gi];

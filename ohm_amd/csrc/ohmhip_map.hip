@@ -975,6 +975,10 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         // layer has its sums already.
         wa.rewalk = (walk_attempt > 0 && (direct_occ || tsdf_mode)) ? 1 : 0;
         wa.flag_all = ((tsdf_mode && m->mc.tsdf_dropoff > 0) || stop_mode) ? 1 : 0;
+        wa.inline_hits = (occupancy_mode && !m->layers[OHMHIP_LID_MEAN] && !sec.traversal && !sec.touch_time &&
+                          !sec.incident && !m->layers[OHMHIP_LID_INTENSITY] && !m->layers[OHMHIP_LID_HIT_MISS]) ?
+                           1 :
+                           0;
         const bool walk_traversal = sec.traversal != nullptr && walk_attempt == 0;
         // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited) or the
         // traversal layer needs the exit range of an end voxel that is part of the walk.  (An end voxel that is walked --
