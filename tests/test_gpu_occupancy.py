@@ -216,9 +216,12 @@ def test_rays_through_voxel_and_region_corners(gpu, origin):
     assert gm.stats()["voxel_visits"] > 0
 
 
-def test_ray_flag_combinations(gpu):
+@pytest.mark.parametrize("layers", [("occupancy", "mean"), ("occupancy",)])
+def test_ray_flag_combinations(gpu, layers):
     # Every subset of the value-dependent / geometry flags, each on a map that already holds free, occupied and
     # unobserved voxels (a first default pass), so kRfExcludeFree / kRfExcludeOccupied / kRfExcludeUnobserved bite.
+    # (Occupancy-only maps replay the samples of single-chunk regions in the walk kernel's epilogue, maps with a mean
+    # layer in k_apply_hits: both routes see every flag.)
     base = synth.random_rays(1500, extent=4.0, seed=51, origin_spread=0.5)
     probe = synth.random_rays(1500, extent=4.0, seed=52, origin_spread=0.5)
     bits = [RayFlag.kRfEndPointAsFree, RayFlag.kRfExcludeOrigin, RayFlag.kRfExcludeSample, RayFlag.kRfExcludeUnobserved,
@@ -227,7 +230,7 @@ def test_ray_flag_combinations(gpu):
         flags = 0
         for k, b in enumerate(bits):
             flags |= int(b) if (subset >> k) & 1 else 0
-        map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+        map_ = OccupancyMap(0.1, (32, 32, 32), layers=layers)
         gm = GpuMap(map_)
         om = make_oracle(map_)
         gm.integrateRays(base)
@@ -235,7 +238,7 @@ def test_ray_flag_combinations(gpu):
         gm.integrateRays(probe, ray_update_flags=flags)
         om.integrate_occupancy(probe, flags=flags)
         gm.syncVoxels()
-        stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
+        stats = compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True)
         assert not {k: v for k, v in stats.items() if (k.startswith("diff_") or k.endswith("_on_gpu")) and v}, (flags, stats)
 
 
@@ -253,12 +256,13 @@ def test_very_long_rays_overflow_the_workgroup_region_table(gpu):
     assert gm.stats()["voxel_visits"] == stats["visits_cpu"]
 
 
+@pytest.mark.parametrize("layers", [("occupancy", "mean"), ("occupancy",)])
 @pytest.mark.parametrize("sat_min,sat_max", [(False, False), (True, False), (False, True), (True, True)])
-def test_non_default_probabilities_clamps_and_saturation(gpu, sat_min, sat_max):
+def test_non_default_probabilities_clamps_and_saturation(gpu, sat_min, sat_max, layers):
     # ohm/VoxelOccupancyCompute.h:44-54, 110-120: saturation freezes a voxel once it reaches min / max; tight clamps make
     # that happen quickly.  Several passes over the same rays so the frozen states matter.
     rays = synth.rays_c1(n=20000, max_range=8.0)
-    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=layers)
     map_.setHitProbability(0.8)
     map_.setMissProbability(0.35)
     map_.min_voxel_value = np.float32(-1.1)
@@ -271,7 +275,7 @@ def test_non_default_probabilities_clamps_and_saturation(gpu, sat_min, sat_max):
         gm.integrateRays(rays)
         om.integrate_occupancy(rays)
     gm.syncVoxels()
-    stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True)
+    stats = compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True)
     assert_parity(stats)
 
 
