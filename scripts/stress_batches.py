@@ -1,0 +1,37 @@
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+from ohm_amd import GpuMap, OccupancyMap, RayFlag, synth
+from parity import compare_maps, make_oracle
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+layers = ("occupancy",) if rng.integers(2) else ("occupancy", "mean")
+map_ = OccupancyMap(0.1, (32, 32, 32), layers=layers)
+gm = GpuMap(map_, region_capacity=64)   # tiny pool: grows repeatedly
+om = make_oracle(map_)
+all_rays = synth.rays_c1(n=400000, max_range=20.0)
+pos = 0
+n_batches = 0
+t0 = time.time()
+while pos < all_rays.shape[0] // 2 and n_batches < 200:
+    n = int(rng.choice([500, 3000, 4096, 20000, 65536, 120000]))
+    part = all_rays[2 * pos:2 * (pos + n)]
+    if part.shape[0] == 0:
+        break
+    pos += n
+    flags = int(rng.choice([0, 0, 0, int(RayFlag.kRfEndPointAsFree), int(RayFlag.kRfExcludeOrigin)]))
+    got = gm.integrateRays(part, ray_update_flags=flags)
+    assert got == part.shape[0], (got, part.shape)
+    om.integrate_occupancy(part, flags=flags)
+    r = rng.integers(6)
+    if r == 0:
+        gm.syncVoxels()
+    elif r == 1:
+        gm.stats()
+    elif r == 2:
+        gm.wait()
+    n_batches += 1
+gm.syncVoxels()
+stats = compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True)
+bad = {k: v for k, v in stats.items() if (k.startswith("diff_") or k.endswith("_on_gpu") or k.endswith("_on_cpu")) and v}
+print("seed", sys.argv[1:], "layers", layers, "batches", n_batches, "rays", pos, "regions", len(map_.chunks), "bad", bad, "%.1fs" % (time.time() - t0))
+assert not bad
