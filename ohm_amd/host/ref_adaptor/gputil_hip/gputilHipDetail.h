@@ -14,7 +14,7 @@ namespace gputil
 {
 class Event;
 struct EventDetail;
-/// Hand a freshly created detail (reference count 1) to an invalid Event (gpuEvent.cpp; used by Queue::mark()).
+/// Hand a freshly created detail (reference count 1) to an invalid Event (gputilHip.cpp; used by Queue::mark()).
 void adoptEventDetail(Event &event, EventDetail *detail);
 
 struct DeviceDetail
