@@ -316,7 +316,9 @@ class GpuMap(RayMapper):
         return int(done.value)
 
     def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=RayFlag.kRfDefault):
-        """Rays already resident in HBM (bench path): d_rays_ptr is a raw device pointer to element_count dvec3."""
+        """Rays already resident in HBM (bench path): d_rays_ptr is a raw device pointer to element_count dvec3.  The
+        array must be complete when the call is made (synchronise the stream that produced it): the map reads it on
+        streams of its own."""
         done = C.c_size_t(0)
         status = L.lib.ohmhip_map_integrate_rays_device(self._handle, d_rays_ptr, element_count, None, None,
                                                         int(ray_update_flags), C.byref(done))

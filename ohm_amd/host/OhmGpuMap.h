@@ -447,7 +447,8 @@ public:
                          ray_update_flags);
   }
   /// Rays already resident in device memory (e.g. the output buffer of GpuTransformSamples::transform): the same
-  /// integration without the host-to-device staging.
+  /// integration without the host-to-device staging.  The buffer's content must be complete when the call is made (the
+  /// transform is synchronous; wait for any other producer): the map reads it on streams of its own.
   size_t integrateRays(const gputil::Buffer &device_rays, size_t element_count, unsigned ray_update_flags = kRfDefault)
   {
     if (!gpuOk() || !device_rays.isValid() || element_count < 2)
