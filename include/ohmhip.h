@@ -242,15 +242,31 @@ typedef struct ohmhip_cache_stats
   uint32_t region_capacity;   /* regions the pool holds without growing                                   */
   uint64_t bytes_per_region;  /* all enabled layers + per-region scratch                                    */
   uint64_t memory_limit;      /* see ohmhip_map_set_memory_limit (0 = device memory is the limit)           */
+  uint64_t evictions;         /* regions moved to the host store (ohmhip_map_set_spill_to_host)             */
+  uint64_t readmissions;      /* regions brought back from it                                               */
+  uint32_t regions_spilled;   /* regions in the host store right now                                        */
+  uint32_t spill_enabled;
 } ohmhip_cache_stats;
 int ohmhip_map_cache_stats(ohmhip_map_t map, ohmhip_cache_stats *stats, int reset);
-/* RESIDENCY LIMIT.  There is no eviction: a map that outgrows what it may allocate fails the batch that needs the
+/* RESIDENCY LIMIT.  Without spilling (below) a map that outgrows what it may allocate fails the batch that needs the
  * extra regions with OHMHIP_ERR_CAPACITY and stays exactly as it was before that batch (the batch's region inserts are
  * rolled back), so the caller can cull regions (ohmhip_map_remove_regions after reading them back) and present the
- * batch again.  The limit is free device memory -- 288 GB of HBM3E hold about 1 million 32^3 occupancy-only regions
- * (8.1 B per voxel with scratch) -- or, when set, `bytes` for this map's region pool (the reference's gpu_mem_size, ohmgpu/GpuCache.h:90, bounds its cache
- * the same way).  0 removes the limit. */
+ * batch again -- or turn on ohmhip_map_set_spill_to_host and let the library move cold regions to host memory.  The
+ * limit is free device memory -- 288 GB of HBM3E hold about 1 million 32^3 occupancy-only regions (8.1 B per voxel
+ * with scratch) -- or, when set, `bytes` for this map's region pool (the reference's gpu_mem_size,
+ * ohmgpu/GpuCache.h:90, bounds its cache the same way).  0 removes the limit. */
 int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
+/* SPILL TO HOST (off by default).  With it on, a batch that needs more regions than the memory limit (or the device)
+ * allows no longer fails: the least recently used resident regions -- the counterpart of the reference's LRU slot
+ * reuse, ohmgpu/GpuLayerCache.cpp:530-584, a quarter of the pool at a time -- are copied to a host store inside the
+ * library and dropped from the pool, and the batch is repeated.  A stored region stays part of the map: it is listed by
+ * ohmhip_map_regions / _region_count / _dirty_regions, ohmhip_map_read_regions serves it from the store, and it returns
+ * to the pool with its content when a later batch reaches it or an upload / ohmhip_map_ensure_regions names it.  Results
+ * are those of an unbounded pool.  What does not combine with it: replica merge (OHMHIP_ERR_UNSUPPORTED either way
+ * round) and the zero-copy views (ohmhip_map_region_slot reports OHMHIP_ERR_NOT_FOUND for a stored region).  A batch
+ * that alone touches more regions than the limit allows still fails with OHMHIP_ERR_CAPACITY; turning spilling on
+ * therefore sets the batch coalescing threshold to 0 (a collected batch touches the regions of all its calls at once). */
+int ohmhip_map_set_spill_to_host(ohmhip_map_t map, int enable);
 /* Wait for all queued work (GpuMap::syncVoxels fence half, ohmgpu/GpuMap.cpp:308-324). */
 int ohmhip_map_sync(ohmhip_map_t map);
 int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);

@@ -61,7 +61,9 @@ class MergeStats(C.Structure):
 
 class CacheStats(C.Structure):
     _fields_ = [("hits", C.c_uint64), ("misses", C.c_uint64), ("full", C.c_uint64), ("regions_resident", C.c_uint32),
-                ("region_capacity", C.c_uint32), ("bytes_per_region", C.c_uint64), ("memory_limit", C.c_uint64)]
+                ("region_capacity", C.c_uint32), ("bytes_per_region", C.c_uint64), ("memory_limit", C.c_uint64),
+                ("evictions", C.c_uint64), ("readmissions", C.c_uint64), ("regions_spilled", C.c_uint32),
+                ("spill_enabled", C.c_uint32)]
 
 
 COMM_ID_BYTES = 128
@@ -133,6 +135,7 @@ _sigs = {
     "ohmhip_region_owner": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_uint32, _vp]),
     "ohmhip_map_cache_stats": (C.c_int, [_vp, C.POINTER(CacheStats), C.c_int]),
     "ohmhip_map_set_memory_limit": (C.c_int, [_vp, C.c_uint64]),
+    "ohmhip_map_set_spill_to_host": (C.c_int, [_vp, C.c_int]),
     "ohmhip_comm_unique_id": (C.c_int, [_vp]),
     "ohmhip_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
     "ohmhip_comm_destroy": (C.c_int, [_vp]),

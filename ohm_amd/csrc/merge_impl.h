@@ -199,6 +199,10 @@ try
   {
     return OHMHIP_OK;
   }
+  if (m->spill_enabled || !m->spilled.empty())
+  {
+    return OHMHIP_ERR_UNSUPPORTED;  // a merging map keeps a base copy per resident region: not combined with spilling
+  }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   const size_t bytes = size_t(m->mc.region_voxels) * sizeof(float) * m->slot_capacity;
   if (hipMalloc(reinterpret_cast<void **>(&m->d_merge_base), bytes) != hipSuccess)

@@ -51,6 +51,8 @@ struct BatchScratch
   uint32_t *hit_begin;     ///< [slot_capacity] first sample of the region in the sorted list
   uint32_t *hit_end;       ///< [slot_capacity]
   uint32_t *dirty;         ///< [slot_capacity]
+  uint32_t *last_use;      ///< [slot_capacity] stamp of the last batch that touched the region (spill-to-host: LRU)
+  uint32_t stamp;          ///< this batch's stamp
   uint32_t *voxel_first_hit;  ///< [slot_capacity * region_voxels] index of a voxel's first sample in the sorted list
   BatchInfo *info;
   struct WgRegion *wg_regions;  ///< [workgroups * kLtabSize] regions each binning workgroup feeds (k_ray_setup -> bin)
@@ -870,6 +872,7 @@ __global__ void __launch_bounds__(1024)
         bs.hit_begin[slot] = hit_excl;
         bs.hit_end[slot] = hit_excl;
         bs.dirty[slot] |= 3u;  // modified since the last syncVoxels() (bit 0) / the last replica merge (bit 1)
+        bs.last_use[slot] = bs.stamp;
       }
       if (nchk)
       {

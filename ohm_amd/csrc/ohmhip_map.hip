@@ -109,6 +109,7 @@ struct ohmhip_map_s
   uint32_t *d_seg_count = nullptr, *d_seg_cursor = nullptr, *d_seg_offset = nullptr, *d_touched_flag = nullptr,
            *d_touched = nullptr;
   uint32_t *d_voxel_first_hit = nullptr, *d_hit_begin = nullptr, *d_hit_end = nullptr, *d_dirty = nullptr;
+  uint32_t *d_last_use = nullptr;  ///< [slot_capacity] batch stamp of a region's last use (k_plan); moves with the slot
   BatchInfo *d_info = nullptr;   ///< three summaries used in turn: k_plan of one batch zeroes the next batch's
   BatchInfo *h_info = nullptr;   ///< pinned, device visible: [0] batch summary (written by k_plan), [1] event count
   BatchInfo *h_info_dev = nullptr;  ///< device address of h_info
@@ -176,7 +177,25 @@ struct ohmhip_map_s
   bool stats_pending = false;
   uint64_t cache_hits = 0, cache_misses = 0, cache_full = 0;  ///< ohmhip_map_cache_stats
   uint64_t memory_limit = 0;                                   ///< ohmhip_map_set_memory_limit
+  /// Spill to host (ohmhip_map_set_spill_to_host): regions evicted from the pool when the memory limit is reached, by
+  /// packed key.  A spilled region is still part of the map: it is listed, read and synced from here, and moves back
+  /// into the pool when a batch (or an upload) touches it.
+  struct SpilledRegion
+  {
+    std::vector<char> layer[OHMHIP_LID_COUNT];
+    std::vector<uint32_t> mask_row;  ///< NDT / TSDF: the persistent per-voxel replay mask
+    uint32_t dirty = 0;
+  };
+  std::unordered_map<uint64_t, SpilledRegion> spilled;
+  bool spill_enabled = false;
+  uint64_t evictions = 0, readmissions = 0;
 };
+
+// Defined further down (they use the region read / remove machinery of the C ABI section).
+int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed);
+int evictColdRegions(ohmhip_map_t m, uint32_t want_free);
+int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot);
+int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count);
 
 namespace
 {
@@ -210,6 +229,8 @@ BatchScratch batchScratch(ohmhip_map_t m)
   bs.hit_begin = m->d_hit_begin + c;
   bs.hit_end = m->d_hit_end + c;
   bs.dirty = m->d_dirty;
+  bs.last_use = m->d_last_use;
+  bs.stamp = uint32_t(m->batch_seq + 1u);
   bs.info = m->d_info + m->info_index;
   bs.wg_regions = static_cast<WgRegion *>(m->wg_regions[m->parity].ptr);
   bs.wg_region_count = static_cast<uint32_t *>(m->wg_region_count[m->parity].ptr);
@@ -281,7 +302,8 @@ void freePool(ohmhip_map_t m)
   }
   void *ptrs[] = { m->d_keys,       m->d_vals,        m->d_slot_keys, m->d_seg_count, m->d_seg_cursor,
                    m->d_seg_offset, m->d_touched_flag, m->d_touched,   m->d_voxel_first_hit, m->d_hit_begin, m->d_hit_end,
-                   m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks,    m->d_hit_count, m->d_sort_list };
+                   m->d_dirty,      m->d_miss_counts,  m->d_hit_mask,  m->d_chunks,    m->d_hit_count, m->d_sort_list,
+                   m->d_last_use };
   for (void *p : ptrs)
   {
     if (p)
@@ -294,6 +316,7 @@ void freePool(ohmhip_map_t m)
   m->d_slot_keys = nullptr;
   m->d_seg_count = m->d_seg_cursor = m->d_seg_offset = m->d_touched_flag = m->d_touched = nullptr;
   m->d_voxel_first_hit = m->d_hit_begin = m->d_hit_end = m->d_dirty = nullptr;
+  m->d_last_use = nullptr;
   m->d_miss_counts = m->d_hit_mask = nullptr;
   m->d_chunks = nullptr;
   m->d_hit_count = m->d_sort_list = nullptr;
@@ -334,7 +357,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   };
   void *new_layers[OHMHIP_LID_COUNT] = {};
   uint64_t *new_slot_keys = nullptr;
-  uint32_t *new_mask = nullptr, *new_dirty = nullptr;
+  uint32_t *new_mask = nullptr, *new_dirty = nullptr, *new_last_use = nullptr;
   unsigned long long *n_keys = nullptr;
   uint32_t *n_vals = nullptr, *n_seg_count = nullptr, *n_seg_cursor = nullptr, *n_hit_count = nullptr,
            *n_sort_list = nullptr, *n_seg_offset = nullptr, *n_touched_flag = nullptr, *n_touched = nullptr,
@@ -390,6 +413,11 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
     if (keep && m->d_dirty)
     {
       OHMHIP_CHECK(hipMemcpyAsync(new_dirty, m->d_dirty, sizeof(uint32_t) * keep, hipMemcpyDeviceToDevice, s));
+    }
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&new_last_use), sizeof(uint32_t) * capacity));
+    if (keep && m->d_last_use)
+    {
+      OHMHIP_CHECK(hipMemcpyAsync(new_last_use, m->d_last_use, sizeof(uint32_t) * keep, hipMemcpyDeviceToDevice, s));
     }
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_keys), sizeof(unsigned long long) * hash_cap));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_vals), sizeof(uint32_t) * hash_cap));
@@ -450,6 +478,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   m->d_slot_keys = new_slot_keys;
   m->d_hit_mask = new_mask;
   m->d_dirty = new_dirty;
+  m->d_last_use = new_last_use;
   m->d_keys = n_keys;
   m->d_vals = n_vals;
   m->d_seg_count = n_seg_count;
@@ -543,12 +572,19 @@ int rollbackTable(ohmhip_map_t m)
 }
 
 /// Restore the region table after a batch that overflowed the pool: drop regions the failed batch inserted.
+/// `needed`: the slots the batch must have; the pool is at least doubled beyond that where it may (amortised growth).
 int rollbackAndGrow(ohmhip_map_t m, uint32_t needed)
 {
   uint32_t cap = 0;
+  const uint32_t wish = std::max(needed, std::min(m->slot_capacity * 2u, kMaxRegionSlots));
   if (!grownCapacity(m->slot_capacity, needed, cap))
   {
     return OHMHIP_ERR_CAPACITY;
+  }
+  uint32_t wished_cap = cap;
+  if (grownCapacity(m->slot_capacity, wish, wished_cap))
+  {
+    cap = wished_cap;
   }
   // Check memory budget: refuse if the new pool cannot fit in free device memory, or in the map's own limit (the
   // largest pool the limit allows is still tried when doubling overshoots it).
@@ -830,18 +866,46 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       // Pool exhausted: forget what this batch inserted, grow, retry.
       OHMHIP_CHECK(hipStreamSynchronize(s));
       m->spec_bucket_ok = false;
-      const int err = rollbackAndGrow(m, std::max(info.n_slots, std::min(m->slot_capacity * 2u, kMaxRegionSlots)));
+      const int err = rollbackAndGrow(m, info.n_slots);
       if (err)
       {
-        // The pool may not grow (memory limit / device memory / slot field): the batch fails, the map stays as it was.
+        // The pool may not grow (memory limit / device memory / slot field): forget what the batch inserted.
         const int rollback_err = rollbackTable(m);
-        return rollback_err ? rollback_err : err;
+        if (rollback_err)
+        {
+          return rollback_err;
+        }
+        if (err == OHMHIP_ERR_CAPACITY && m->spill_enabled && !(info.error & kErrHashFull) &&
+            info.n_slots > m->slots_committed)
+        {
+          // Spill to host: make room by moving the least recently used regions to the host store, then repeat the
+          // batch.  (The failed attempt's k_plan stamped the regions this batch touches: they go last.)
+          const uint64_t per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
+          const uint64_t allowed =
+            m->memory_limit ? std::min<uint64_t>(m->memory_limit / per_region, kMaxRegionSlots) : m->slot_capacity;
+          const uint64_t wanted = uint64_t(info.n_slots);  // committed + the batch's new regions
+          if (wanted > allowed && wanted - allowed <= m->slots_committed)
+          {
+            const int evict_err = evictColdRegions(m, uint32_t(wanted - allowed));
+            if (evict_err == OHMHIP_OK)
+            {
+              continue;
+            }
+          }
+        }
+        return err;  // the batch fails, the map stays as it was
       }
       continue;
     }
 
     m->cache_misses += info.n_slots - m->slots_committed;
     m->cache_hits += info.n_touched - std::min(info.n_touched, info.n_slots - m->slots_committed);
+    if (!m->spilled.empty())
+    {
+      // Regions this batch created that are waiting in the host store: their content comes back before the binning
+      // pass (NDT / TSDF: the replay mask) and the walk see them.
+      OHMHIP_CHECK(readmitSpilledSlots(m, m->slots_committed, info.n_slots));
+    }
     m->slots_committed = info.n_slots;
     if (speculated && (info.n_segments > spec_seg_cap || info.max_region_hits > kSortRegionHits))
     {
@@ -2182,9 +2246,14 @@ try
   stats->region_capacity = m->slot_capacity;
   stats->bytes_per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
   stats->memory_limit = m->memory_limit;
+  stats->evictions = m->evictions;
+  stats->readmissions = m->readmissions;
+  stats->regions_spilled = uint32_t(m->spilled.size());
+  stats->spill_enabled = m->spill_enabled ? 1u : 0u;
   if (reset)
   {
     m->cache_hits = m->cache_misses = m->cache_full = 0;
+    m->evictions = m->readmissions = 0;
   }
   return OHMHIP_OK;
 }
@@ -2198,6 +2267,29 @@ try
     return OHMHIP_ERR_INVALID_ARG;
   }
   m->memory_limit = bytes;
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_set_spill_to_host(ohmhip_map_t m, int enable)
+try
+{
+  OHMHIP_SETTLE(m);
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (enable && m->d_merge_base)
+  {
+    return OHMHIP_ERR_UNSUPPORTED;  // replica-merge maps keep a base copy per region: they do not spill
+  }
+  m->spill_enabled = enable != 0;
+  if (m->spill_enabled)
+  {
+    // A collected batch touches the regions of all its calls at once -- more than any one of them, possibly more than
+    // the limit holds: with spilling on every call runs as its own device batch (the caller may still set a threshold).
+    m->coalesce_min_rays = 0;
+  }
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH
@@ -2235,7 +2327,7 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
-  *count = m->slots_committed;
+  *count = size_t(m->slots_committed) + m->spilled.size();  // (regions in the host store are part of the map)
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH
@@ -2254,10 +2346,15 @@ try
   {
     return err;
   }
-  *count = m->slot_keys_host.size();
-  for (size_t i = 0; i < m->slot_keys_host.size() && i < capacity && keys_xyz; ++i)
+  *count = m->slot_keys_host.size() + m->spilled.size();
+  size_t at = 0;
+  for (; at < m->slot_keys_host.size() && at < capacity && keys_xyz; ++at)
   {
-    unpackRegionKey(m->slot_keys_host[i], keys_xyz + 3 * i);
+    unpackRegionKey(m->slot_keys_host[at], keys_xyz + 3 * at);
+  }
+  for (auto it = m->spilled.begin(); it != m->spilled.end() && at < capacity && keys_xyz; ++it, ++at)
+  {
+    unpackRegionKey(it->first, keys_xyz + 3 * at);
   }
   return OHMHIP_OK;
 }
@@ -2294,6 +2391,17 @@ try
       ++n;
     }
   }
+  for (const auto &entry : m->spilled)
+  {
+    if (entry.second.dirty & kDirtySync)
+    {
+      if (keys_xyz && n < capacity)
+      {
+        unpackRegionKey(entry.first, keys_xyz + 3 * n);
+      }
+      ++n;
+    }
+  }
   *count = n;
   return OHMHIP_OK;
 }
@@ -2308,6 +2416,10 @@ try
     return OHMHIP_ERR_INVALID_ARG;
   }
   hipLaunchKernelGGL(k_and_u32, dim3(256), dim3(256), 0, m->stream, m->d_dirty, ~kDirtySync, size_t(m->slot_capacity));
+  for (auto &entry : m->spilled)
+  {
+    entry.second.dirty &= ~kDirtySync;
+  }
   return hipGetLastError();
 }
 OHMHIP_ABI_CATCH
@@ -2376,6 +2488,33 @@ try
     return err;
   }
   const size_t stride = size_t(m->mc.region_voxels) * kLayerBytes[layer_id];
+  std::vector<int16_t> resident_keys;
+  std::vector<void *> resident_dsts;
+  if (!m->spilled.empty())
+  {
+    // Regions in the host store are copied straight from there; the rest goes through the device path below.
+    for (size_t k = 0; k < count; ++k)
+    {
+      const int16_t *key = keys_xyz + 3 * k;
+      const auto it = m->spilled.find(packRegionKey(key[0], key[1], key[2]));
+      if (it != m->spilled.end())
+      {
+        if (it->second.layer[layer_id].size() != stride)
+        {
+          return OHMHIP_ERR_INTERNAL;
+        }
+        std::memcpy(dsts[k], it->second.layer[layer_id].data(), stride);
+      }
+      else
+      {
+        resident_keys.insert(resident_keys.end(), key, key + 3);
+        resident_dsts.push_back(dsts[k]);
+      }
+    }
+    keys_xyz = resident_keys.data();
+    dsts = resident_dsts.data();
+    count = resident_dsts.size();
+  }
   // Pinned double-buffered staging on the copy stream, 64 regions per burst.
   const size_t burst = 64;
   err = ensureStage(m, std::max(m->h_stage_bytes, 2 * burst * stride));
@@ -2502,6 +2641,7 @@ try
     return OHMHIP_ERR_NOT_FOUND;
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  OHMHIP_CHECK(readmitSpilledKeys(m, keys_xyz, count));  // (an upload edits the region where it lives: in the pool)
   int err = refreshHostRegionTable(m);
   if (err)
   {
@@ -2591,6 +2731,7 @@ try
     return OHMHIP_ERR_INVALID_ARG;
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  OHMHIP_CHECK(readmitSpilledKeys(m, keys_xyz, count));
   int err = refreshHostRegionTable(m);
   if (err)
   {
@@ -2648,6 +2789,31 @@ try
     return OHMHIP_ERR_INVALID_ARG;
   }
   OHMHIP_SETTLE(m);
+  // Regions held in the host store (spill to host) are simply forgotten.
+  size_t forgotten = 0;
+  for (size_t i = 0; i < count && !m->spilled.empty(); ++i)
+  {
+    forgotten += m->spilled.erase(packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]));
+  }
+  size_t resident_removed = 0;
+  const int err = removeResidentRegions(m, keys_xyz, count, &resident_removed);
+  if (removed)
+  {
+    *removed = resident_removed + forgotten;
+  }
+  return err;
+}
+OHMHIP_ABI_CATCH
+
+}  // extern "C"
+
+/// Drop resident regions from the pool (ohmhip_map_remove_regions; also the second half of an eviction).
+int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed)
+{
+  if (removed)
+  {
+    *removed = 0;
+  }
   hipStream_t s = m->stream;
   OHMHIP_CHECK(hipStreamSynchronize(s));
   int err = refreshHostRegionTable(m);
@@ -2705,6 +2871,7 @@ try
                                 reinterpret_cast<const char *>(m->d_hit_mask) + mask_row * src, mask_row,
                                 hipMemcpyDeviceToDevice, s));
     OHMHIP_CHECK(hipMemcpyAsync(m->d_dirty + dst, m->d_dirty + src, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    OHMHIP_CHECK(hipMemcpyAsync(m->d_last_use + dst, m->d_last_use + src, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     if (m->d_merge_base)
     {
       OHMHIP_CHECK(hipMemcpyAsync(m->d_merge_base + rv * dst, m->d_merge_base + rv * src, sizeof(float) * rv,
@@ -2733,6 +2900,7 @@ try
   }
   OHMHIP_CHECK(hipMemsetAsync(reinterpret_cast<char *>(m->d_hit_mask) + mask_row * new_n, 0, mask_row * k, s));
   OHMHIP_CHECK(hipMemsetAsync(m->d_dirty + new_n, 0, sizeof(uint32_t) * k, s));
+  OHMHIP_CHECK(hipMemsetAsync(m->d_last_use + new_n, 0, sizeof(uint32_t) * k, s));
   if (m->d_merge_base)
   {
     hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint32_t *>(m->d_merge_base + rv * new_n),
@@ -2762,7 +2930,168 @@ try
   m->spec_bucket_ok = false;  // per-slot sample ranges of the previous batch no longer describe these slots
   return OHMHIP_OK;
 }
-OHMHIP_ABI_CATCH
+
+/// Spill to host, first half: copy the least recently used resident regions into the host store and drop them from the
+/// pool, so that at least `want_free` slots become free (a quarter of the pool at a time, so evictions are rare).
+/// Regions the current batch attempt touched carry the newest stamp (k_plan) and go last.
+int evictColdRegions(ohmhip_map_t m, uint32_t want_free)
+{
+  hipStream_t s = m->stream;
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+  OHMHIP_CHECK(refreshHostRegionTable(m));
+  const uint32_t n = m->slots_committed;
+  if (n == 0 || m->d_merge_base)
+  {
+    return OHMHIP_ERR_CAPACITY;  // nothing to evict / replica-merge maps keep a base copy per region: not spilled
+  }
+  const uint32_t k = std::min(n, std::max(want_free, n / 4u));
+  std::vector<uint32_t> stamps(n), dirty(n);
+  OHMHIP_CHECK(hipMemcpy(stamps.data(), m->d_last_use, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  OHMHIP_CHECK(hipMemcpy(dirty.data(), m->d_dirty, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> order(n);
+  for (uint32_t i = 0; i < n; ++i)
+  {
+    order[i] = i;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return stamps[a] < stamps[b]; });
+  const size_t rv = size_t(m->mc.region_voxels);
+  const size_t mask_words = (rv + 31) / 32;
+  const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;  // (transient in occupancy mode: empty between batches)
+  std::vector<int16_t> victim_keys(3 * size_t(k));
+  for (uint32_t v = 0; v < k; ++v)
+  {
+    const uint32_t slot = order[v];
+    const uint64_t key = m->slot_keys_host[slot];
+    ohmhip_map_s::SpilledRegion &store = m->spilled[key];
+    for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+    {
+      if (m->layers[l])
+      {
+        const size_t stride = rv * kLayerBytes[l];
+        store.layer[l].resize(stride);
+        OHMHIP_CHECK(hipMemcpy(store.layer[l].data(), static_cast<const char *>(m->layers[l]) + stride * slot, stride,
+                               hipMemcpyDeviceToHost));
+      }
+    }
+    if (keep_mask)
+    {
+      store.mask_row.resize(mask_words);
+      OHMHIP_CHECK(hipMemcpy(store.mask_row.data(), m->d_hit_mask + mask_words * slot, sizeof(uint32_t) * mask_words,
+                             hipMemcpyDeviceToHost));
+    }
+    store.dirty = dirty[slot];
+    unpackRegionKey(key, &victim_keys[3 * size_t(v)]);
+  }
+  size_t removed = 0;
+  OHMHIP_CHECK(removeResidentRegions(m, victim_keys.data(), k, &removed));
+  m->evictions += removed;
+  return OHMHIP_OK;
+}
+
+namespace
+{
+/// Put a stored region's content into pool slot `slot` (which holds a fresh, unobserved region of the same key).
+int uploadSpilledRegion(ohmhip_map_t m, uint32_t slot, const ohmhip_map_s::SpilledRegion &store)
+{
+  const size_t rv = size_t(m->mc.region_voxels);
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    if (m->layers[l] && !store.layer[l].empty())
+    {
+      const size_t stride = rv * kLayerBytes[l];
+      OHMHIP_CHECK(hipMemcpy(static_cast<char *>(m->layers[l]) + stride * slot, store.layer[l].data(), stride,
+                             hipMemcpyHostToDevice));
+    }
+  }
+  if (!store.mask_row.empty())
+  {
+    OHMHIP_CHECK(hipMemcpy(m->d_hit_mask + store.mask_row.size() * slot, store.mask_row.data(),
+                           sizeof(uint32_t) * store.mask_row.size(), hipMemcpyHostToDevice));
+  }
+  if (store.dirty)
+  {
+    // (k_plan may be OR-ing this batch's bits into the same word: an atomic OR from a one-thread kernel)
+    uint32_t *d_index = nullptr;
+    OHMHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_index), sizeof(uint32_t)));
+    int err = int(hipMemcpy(d_index, &slot, sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!err)
+    {
+      hipLaunchKernelGGL(k_or_at_u32, dim3(1), dim3(1), 0, m->stream, m->d_dirty, d_index, size_t(1),
+                         store.dirty & (kDirtySync | kDirtyMerge));
+      err = int(hipStreamSynchronize(m->stream));
+    }
+    (void)hipFree(d_index);
+    OHMHIP_CHECK(err);
+  }
+  return OHMHIP_OK;
+}
+}  // namespace
+
+/// Spill to host, second half: a batch's set-up pass has just created the slots [first_slot, end_slot); those whose key
+/// is in the host store get their content back before anything reads or updates the layers.
+int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot)
+{
+  if (m->spilled.empty() || end_slot <= first_slot)
+  {
+    return OHMHIP_OK;
+  }
+  std::vector<uint64_t> keys(end_slot - first_slot);
+  OHMHIP_CHECK(hipMemcpy(keys.data(), m->d_slot_keys + first_slot, sizeof(uint64_t) * keys.size(), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < keys.size(); ++i)
+  {
+    const auto it = m->spilled.find(keys[i]);
+    if (it != m->spilled.end())
+    {
+      OHMHIP_CHECK(uploadSpilledRegion(m, first_slot + uint32_t(i), it->second));
+      m->spilled.erase(it);
+      ++m->readmissions;
+    }
+  }
+  return OHMHIP_OK;
+}
+
+/// Bring stored regions back for an upload / a caller that wants their slots (ohmhip_map_write_regions,
+/// ohmhip_map_ensure_regions): afterwards the keys are ordinary resident regions.
+int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count)
+{
+  if (m->spilled.empty())
+  {
+    return OHMHIP_OK;
+  }
+  std::vector<int16_t> wanted;
+  for (size_t i = 0; i < count; ++i)
+  {
+    if (m->spilled.count(packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2])))
+    {
+      wanted.insert(wanted.end(), keys_xyz + 3 * i, keys_xyz + 3 * i + 3);
+    }
+  }
+  if (wanted.empty())
+  {
+    return OHMHIP_OK;
+  }
+  // Take the entries out of the store first: ensure_regions would otherwise come straight back here.
+  std::vector<ohmhip_map_s::SpilledRegion> content(wanted.size() / 3);
+  for (size_t i = 0; i < content.size(); ++i)
+  {
+    const auto it = m->spilled.find(packRegionKey(wanted[3 * i], wanted[3 * i + 1], wanted[3 * i + 2]));
+    if (it != m->spilled.end())  // (a key listed twice)
+    {
+      content[i] = std::move(it->second);
+      m->spilled.erase(it);
+    }
+  }
+  std::vector<uint32_t> slots(content.size());
+  OHMHIP_CHECK(ohmhip_map_ensure_regions(m, wanted.data(), content.size(), slots.data()));
+  for (size_t i = 0; i < content.size(); ++i)
+  {
+    OHMHIP_CHECK(uploadSpilledRegion(m, slots[i], content[i]));
+    ++m->readmissions;
+  }
+  return OHMHIP_OK;
+}
+
+extern "C" {
 
 int ohmhip_map_mark_dirty(ohmhip_map_t m, const uint32_t *slots, size_t count)
 try
@@ -2889,6 +3218,7 @@ try
   m->slots_committed = 0;
   m->region_slots.clear();
   m->slot_keys_host.clear();
+  m->spilled.clear();
   return allocPool(m, m->slot_capacity, 0);
 }
 OHMHIP_ABI_CATCH

@@ -417,6 +417,13 @@ class GpuMap(RayMapper):
         OHMHIP_ERR_CAPACITY and leaves the map as it was.  0 removes the bound."""
         L.check(L.lib.ohmhip_map_set_memory_limit(self._handle, int(nbytes)), "set_memory_limit")
 
+    def setSpillToHost(self, enable=True):
+        """With a memory limit set: instead of failing, a batch that needs more regions than fit moves the least
+        recently used resident regions to a host store inside the library and repeats; stored regions stay part of the
+        map (listed, synced, brought back when touched).  include/ohmhip.h "SPILL TO HOST"; the reference's LRU reuse
+        of cache slots (ohmgpu/GpuLayerCache.cpp:530-584) serves the same purpose."""
+        L.check(L.lib.ohmhip_map_set_spill_to_host(self._handle, 1 if enable else 0), "set_spill_to_host")
+
     def setBatchCoalescing(self, min_rays):
         """Collect consecutive small host batches and run them as one device batch of >= min_rays rays
         (include/ohmhip.h: ohmhip_map_set_batch_coalescing; on by default with 65536).  0 turns it off."""

@@ -569,6 +569,14 @@ public:
   /// needs more fails -- integrateRays() returns 0 -- and leaves the map as it was.  0 removes the bound.
   void setMemoryLimit(uint64_t bytes) { OHMHIP_GPUAPICHECK(ohmhip_map_set_memory_limit(handle_, bytes)); }
 
+  /// With a memory limit: spill the least recently used regions to a host store instead of failing the batch
+  /// (include/ohmhip.h "SPILL TO HOST"; the reference reuses its least recently used cache slot,
+  /// ohmgpu/GpuLayerCache.cpp:530-584).  Stored regions stay part of the map and come back when touched.
+  void setSpillToHost(bool enable = true)
+  {
+    OHMHIP_GPUAPICHECK(ohmhip_map_set_spill_to_host(handle_, enable ? 1 : 0));
+  }
+
   /// Not in the reference: run consecutive small integrateRays() batches as one device batch of at least @p min_rays
   /// rays (see ohmhip_map_set_batch_coalescing; on by default with 65536); 0 turns it off.
   void setBatchCoalescing(size_t min_rays) { OHMHIP_GPUAPICHECK(ohmhip_map_set_batch_coalescing(handle_, min_rays)); }

@@ -1,0 +1,154 @@
+"""-m gpu: spill to host (include/ohmhip.h "SPILL TO HOST") -- a map bounded to a fraction of the regions a sensor
+track covers keeps integrating: cold regions move to the library's host store, come back when rays reach them again,
+and the result equals the CPU oracle's (the reference bounds its GPU cache and reuses the least recently used slot,
+ohmgpu/GpuLayerCache.cpp:530-584)."""
+import numpy as np
+import pytest
+
+from ohm_amd import GpuMap, GpuNdtMap, OccupancyMap, _lib as L
+
+from parity import assert_parity, compare_maps, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def sensor_rays(origin, n, seed, min_range=1.5, max_range=4.0):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    length = rng.uniform(min_range, max_range, n)
+    rays = np.empty((2 * n, 3), dtype=np.float64)
+    rays[0::2] = np.asarray(origin, dtype=np.float64) + 0.013
+    rays[1::2] = rays[0::2] + d * length[:, None]
+    return rays
+
+
+def track(n_stops, spacing=9.0):
+    """A sensor moving out along x and back again: the return leg reaches regions that were evicted on the way out."""
+    out = [(spacing * i, 0.3 * i, 0.0) for i in range(n_stops)]
+    return out + out[-2::-1]
+
+
+def limited_map(map_, regions, cls=GpuMap, **kwargs):
+    gm = cls(map_, region_capacity=64, **kwargs)
+    per_region = gm.cacheStats()["bytes_per_region"]
+    gm.setMemoryLimit(regions * per_region)
+    return gm
+
+
+@pytest.mark.parametrize("layers", [("occupancy",), ("occupancy", "mean")])
+def test_track_under_a_memory_limit_equals_the_unbounded_result(gpu, layers):
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=layers)
+    gm = limited_map(map_, 100)
+    gm.setSpillToHost(True)
+    om = make_oracle(map_)
+    for k, origin in enumerate(track(6)):
+        rays = sensor_rays(origin, 6000, seed=700 + k)
+        assert gm.integrateRays(rays) == rays.shape[0]
+        om.integrate_occupancy(rays)
+    st = gm.cacheStats()
+    assert st["evictions"] > 0 and st["readmissions"] > 0 and st["regions_spilled"] > 0 and st["spill_enabled"] == 1
+    assert st["regions_resident"] <= 100
+    n_regions = len(om.chunks())
+    assert len(gm.regionKeys()) == n_regions == st["regions_resident"] + st["regions_spilled"]
+    assert len(gm.regionKeys(dirty_only=True)) == n_regions  # nothing synced yet: stored regions count as well
+    gm.syncVoxels()
+    assert len(gm.regionKeys(dirty_only=True)) == 0
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
+    # a second leg after the sync: only what it touches is dirty again, and the map still matches
+    rays = sensor_rays((0.0, 0.0, 0.0), 6000, seed=999)
+    assert gm.integrateRays(rays) == rays.shape[0]
+    om.integrate_occupancy(rays)
+    assert 0 < len(gm.regionKeys(dirty_only=True)) < n_regions
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
+
+
+def test_ndt_regions_keep_their_replay_mask_across_a_spill(gpu):
+    map_ = OccupancyMap(0.2, (32, 32, 32), layers=("occupancy",))
+    gm = limited_map(map_, 70, cls=GpuNdtMap)
+    gm.setSpillToHost(True)
+    om = make_oracle(map_)
+    om.set_ndt(sensor_noise=gm.sensor_noise, sample_threshold=gm.sample_threshold,
+               adaptation_rate=gm.adaptation_rate, reinit_threshold=gm.reinitialise_covariance_threshold,
+               reinit_count=gm.reinitialise_covariance_point_count, ndt_tm=False)
+    for k, origin in enumerate(track(4, spacing=16.0)):
+        rays = sensor_rays(origin, 5000, seed=800 + k, min_range=2.0, max_range=7.0)
+        # cluster the samples so voxels collect several of them (NDT state beyond the first sample)
+        rays[1::2] = np.round(rays[1::2] / 0.5) * 0.5 + 0.017 * np.sin(np.arange(5000))[:, None]
+        assert gm.integrateRays(rays) == rays.shape[0]
+        om.integrate_ndt(rays)
+    st = gm.cacheStats()
+    assert st["evictions"] > 0 and st["readmissions"] > 0
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean", "covariance"], rel=1e-5)
+    assert_parity(stats)
+
+
+def test_tsdf_regions_across_a_spill(gpu):
+    from ohm_amd import GpuTsdfMap
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("tsdf",))
+    gm = limited_map(map_, 100, cls=GpuTsdfMap, default_truncation_distance=0.3)
+    gm.setSpillToHost(True)
+    om = make_oracle(map_)
+    opts = gm.tsdf_options
+    om.set_tsdf(max_weight=opts[0], trunc=opts[1], dropoff=opts[2], sparsity=opts[3])
+    for k, origin in enumerate(track(5)):
+        rays = sensor_rays(origin, 4000, seed=850 + k)
+        assert gm.integrateRays(rays) == rays.shape[0]
+        om.integrate_tsdf(rays)
+    st = gm.cacheStats()
+    assert st["evictions"] > 0 and st["readmissions"] > 0
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True))
+
+
+def test_stored_regions_answer_the_region_calls(gpu):
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm = limited_map(map_, 80)
+    gm.setSpillToHost(True)
+    om = make_oracle(map_)
+    for k, origin in enumerate([(0.0, 0.0, 0.0), (12.0, 0.0, 0.0), (24.0, 0.0, 0.0)]):
+        rays = sensor_rays(origin, 5000, seed=900 + k)
+        gm.integrateRays(rays)
+        om.integrate_occupancy(rays)
+    st = gm.cacheStats()
+    assert st["regions_spilled"] > 0
+    resident = {tuple(int(v) for v in k) for k in gm.regionKeys()}
+    assert resident == set(om.chunks().keys())
+    # the first stop's own region is cold by now: stored, so it has no slot ...
+    import ctypes as C
+    first_key = np.array([[0, 0, 0]], dtype=np.int16)
+    slot = C.c_uint32(0)
+    assert L.lib.ohmhip_map_region_slot(gm._handle, first_key.ctypes.data, C.byref(slot)) == L.ERR_NOT_FOUND
+    # ... an upload of the host copy brings it back as an ordinary resident region ...
+    gm.syncVoxels()
+    gm.uploadRegions(first_key)
+    assert L.lib.ohmhip_map_region_slot(gm._handle, first_key.ctypes.data, C.byref(slot)) == L.OK
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+    # ... removing a stored region forgets it, clear() forgets everything
+    stored = [k for k in gm.regionKeys() if L.lib.ohmhip_map_region_slot(
+        gm._handle, np.ascontiguousarray(k).ctypes.data, C.byref(slot)) == L.ERR_NOT_FOUND]
+    assert stored
+    before = len(gm.regionKeys())
+    assert gm.removeRegions([stored[0]]) == 1
+    assert len(gm.regionKeys()) == before - 1
+    # replica merge does not combine with spilling
+    assert L.lib.ohmhip_map_enable_merge(gm._handle) == L.ERR_UNSUPPORTED
+    gm.clear()
+    assert len(gm.regionKeys()) == 0 and gm.cacheStats()["regions_spilled"] == 0
+
+
+def test_a_batch_larger_than_the_limit_still_fails_cleanly(gpu):
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm = limited_map(map_, 20)
+    gm.setSpillToHost(True)
+    om = make_oracle(map_)
+    small = sensor_rays((0.0, 0.0, 0.0), 2000, seed=11, max_range=2.5)
+    assert gm.integrateRays(small) == small.shape[0]
+    om.integrate_occupancy(small)
+    big = sensor_rays((0.0, 0.0, 0.0), 4000, seed=12, min_range=5.0, max_range=9.0)  # > 20 regions on its own
+    assert gm.integrateRays(big) == 0
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
