@@ -259,6 +259,41 @@ def main():
             L.lib.ohmhip_buffer_destroy(b2)
             g2.close()
             del r2
+        # C3 cache-stress variant: the region pool bounded at the reference's default budget of 1 GiB and the
+        # 4 M rays presented as 45-degree sectors of the sweep, so the least recently used regions spill to the host
+        # store as the sensor turns and come back one revolution later (include/ohmhip.h "SPILL TO HOST").
+        try:
+            m4 = ohm_amd.OccupancyMap(0.05, (32, 32, 32), layers=("tsdf",))
+            g4 = ohm_amd.GpuTsdfMap(m4, region_capacity=1024)
+            g4.setMemoryLimit(1 << 30)
+            g4.setSpillToHost(True)
+            r4 = synth.rays_c3(n=4 * n_rays)
+            b4 = L._vp()
+            L.check(L.lib.ohmhip_buffer_create(C.byref(b4), r4.nbytes, 3), "buffer_create")
+            L.check(L.lib.ohmhip_buffer_write(b4, r4.ctypes.data, r4.nbytes, 0, None, None, None), "buffer_write")
+            p4 = L._vp()
+            L.check(L.lib.ohmhip_buffer_ptr(b4, C.byref(p4)), "buffer_ptr")
+            sectors = 32
+            per = (r4.shape[0] // 2) // sectors
+            t1 = time.perf_counter()
+            done4 = 0
+            for k in range(sectors):
+                done4 += g4.integrateRaysDevice(C.c_void_p(p4.value + k * per * 48), 2 * per)
+            g4.wait()
+            dt4 = time.perf_counter() - t1
+            cs = g4.cacheStats()
+            extra["C3_tsdf_cache_stress_1GiB"] = {
+                "rays_per_s": (done4 // 2) / dt4, "seconds": dt4, "rays": done4 // 2, "calls": sectors,
+                "memory_limit_bytes": int(cs["memory_limit"]), "regions_resident": int(cs["regions_resident"]),
+                "regions_in_host_store": int(cs["regions_spilled"]), "evictions": int(cs["evictions"]),
+                "readmissions": int(cs["readmissions"]),
+                "note": "first pass over a fresh map: includes pool growth to the limit and every eviction / "
+                        "re-admission copy (synchronous, pageable host store)"}
+            L.lib.ohmhip_buffer_destroy(b4)
+            g4.close()
+            del r4
+        except Exception as exc:  # never lose the bench line over a secondary figure
+            extra["C3_tsdf_cache_stress_1GiB"] = {"error": repr(exc)}
         # C1 variants SURVEY 8d asks to be reported next to the headline (never the headline `value`):
         # (i) the same batch fed as 4096-ray calls (the reference tools' default batch size): launch-latency bound;
         # (ii) end to end from HOST memory: pinned staging + H2D + integrate + syncVoxels into the host MapChunk blocks.

@@ -5,7 +5,7 @@ ohmgpu/GpuLayerCache.cpp:530-584)."""
 import numpy as np
 import pytest
 
-from ohm_amd import GpuMap, GpuNdtMap, OccupancyMap, _lib as L
+from ohm_amd import GpuMap, GpuNdtMap, OccupancyMap, _lib as L, synth
 
 from parity import assert_parity, compare_maps, make_oracle
 
@@ -99,6 +99,29 @@ def test_tsdf_regions_across_a_spill(gpu):
         om.integrate_tsdf(rays)
     st = gm.cacheStats()
     assert st["evictions"] > 0 and st["readmissions"] > 0
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True))
+
+
+def test_c3_sweep_under_the_reference_cache_budget(gpu):
+    """SURVEY 8d's cache-stress variant of C3 at test size: the lidar sweep presented as 45-degree sectors to a TSDF map
+    whose pool holds a third of the regions a revolution touches; a quarter of a second revolution brings the first
+    sectors back from the host store.  Bit exact against the oracle."""
+    from ohm_amd import GpuTsdfMap
+    map_ = OccupancyMap(0.05, (32, 32, 32), layers=("tsdf",))
+    gm = limited_map(map_, 1500, cls=GpuTsdfMap)
+    gm.setSpillToHost(True)
+    om = make_oracle(map_)
+    opts = gm.tsdf_options
+    om.set_tsdf(max_weight=opts[0], trunc=opts[1], dropoff=opts[2], sparsity=opts[3])
+    rays = synth.rays_c3(n=1_250_000)
+    per = 125_000
+    for k in range(10):
+        part = rays[2 * k * per:2 * (k + 1) * per]
+        assert gm.integrateRays(part) == part.shape[0]
+    om.integrate_tsdf(rays)
+    st = gm.cacheStats()
+    assert st["evictions"] > 1000 and st["readmissions"] > 100 and st["regions_resident"] <= 1500
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True))
 
