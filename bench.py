@@ -288,7 +288,7 @@ def main():
                 "regions_in_host_store": int(cs["regions_spilled"]), "evictions": int(cs["evictions"]),
                 "readmissions": int(cs["readmissions"]),
                 "note": "first pass over a fresh map: includes pool growth to the limit and every eviction / "
-                        "re-admission copy (synchronous, pageable host store)"}
+                        "re-admission copy (pinned staging, synchronous with the batch)"}
             L.lib.ohmhip_buffer_destroy(b4)
             g4.close()
             del r4

@@ -2957,33 +2957,47 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free)
   const size_t rv = size_t(m->mc.region_voxels);
   const size_t mask_words = (rv + 31) / 32;
   const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;  // (transient in occupancy mode: empty between batches)
+  // The victims' content: every layer through the pinned, double-buffered read path (ohmhip_map_read_regions -- the
+  // entries join the store only afterwards, so that path still sees them as resident), the mask rows out of one copy
+  // of the whole mask.
   std::vector<int16_t> victim_keys(3 * size_t(k));
+  std::vector<ohmhip_map_s::SpilledRegion> content(k);
   for (uint32_t v = 0; v < k; ++v)
   {
-    const uint32_t slot = order[v];
-    const uint64_t key = m->slot_keys_host[slot];
-    ohmhip_map_s::SpilledRegion &store = m->spilled[key];
-    for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+    unpackRegionKey(m->slot_keys_host[order[v]], &victim_keys[3 * size_t(v)]);
+    content[v].dirty = dirty[order[v]];
+  }
+  std::vector<void *> dsts(k);
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    if (!m->layers[l])
     {
-      if (m->layers[l])
-      {
-        const size_t stride = rv * kLayerBytes[l];
-        store.layer[l].resize(stride);
-        OHMHIP_CHECK(hipMemcpy(store.layer[l].data(), static_cast<const char *>(m->layers[l]) + stride * slot, stride,
-                               hipMemcpyDeviceToHost));
-      }
+      continue;
     }
-    if (keep_mask)
+    const size_t stride = rv * kLayerBytes[l];
+    for (uint32_t v = 0; v < k; ++v)
     {
-      store.mask_row.resize(mask_words);
-      OHMHIP_CHECK(hipMemcpy(store.mask_row.data(), m->d_hit_mask + mask_words * slot, sizeof(uint32_t) * mask_words,
-                             hipMemcpyDeviceToHost));
+      content[v].layer[l].resize(stride);
+      dsts[v] = content[v].layer[l].data();
     }
-    store.dirty = dirty[slot];
-    unpackRegionKey(key, &victim_keys[3 * size_t(v)]);
+    OHMHIP_CHECK(ohmhip_map_read_regions(m, l, victim_keys.data(), k, dsts.data()));
+  }
+  if (keep_mask)
+  {
+    std::vector<uint32_t> all_rows(mask_words * n);
+    OHMHIP_CHECK(hipMemcpy(all_rows.data(), m->d_hit_mask, sizeof(uint32_t) * all_rows.size(), hipMemcpyDeviceToHost));
+    for (uint32_t v = 0; v < k; ++v)
+    {
+      content[v].mask_row.assign(all_rows.begin() + mask_words * order[v], all_rows.begin() + mask_words * (order[v] + 1));
+    }
   }
   size_t removed = 0;
   OHMHIP_CHECK(removeResidentRegions(m, victim_keys.data(), k, &removed));
+  for (uint32_t v = 0; v < k; ++v)
+  {
+    m->spilled[packRegionKey(victim_keys[3 * size_t(v)], victim_keys[3 * size_t(v) + 1], victim_keys[3 * size_t(v) + 2])] =
+      std::move(content[v]);
+  }
   m->evictions += removed;
   return OHMHIP_OK;
 }
@@ -3037,16 +3051,91 @@ int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot)
   }
   std::vector<uint64_t> keys(end_slot - first_slot);
   OHMHIP_CHECK(hipMemcpy(keys.data(), m->d_slot_keys + first_slot, sizeof(uint64_t) * keys.size(), hipMemcpyDeviceToHost));
+  // (slot, stored content) of the new slots that have content waiting, in slot order
+  std::vector<std::pair<uint32_t, ohmhip_map_s::SpilledRegion>> back;
   for (size_t i = 0; i < keys.size(); ++i)
   {
     const auto it = m->spilled.find(keys[i]);
     if (it != m->spilled.end())
     {
-      OHMHIP_CHECK(uploadSpilledRegion(m, first_slot + uint32_t(i), it->second));
+      back.emplace_back(first_slot + uint32_t(i), std::move(it->second));
       m->spilled.erase(it);
-      ++m->readmissions;
     }
   }
+  if (back.empty())
+  {
+    return OHMHIP_OK;
+  }
+  // Layers: through the pinned staging block in bursts, runs of consecutive slots as one copy.
+  const size_t rv = size_t(m->mc.region_voxels);
+  const size_t burst = 64;
+  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  {
+    if (!m->layers[l])
+    {
+      continue;
+    }
+    const size_t stride = rv * kLayerBytes[l];
+    OHMHIP_CHECK(ensureStage(m, std::max(m->h_stage_bytes, burst * stride)));
+    char *stage = static_cast<char *>(m->h_stage);
+    for (size_t base = 0; base < back.size(); base += burst)
+    {
+      const size_t n = std::min(burst, back.size() - base);
+      for (size_t i = 0; i < n; ++i)
+      {
+        if (back[base + i].second.layer[l].size() != stride)
+        {
+          return OHMHIP_ERR_INTERNAL;
+        }
+        std::memcpy(stage + i * stride, back[base + i].second.layer[l].data(), stride);
+      }
+      for (size_t i = 0; i < n;)
+      {
+        size_t run = 1;
+        while (i + run < n && back[base + i + run].first == back[base + i].first + uint32_t(run))
+        {
+          ++run;
+        }
+        OHMHIP_CHECK(hipMemcpyAsync(static_cast<char *>(m->layers[l]) + stride * back[base + i].first, stage + i * stride,
+                                    run * stride, hipMemcpyHostToDevice, m->copy_stream));
+        i += run;
+      }
+      OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));  // (the staging block is reused by the next burst)
+    }
+  }
+  // Mask rows and dirty bits: small, per region.
+  std::vector<uint32_t> dirty_slots[4];
+  for (const auto &entry : back)
+  {
+    const ohmhip_map_s::SpilledRegion &store = entry.second;
+    if (!store.mask_row.empty())
+    {
+      OHMHIP_CHECK(hipMemcpy(m->d_hit_mask + store.mask_row.size() * entry.first, store.mask_row.data(),
+                             sizeof(uint32_t) * store.mask_row.size(), hipMemcpyHostToDevice));
+    }
+    dirty_slots[store.dirty & (kDirtySync | kDirtyMerge)].push_back(entry.first);
+  }
+  for (uint32_t bits = 1; bits < 4; ++bits)
+  {
+    if (dirty_slots[bits].empty())
+    {
+      continue;
+    }
+    // (k_plan may be OR-ing this batch's bits into the same words: atomic ORs)
+    uint32_t *d_index = nullptr;
+    OHMHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_index), sizeof(uint32_t) * dirty_slots[bits].size()));
+    int err = int(hipMemcpy(d_index, dirty_slots[bits].data(), sizeof(uint32_t) * dirty_slots[bits].size(),
+                            hipMemcpyHostToDevice));
+    if (!err)
+    {
+      hipLaunchKernelGGL(k_or_at_u32, dim3(64), dim3(256), 0, m->stream, m->d_dirty, d_index,
+                         dirty_slots[bits].size(), bits);
+      err = int(hipStreamSynchronize(m->stream));
+    }
+    (void)hipFree(d_index);
+    OHMHIP_CHECK(err);
+  }
+  m->readmissions += back.size();
   return OHMHIP_OK;
 }
 
