@@ -7,8 +7,13 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 layers = ("occupancy",) if rng.integers(2) else ("occupancy", "mean")
 map_ = OccupancyMap(0.1, (32, 32, 32), layers=layers)
 gm = GpuMap(map_, region_capacity=64)   # tiny pool: grows repeatedly
+if len(sys.argv) > 2 and sys.argv[2] == "spill":
+    # bounded pool: the least recently used regions move to the host store and back (one sensor position: every batch
+    # touches most regions, so this mostly exercises eviction + immediate re-admission)
+    gm.setMemoryLimit(70 * gm.cacheStats()["bytes_per_region"])
+    gm.setSpillToHost(True)
 om = make_oracle(map_)
-all_rays = synth.rays_c1(n=400000, max_range=20.0)
+all_rays = synth.rays_c1(n=400000, max_range=20.0 if len(sys.argv) <= 2 else 16.0)
 pos = 0
 n_batches = 0
 t0 = time.time()
@@ -33,5 +38,6 @@ while pos < all_rays.shape[0] // 2 and n_batches < 200:
 gm.syncVoxels()
 stats = compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True)
 bad = {k: v for k, v in stats.items() if (k.startswith("diff_") or k.endswith("_on_gpu") or k.endswith("_on_cpu")) and v}
+print(gm.cacheStats()["evictions"], gm.cacheStats()["readmissions"], end=" ")
 print("seed", sys.argv[1:], "layers", layers, "batches", n_batches, "rays", pos, "regions", len(map_.chunks), "bad", bad, "%.1fs" % (time.time() - t0))
 assert not bad
