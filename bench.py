@@ -4,8 +4,9 @@
   python bench.py --gpus N --steps K --warmup W
 
 One "step" = one GpuMap::integrateRays pass over one 1 M-ray synthetic lidar batch (C1) whose rays are already
-resident in HBM when the timed region starts.  At N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank integrates the C4 shard of its own sensor origin into its own resident map and, inside the timed region, the
+resident in HBM when the timed region starts.  At N > 1 -- launched by torch.distributed.run, one rank per GPU, or,
+when `--gpus N` is given WITHOUT a torch.distributed environment, re-launched by this script itself under
+torch.distributed.run (127.0.0.1 rendezvous) -- every rank integrates the C4 shard of its own sensor origin into its own resident map and, inside the timed region, the
 replicas are reconciled after every batch: the library's replica merge (include/ohmhip.h) all-gathers the region key
 lists and all-reduces, over RCCL, the occupancy deltas of the regions more than one rank touched ("weak" scaling);
 value = rays of all ranks / max-over-ranks time, bytes moved are reported under "merge".
@@ -27,20 +28,100 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
-def cpu_baseline(rays, resolution, sample_rays):
-    """Oracle (bit-identical CPU port of RayMapperOccupancy) timed single-threaded on a bounded sample."""
+def _oracle_rate(rays, resolution, repeats=3):
     from oracle.oracle import OracleMap
-    sample = rays[: 2 * sample_rays]
-    best = None
-    for _ in range(3):
+    best, om = None, None
+    for _ in range(repeats):
         om = OracleMap(resolution, (32, 32, 32), layers=("occupancy",))
         t0 = time.perf_counter()
-        om.integrate_occupancy(sample)
+        om.integrate_occupancy(rays)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    return {"value": sample_rays / best, "unit": "rays/s", "cores": 1, "kind": "port",
-            "sample": f"first {sample_rays} rays of the same C1 batch, fresh map, best of 3, {best:.2f} s",
-            "visits_per_s": om.visit_count() / best}
+    return best, om.visit_count()
+
+
+def _cpu_replica_worker(args):
+    """One of P processes of the all-cores leg: its own oracle map, its own slice of the C1 batch ("replicas": the CPU
+    mapper is single threaded, ohm/RayMapperOccupancy.cpp, so the only way to use P cores is P independent maps)."""
+    index, n_rays, resolution, start_at = args
+    from oracle.oracle import OracleMap
+    from ohm_amd import synth as S  # numpy only; no device call
+    rays = S.rays_c1(n=n_rays, first=index * n_rays)
+    om = OracleMap(resolution, (32, 32, 32), layers=("occupancy",))
+    while time.time() < start_at:  # common start so the replicas really run side by side
+        time.sleep(0.001)
+    t0 = time.time()
+    om.integrate_occupancy(rays)
+    return t0, time.time(), om.visit_count()
+
+
+def _physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            try:  # respect a cgroup / affinity restriction
+                return max(1, min(n, len(os.sched_getaffinity(0))))
+            except AttributeError:
+                return n
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(rays, resolution, sample_rays, all_cores=True):
+    """The oracle (bit-identical CPU port of RayMapperOccupancy, kind "port") timed on the host cores, bounded samples:
+      value      single thread, the first `sample_rays` rays of the SAME C1 batch the GPU integrates (headline figure);
+      c0         single thread on BASELINE config 0's own rays (100 k uniform 10 m rays from one origin);
+      all_cores  P = physical cores, P processes each integrating its own slice of the C1 sweep into its own map
+                 ("replicas"), rays of all / (latest end - earliest start)."""
+    from ohm_amd import synth
+    sample = rays[: 2 * sample_rays]
+    best, visits = _oracle_rate(sample, resolution)
+    out = {"value": sample_rays / best, "unit": "rays/s", "cores": 1, "kind": "port",
+           "sample": f"first {sample_rays} rays of the same C1 batch, fresh map, best of 3, {best:.2f} s",
+           "visits_per_s": visits / best}
+    c0 = synth.rays_c0()
+    best0, visits0 = _oracle_rate(c0, resolution)
+    out["c0"] = {"value": (c0.shape[0] // 2) / best0, "unit": "rays/s", "cores": 1, "visits_per_s": visits0 / best0,
+                 "sample": f"C0: {c0.shape[0] // 2} uniform 10 m rays from one origin, 0.1 m voxels, fresh map, best of 3, "
+                           f"{best0:.2f} s"}
+    if all_cores:
+        try:
+            import multiprocessing as mp
+            procs = _physical_cores()
+            per = max(50_000, min(250_000, sample_rays // 4))
+            start_at = time.time() + 4.0 + 0.02 * procs  # interpreter start + ray generation of every worker
+            with mp.get_context("spawn").Pool(procs) as pool:
+                res = pool.map(_cpu_replica_worker, [(i, per, resolution, start_at) for i in range(procs)], chunksize=1)
+            late = sum(1 for r in res if r[0] > start_at + 0.25)
+            wall = max(r[1] for r in res) - min(r[0] for r in res)
+            out["all_cores"] = {"value": procs * per / wall, "unit": "rays/s", "cores": procs, "kind": "port",
+                                "visits_per_s": sum(r[2] for r in res) / wall, "late_starters": late,
+                                "sample": f"{procs} replica processes x {per} rays of the C1 sweep each, own map each, "
+                                          f"{wall:.2f} s wall"}
+        except Exception as exc:  # never lose the bench line over a secondary figure
+            out["all_cores"] = {"error": repr(exc)}
+    return out
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _relaunch_ranks(n):
+    """`python bench.py --gpus N` with no torch.distributed environment: start the N ranks ourselves, exactly as the
+    contract's launcher would (one process per GPU, 127.0.0.1 rendezvous).  Rank 0's JSON line is this process' output."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OHM_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -51,8 +132,13 @@ def main():
     ap.add_argument("--rays", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the P-process leg of cpu_baseline")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-deviation", action="store_true", help="N > 1: skip the untimed merge-vs-sequential check")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_relaunch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -64,10 +150,22 @@ def main():
         import torch
         import torch.distributed as dist
         n_dev = torch.cuda.device_count()
-        device_index = local_rank % max(n_dev, 1)
+        if n_dev == 0:
+            # No HIP device: the product path cannot run (no CPU fallback).  What CAN be checked is the launcher: the N
+            # ranks exist, rendezvous and count each other.  value stays null and the line carries "error".
+            dist.init_process_group("gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            if rank == 0:
+                print(json.dumps({"metric": "rays/sec integrated (occupancy)", "value": None, "unit": "rays/s",
+                                  "n_gpus": world, "ranks": int(t.item()), "devices_visible": 0, "backend": "gloo",
+                                  "error": "no HIP device visible: launcher check only, nothing was integrated"}))
+            dist.destroy_process_group()
+            sys.exit(0)
+        device_index = local_rank % n_dev
         torch.cuda.set_device(device_index)
         # One rank per GPU over RCCL; if ranks outnumber GPUs (single-GPU smoke runs) fall back to gloo for the
-        # control-plane collectives -- the data path has no collective.
+        # control-plane collectives and the staged merge -- the integration itself has no collective.
         backend = "nccl" if n_dev >= world else "gloo"
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
@@ -75,6 +173,7 @@ def main():
             dist.init_process_group("gloo")
     else:
         device_index = 0
+        n_dev = None
 
     import ohm_amd
     from ohm_amd import _lib as L
@@ -115,6 +214,15 @@ def main():
         except Exception as exc:  # the library's RCCL communicator could not be made: merge over the torch group
             comm = None
             merge_note = "library RCCL communicator unavailable (%s): merge staged over the torch group" % (exc,)
+        if backend == "nccl":
+            # all ranks use the same transport: the library's communicator only if EVERY rank has one
+            import torch
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda", dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()) and comm is not None:
+                comm.close()
+                comm = None
+                merge_note = "library RCCL communicator missing on another rank: merge staged over the torch group"
         merger = D.ReplicaMerger(gm, comm=comm)
 
     def barrier():
@@ -132,7 +240,10 @@ def main():
         if merge_state["merger"] is not None:
             try:
                 merge_log.append(merge_state["merger"].merge())
-            except Exception as exc:  # reported in the output line; the ranks keep integrating their own maps
+            except Exception as exc:
+                # Reported in the output line.  The library (and ReplicaMerger's gloo path) make the ranks agree on a
+                # rank-local failure before the payload collective: the failing rank raises its own error, every other
+                # rank OHMHIP_ERR_PEER from the SAME call, so all ranks stop merging together and none is left blocked.
                 merge_state["error"] = repr(exc)
                 merge_state["merger"] = None
 
@@ -203,6 +314,11 @@ def main():
                               "the moment it may start on its own stream -- queued behind the previous batch's walk "
                               "kernel it mostly waits for CUs -- so the parts overlap and do not add up to total"},
     }
+    out["ranks"] = world
+    out["devices_visible"] = n_dev if n_dev is not None else int(ohm_amd.device_count())
+    if world > 1:
+        out["backend"] = "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: staged merge, NOT a scaling figure)"
+        out["rccl_ranks"] = comm.world if comm is not None else None
     if world > 1 and (merge_state["error"] or not merge_log):
         out["merge"] = {"error": merge_state["error"] or "no merge ran", "note": "replicas not reconciled in this run"}
     elif merge_log:
@@ -213,7 +329,37 @@ def main():
                                      "ms_host": float(np.mean([m.get("ms_total", 0.0) for m in merge_log]))},
                         "transport": "RCCL (library)" if comm is not None else "torch.distributed group (staged)",
                         "note": merge_note,
-                        "rule": "merged = clamp(base + sum_r (x_r - base)); exact where no clamp engaged between ranks"}
+                        "rule": "merged = clamp(base + sum_r (x_r - base)); exact where no clamp engaged between ranks; "
+                                "regions pending on one rank only stay on that rank (shared base untouched)"}
+    if world > 1 and merge_state["merger"] is not None and not args.no_deviation:
+        # Untimed: how far the replica merge is from SEQUENTIAL integration ("must be stated with results").
+        # Fresh maps: every rank integrates its shard ONCE and the replicas merge (collective); rank 0 also integrates
+        # the shards of all ranks one after the other into one map -- the HIP path, which is bit exact against the CPU
+        # mapper (tests/test_gpu_full_configs.py) -- and compares the regions it holds.
+        try:
+            from ohm_amd import distributed as D
+            dm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+            dg = ohm_amd.GpuMap(dm, gpu_mem_size=8 << 30)
+            dmerger = D.ReplicaMerger(dg, comm=comm)
+            dg.integrateRaysDevice(dptr, rays.shape[0])
+            dstats = dmerger.merge()
+            if rank == 0:
+                sm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+                sg = ohm_amd.GpuMap(sm, gpu_mem_size=16 << 30)
+                for r in range(world):
+                    sg.integrateRays(synth.rays_c4_shard(r, n=n_rays))
+                sg.syncVoxels()
+                dg.syncVoxels()
+                dev = D.merge_deviation(dm.chunks, sm.chunks)
+                dev["regions_exchanged"] = int(dstats["regions_shared"])
+                dev["note"] = ("rank 0's replica after ONE batch per rank + one merge vs one map integrating the shards "
+                               "of all ranks in rank order; differences = float summation order + clamp interplay")
+                out["merge"]["deviation"] = dev
+                sg.close()
+            dg.close()
+        except Exception as exc:
+            if rank == 0 and "merge" in out:
+                out["merge"]["deviation"] = {"error": repr(exc)}
     if world == 1 and not args.no_extra:
         # Secondary figures (not the headline `value`): C2 GpuNdtMap (1 M rays) and C3 GpuTsdfMap (its full 4 M rays in one
         # call), same harness, each with its own roofline block.  Algorithmic bytes per SURVEY.md 8d:
@@ -253,9 +399,12 @@ def main():
                                         "unit": "GB/s", "pipeline_ms": dev2 * 1e3,
                                         "achieved": b_alg2 / dev2 / 1e9, "frac": b_alg2 / dev2 / 1e9 / HBM_PEAK_GBPS,
                                         "walk_kernel_ms": walk2 * 1e3,
-                                        "walk_kernel_frac": b_alg2 / walk2 / 1e9 / HBM_PEAK_GBPS,
-                                        "note": "frac is over the whole device pipeline of a batch (walk + event sort + "
-                                                "ordered replay); the walk kernel alone is walk_kernel_frac"}}
+                                        "note": "frac is over the whole device pipeline of a batch (walk + event order + "
+                                                "ordered replay).  The formula charges every voxel visit with the "
+                                                "layer bytes the reference formulation would move; this design only "
+                                                "touches the layers of marked voxels, so frac compares against an "
+                                                "ideal HBM-bound implementation of the reference formulation, it is "
+                                                "not an HBM utilisation (measured traffic: profiles/)"}}
             L.lib.ohmhip_buffer_destroy(b2)
             g2.close()
             del r2
@@ -294,6 +443,66 @@ def main():
             del r4
         except Exception as exc:  # never lose the bench line over a secondary figure
             extra["C3_tsdf_cache_stress_1GiB"] = {"error": repr(exc)}
+        # C0 (BASELINE configs[0]: 100 k uniform 10 m rays from one origin) on the HIP path, device-resident rays.
+        try:
+            r0 = synth.rays_c0()
+            m0 = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+            g0 = ohm_amd.GpuMap(m0)
+            b0 = L._vp()
+            L.check(L.lib.ohmhip_buffer_create(C.byref(b0), r0.nbytes, 3), "buffer_create")
+            L.check(L.lib.ohmhip_buffer_write(b0, r0.ctypes.data, r0.nbytes, 0, None, None, None), "buffer_write")
+            p0 = L._vp()
+            L.check(L.lib.ohmhip_buffer_ptr(b0, C.byref(p0)), "buffer_ptr")
+            g0.integrateRaysDevice(p0, r0.shape[0])
+            g0.wait()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                g0.integrateRaysDevice(p0, r0.shape[0])
+            g0.wait()
+            dt = (time.perf_counter() - t1) / 10
+            st0 = g0.stats()
+            extra["C0_100k_rays_10m"] = {"rays_per_s": (r0.shape[0] // 2) / dt, "ms_per_step": dt * 1e3,
+                                         "voxel_visits": int(st0["voxel_visits"]), "regions": int(st0["regions_resident"])}
+            L.lib.ohmhip_buffer_destroy(b0)
+            g0.close()
+        except Exception as exc:
+            extra["C0_100k_rays_10m"] = {"error": repr(exc)}
+        # C4 on ONE GPU (8 replica maps in this process standing in for the 8 ranks): what the replica merge moves and how
+        # far its result is from the sequential integration of the 8 shards.  Not a scaling figure.
+        if not args.no_deviation:
+            try:
+                from ohm_amd import distributed as D
+                reps, rmaps = [], []
+                for r in range(8):
+                    rm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+                    rg = ohm_amd.GpuMap(rm, gpu_mem_size=2 << 30)
+                    L.check(L.lib.ohmhip_map_enable_merge(rg._handle), "enable_merge")
+                    rg.integrateRays(synth.rays_c4_shard(r, n=n_rays))
+                    reps.append(rg)
+                    rmaps.append(rm)
+                t1 = time.perf_counter()
+                shared, mstats = D.merge_in_process(reps)
+                t_merge = time.perf_counter() - t1
+                sm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+                sg = ohm_amd.GpuMap(sm, gpu_mem_size=16 << 30)
+                for r in range(8):
+                    sg.integrateRays(synth.rays_c4_shard(r, n=n_rays))
+                sg.syncVoxels()
+                reps[0].syncVoxels()
+                dev = D.merge_deviation(rmaps[0].chunks, sm.chunks, keys=[tuple(k) for k in shared.tolist()])
+                extra["C4_8_shards_one_gpu_replica_merge"] = {
+                    "regions_pending_per_rank": mstats["regions_pending"], "regions_union": mstats["regions_union"],
+                    "regions_exchanged": mstats["regions_shared"],
+                    "payload_bytes_per_rank": mstats["payload_bytes_per_rank"], "host_staged_merge_s": t_merge,
+                    "deviation_vs_sequential": dev,
+                    "note": "replica 0 vs ONE map integrating the 8 shards in rank order (the HIP path, bit exact vs the "
+                            "CPU mapper), over the exchanged regions"}
+                for rg in reps:
+                    rg.close()
+                sg.close()
+                del rmaps, sm
+            except Exception as exc:
+                extra["C4_8_shards_one_gpu_replica_merge"] = {"error": repr(exc)}
         # C1 variants SURVEY 8d asks to be reported next to the headline (never the headline `value`):
         # (i) the same batch fed as 4096-ray calls (the reference tools' default batch size): launch-latency bound;
         # (ii) end to end from HOST memory: pinned staging + H2D + integrate + syncVoxels into the host MapChunk blocks.
@@ -377,7 +586,8 @@ def main():
                     "48 B/ray all-gather"}
         out["other_configs"] = extra
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(rays, resolution, min(args.cpu_sample, n_rays))
+        out["cpu_baseline"] = cpu_baseline(rays, resolution, min(args.cpu_sample, n_rays),
+                                           all_cores=not args.no_cpu_all_cores)
     elif rank == 0:
         out["cpu_baseline"] = None
     L.lib.ohmhip_buffer_destroy(buf)

@@ -30,6 +30,7 @@ extern "C" {
 #define OHMHIP_ERR_UNSUPPORTED (-4) /* flag / layout not supported by the HIP path */
 #define OHMHIP_ERR_NOT_FOUND (-5)
 #define OHMHIP_ERR_INTERNAL (-6)
+#define OHMHIP_ERR_PEER (-7)        /* a collective call was abandoned because ANOTHER rank failed in it */
 
 const char *ohmhip_error_string(int status);
 
@@ -356,11 +357,26 @@ int ohmhip_region_owner(const int16_t *keys_xyz, size_t count, int block_shift, 
  * region-ownership mode above.  Other layers are not additive and stay per replica.
  *
  * ohmhip_map_enable_merge() gives the map a base copy of its occupancy layer (current content == base) and starts
- * tracking the regions modified since.  The merge itself is either one call over RCCL (ohmhip_map_merge_replicas:
- * region key lists are all-gathered, the delta tiles of the regions touched by MORE THAN ONE rank are all-reduced --
- * 5 bytes per voxel: float delta + observer count --, everything on the map's stream) or, for any other transport, the
- * three steps it is made of: ohmhip_map_merge_keys -> (exchange keys, agree on the ordered shared set) ->
- * ohmhip_map_merge_pack -> (sum the payloads across ranks) -> ohmhip_map_merge_apply -> ohmhip_map_merge_finish. */
+ * tracking the regions modified since.  INVARIANT: `base` of a region is the same on every rank (a rank that does not
+ * hold the region == base unobserved).  It changes only when the region is EXCHANGED, and then on every rank (a rank
+ * that never touched the region creates it and receives the merged tile).  A region that only one rank modified is
+ * not exchanged in OHMHIP_MERGE_SHARED_ONLY mode (the default): it stays PENDING on that rank -- listed by
+ * merge_keys in every later round, its base untouched -- until a second rank lists it too; then the owner's whole
+ * pending delta travels.  (Round 2 rebased such regions locally, which made `base` rank-private and later exchanges
+ * wrong on the peers.)  So after a merge: an exchanged region is bit-identical on all ranks; a pending region is
+ * exact on its one rank and absent / at its last exchanged value elsewhere.  OHMHIP_MERGE_FULL_UNION exchanges every
+ * pending region of any rank: all replicas are then bit-identical maps after every merge, at the price of moving
+ * the tiles only one rank needed.
+ *
+ * The merge itself is either one call over RCCL (ohmhip_map_merge_replicas: region key lists are all-gathered, the
+ * delta tiles of the agreed region list are all-reduced -- 5 bytes per voxel: float delta summed + observer flag by
+ * max --, everything on the map's stream; the ranks agree on the outcome of their local steps with a one-word
+ * all-reduce BEFORE the tile all-reduce, so a rank-local failure makes every rank return together: the failing rank its
+ * own error, the others OHMHIP_ERR_PEER, nothing applied, all regions still pending) or, for any other transport, the
+ * steps it is made of: ohmhip_map_merge_keys -> (exchange keys, agree on the ordered region list) ->
+ * ohmhip_map_merge_pack -> (sum the deltas / max the observer flags across ranks) -> ohmhip_map_merge_apply. */
+#define OHMHIP_MERGE_SHARED_ONLY 0
+#define OHMHIP_MERGE_FULL_UNION 1
 typedef struct ohmhip_comm_s *ohmhip_comm_t;
 #define OHMHIP_COMM_ID_BYTES 128
 int ohmhip_comm_unique_id(unsigned char id[OHMHIP_COMM_ID_BYTES]);  /* ncclGetUniqueId; hand it to every rank */
@@ -370,22 +386,24 @@ int ohmhip_comm_destroy(ohmhip_comm_t comm);
 
 typedef struct ohmhip_merge_stats
 {
-  uint32_t regions_local;   /* regions this rank modified since the previous merge                     */
+  uint32_t regions_local;   /* regions pending on this rank (modified since they were last exchanged)  */
   uint32_t regions_union;   /* ... any rank did                                                       */
-  uint32_t regions_shared;  /* ... more than one rank did: the ones whose tiles travel                */
+  uint32_t regions_shared;  /* the ones whose tiles travel (pending on > 1 rank; all in FULL_UNION)    */
   uint64_t payload_bytes;   /* bytes this rank contributed to the tile all-reduce (5 per shared voxel) */
   uint64_t key_bytes;       /* bytes it contributed to the key all-gather                              */
   float ms_total;           /* host wall time of the call                                              */
 } ohmhip_merge_stats;
 
 int ohmhip_map_enable_merge(ohmhip_map_t map);
-/* Collective over `comm`.  On return every rank holds the merged values of the shared regions, which -- like every
- * other region modified since the previous merge -- become the new base. */
+int ohmhip_map_set_merge_mode(ohmhip_map_t map, int mode);
+/* Collective over `comm`.  On return every rank holds the merged values of the exchanged regions, which become the new
+ * base on every rank. */
 int ohmhip_map_merge_replicas(ohmhip_map_t map, ohmhip_comm_t comm, ohmhip_merge_stats *stats);
-/* The steps, for other transports.  merge_keys: region keys (int16 x 3 each) modified since the previous merge, at most
- * `capacity` written, *count = how many there are.  merge_pack: for `count` regions in the given order (made resident
- * if they are not) write count x region_voxels float deltas and uint8 observer flags to the DEVICE buffers.
- * merge_apply: the same regions with the payloads summed over all ranks.  merge_finish: rebase everything modified. */
+/* The steps, for other transports.  merge_keys: keys (int16 x 3 each) of the PENDING regions -- modified since they were
+ * last exchanged --, at most `capacity` written, *count = how many there are.  merge_pack: for `count` regions in the
+ * given order (made resident if they are not) write count x region_voxels float deltas and uint8 observer flags to the
+ * DEVICE buffers.  merge_apply: the same regions with the deltas summed / flags max-ed (or summed) over all ranks; EVERY
+ * rank applies every exchanged region.  merge_finish: kept for ABI compatibility, nothing left to do. */
 int ohmhip_map_merge_keys(ohmhip_map_t map, int16_t *keys_xyz, size_t capacity, size_t *count);
 int ohmhip_map_merge_pack(ohmhip_map_t map, const int16_t *keys_xyz, size_t count, float *d_delta,
                           unsigned char *d_observers);

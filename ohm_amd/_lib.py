@@ -27,7 +27,9 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 OK = 0
-ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NOT_FOUND, ERR_INTERNAL = -1, -2, -3, -4, -5, -6
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NOT_FOUND, ERR_INTERNAL, ERR_PEER = (-1, -2, -3, -4,
+                                                                                                       -5, -6, -7)
+MERGE_SHARED_ONLY, MERGE_FULL_UNION = 0, 1
 
 (LID_OCCUPANCY, LID_MEAN, LID_COVARIANCE, LID_TRAVERSAL, LID_TOUCH_TIME, LID_INCIDENT, LID_INTENSITY, LID_HIT_MISS,
  LID_TSDF, LID_COUNT) = range(10)
@@ -145,6 +147,7 @@ _sigs = {
     "ohmhip_map_merge_pack": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "ohmhip_map_merge_apply": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "ohmhip_map_merge_finish": (C.c_int, [_vp]),
+    "ohmhip_map_set_merge_mode": (C.c_int, [_vp, C.c_int]),
 }
 
 EXPORTED_SYMBOLS = sorted(_sigs)

@@ -69,30 +69,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-/// Rebase: every region still flagged as modified since the previous merge takes its current values as base.
-__global__ void __launch_bounds__(256)
-  k_merge_rebase(uint32_t n_slots, uint32_t region_voxels, const float *__restrict__ occupancy,
-                 float *__restrict__ base, uint32_t *__restrict__ dirty)
-{
-  for (uint32_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x)
-  {
-    if (!(dirty[slot] & kDirtyMerge))
-    {
-      continue;
-    }
-    const size_t at = size_t(slot) * region_voxels;
-    for (uint32_t v = threadIdx.x; v < region_voxels; v += blockDim.x)
-    {
-      base[at + v] = occupancy[at + v];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      dirty[slot] &= ~kDirtyMerge;
-    }
-  }
-}
-
 int64_t packSortable(const int16_t *k)
 {
   return ((int64_t(k[0]) + 32768) << 32) | ((int64_t(k[1]) + 32768) << 16) | (int64_t(k[2]) + 32768);
@@ -309,13 +285,22 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
-  if (m->slots_committed)
+  // Nothing is rebased here (round 3): `base` must stay the state ALL replicas share, so a region only this
+  // rank modified keeps its shared base -- and stays pending -- until it has been exchanged (k_merge_apply clears
+  // the flag).  Rebasing it locally made `base` rank-private and later exchanges of the region wrong on the peers.
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_set_merge_mode(ohmhip_map_t m, int mode)
+try
+{
+  if (!m || (mode != OHMHIP_MERGE_SHARED_ONLY && mode != OHMHIP_MERGE_FULL_UNION))
   {
-    hipLaunchKernelGGL(k_merge_rebase, dim3(std::min<uint32_t>(m->slots_committed, 1024u)), dim3(256), 0, m->stream,
-                       m->slots_committed, uint32_t(m->mc.region_voxels),
-                       static_cast<const float *>(m->layers[OHMHIP_LID_OCCUPANCY]), m->d_merge_base, m->d_dirty);
+    return OHMHIP_ERR_INVALID_ARG;
   }
-  return hipGetLastError();
+  m->merge_mode = mode;
+  return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH
 
@@ -381,7 +366,7 @@ try
         ++j;
       }
       ++n_union;
-      if (j - i > 1)
+      if (j - i > 1 || m->merge_mode == OHMHIP_MERGE_FULL_UNION)
       {
         shared_keys.resize(shared_keys.size() + 3);
         unpackSortable(valid[i], &shared_keys[shared_keys.size() - 3]);
@@ -391,21 +376,49 @@ try
   }
   const size_t n_shared = shared_keys.size() / 3;
   const size_t voxels = n_shared * size_t(m->mc.region_voxels);
+  // 4. the fallible local work (buffers, making the regions resident, pack), then the ranks AGREE on its outcome with
+  //    a one-word all-reduce before the payload collective: a rank that failed must not leave its peers blocked in
+  //    the tile all-reduce.  Every rank takes part in both collectives whatever happened locally.
+  int local_err = OHMHIP_OK;
+  float *d_delta = nullptr;
+  unsigned char *d_obs = nullptr;
   if (n_shared)
   {
-    // 4. pack -> all-reduce (float deltas + observer counts, one group) -> apply, all on the map's stream
-    OHMHIP_CHECK(m->merge_delta.ensure(sizeof(float) * voxels, false, s));
-    OHMHIP_CHECK(m->merge_observers.ensure(voxels, false, s));
-    float *d_delta = static_cast<float *>(m->merge_delta.ptr);
-    unsigned char *d_obs = static_cast<unsigned char *>(m->merge_observers.ptr);
-    OHMHIP_CHECK(ohmhip_map_merge_pack(m, shared_keys.data(), n_shared, d_delta, d_obs));
+    local_err = m->merge_delta.ensure(sizeof(float) * voxels, false, s);
+    if (!local_err)
+    {
+      local_err = m->merge_observers.ensure(voxels, false, s);
+    }
+    if (!local_err)
+    {
+      d_delta = static_cast<float *>(m->merge_delta.ptr);
+      d_obs = static_cast<unsigned char *>(m->merge_observers.ptr);
+      local_err = ohmhip_map_merge_pack(m, shared_keys.data(), n_shared, d_delta, d_obs);
+    }
+  }
+  OHMHIP_CHECK(m->merge_keys_dev.ensure(sizeof(int64_t) * 2, true, s));
+  int32_t *d_status = static_cast<int32_t *>(m->merge_keys_dev.ptr);
+  const int32_t failed = local_err ? 1 : 0;
+  int32_t any_failed = 0;
+  OHMHIP_CHECK(hipMemcpyAsync(d_status, &failed, sizeof(failed), hipMemcpyHostToDevice, s));
+  OHMHIP_CHECK(ncclStatus(ncclAllReduce(d_status, d_status + 1, 1, ncclInt32, ncclMax, comm->comm, s)));
+  OHMHIP_CHECK(hipMemcpyAsync(&any_failed, d_status + 1, sizeof(any_failed), hipMemcpyDeviceToHost, s));
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+  if (any_failed)
+  {
+    return local_err ? local_err : OHMHIP_ERR_PEER;  // every rank leaves here together; nothing was applied
+  }
+  if (n_shared)
+  {
+    // 5. all-reduce (float deltas summed; observer flags by max: only non-zero matters and a u8 sum would wrap at 256
+    //    ranks) -> apply, all on the map's stream
     OHMHIP_CHECK(ncclStatus(ncclGroupStart()));
     OHMHIP_CHECK(ncclStatus(ncclAllReduce(d_delta, d_delta, voxels, ncclFloat, ncclSum, comm->comm, s)));
-    OHMHIP_CHECK(ncclStatus(ncclAllReduce(d_obs, d_obs, voxels, ncclUint8, ncclSum, comm->comm, s)));
+    OHMHIP_CHECK(ncclStatus(ncclAllReduce(d_obs, d_obs, voxels, ncclUint8, ncclMax, comm->comm, s)));
     OHMHIP_CHECK(ncclStatus(ncclGroupEnd()));
     OHMHIP_CHECK(ohmhip_map_merge_apply(m, shared_keys.data(), n_shared, d_delta, d_obs));
   }
-  // 5. everything else this rank modified becomes base as it is
+  // 6. regions only this rank modified are left pending on their shared base (see ohmhip_map_merge_finish)
   OHMHIP_CHECK(ohmhip_map_merge_finish(m));
   if (stats)
   {

@@ -26,6 +26,8 @@ const char *ohmhip_error_string(int status)
     return "ohmhip: region not found";
   case OHMHIP_ERR_INTERNAL:
     return "ohmhip: internal error";
+  case OHMHIP_ERR_PEER:
+    return "ohmhip: collective abandoned, another rank failed";
   default:
     break;
   }

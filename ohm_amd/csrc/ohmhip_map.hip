@@ -124,6 +124,7 @@ struct ohmhip_map_s
   DevBuf wg_regions[2], wg_region_count[2], group_heads;  // (workgroup region lists: per parity)
   /// Replica merge (merge_impl.h): base copy of the occupancy layer (null until ohmhip_map_enable_merge) and scratch.
   float *d_merge_base = nullptr;
+  int merge_mode = 0;  ///< OHMHIP_MERGE_SHARED_ONLY / OHMHIP_MERGE_FULL_UNION
   /// Traversal layer only: per-voxel fixed-point sum of a batch's ray lengths (zero between batches).
   unsigned long long *d_traversal_acc = nullptr;
   DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;

@@ -201,21 +201,28 @@ class Communicator:
 
 
 class ReplicaMerger:
-    """Replica merge of a GpuMap's occupancy layer (include/ohmhip.h "Replica merge"): the map keeps the state all
-    replicas shared after the previous merge and the set of regions modified since; merge() reconciles the regions more
-    than one rank modified.
+    """Replica merge of a GpuMap's occupancy layer (include/ohmhip.h "Replica merge").  The map keeps, per region, the
+    state ALL replicas share (`base`: identical on every rank, changed only when the region is exchanged -- and then on
+    every rank) and the set of PENDING regions (modified since they were last exchanged).  merge() exchanges the regions
+    pending on more than one rank (`full_union=True`: on any rank, which keeps all replicas bit-identical maps); a
+    region pending on one rank only stays pending, on its shared base, until a second rank reaches it.
 
     usage:  merger = ReplicaMerger(gpu_map, comm=Communicator())   # RCCL inside the library, everything on device
             ... integrateRays on every rank ...;  stats = merger.merge()
     Without `comm` the same steps run over a torch.distributed group of any backend (gloo in the tests): key lists by
-    all_gather_object, payloads by all_reduce on tensors that alias the library's device buffers (or host copies)."""
+    all_gather_object, payloads by all_reduce on host copies of the library's device buffers.  Either way the ranks
+    agree on the outcome of their local steps BEFORE the payload collective, so a rank-local failure raises on every
+    rank (OhmHipError with ERR_PEER on the ranks that did not fail themselves) instead of leaving the peers blocked."""
 
-    def __init__(self, gpu_map, group=None, comm=None):
+    def __init__(self, gpu_map, group=None, comm=None, full_union=False):
         from . import _lib as L
         self.gpu_map = gpu_map
         self.group = group
         self.comm = comm
+        self.full_union = bool(full_union)
         L.check(L.lib.ohmhip_map_enable_merge(gpu_map._handle), "enable_merge")
+        L.check(L.lib.ohmhip_map_set_merge_mode(gpu_map._handle,
+                                                L.MERGE_FULL_UNION if full_union else L.MERGE_SHARED_ONLY), "merge_mode")
 
     def local_keys(self):
         import ctypes as C
@@ -243,43 +250,142 @@ class ReplicaMerger:
         import torch.distributed as dist
         from . import _lib as L
         gm = self.gpu_map
-        local = self.local_keys()
         world = dist.get_world_size(self.group)
+        # local, fallible: the pending list.  A failure is carried into the first collective instead of raised here.
+        local_err, local = None, np.zeros((0, 3), dtype=np.int16)
+        try:
+            local = self.local_keys()
+        except Exception as exc:
+            local_err = exc
         gathered = [None] * world
-        dist.all_gather_object(gathered, _pack_keys(local).tolist(), group=self.group)
+        dist.all_gather_object(gathered, None if local_err else _pack_keys(local).tolist(), group=self.group)
+        if any(lst is None for lst in gathered):
+            raise local_err if local_err else L.OhmHipError(L.ERR_PEER, "merge_keys failed on another rank")
         counts = {}
         for lst in gathered:
             for k in lst:
                 counts[k] = counts.get(k, 0) + 1
-        shared = _unpack_keys(np.array(sorted(k for k, c in counts.items() if c > 1), dtype=np.int64)).reshape(-1, 3)
+        need = 0 if self.full_union else 1
+        shared = _unpack_keys(np.array(sorted(k for k, c in counts.items() if c > need), dtype=np.int64)).reshape(-1, 3)
         shared = np.ascontiguousarray(shared, dtype=np.int16)
         n = len(shared)
         voxels = n * int(np.prod(gm._map.region_voxel_dimensions))
+        delta = obs = None
+        h_delta = np.zeros(voxels, dtype=np.float32)
+        h_obs = np.zeros(voxels, dtype=np.uint8)
         if n:
-            delta = L._vp()
-            obs = L._vp()
-            L.check(L.lib.ohmhip_buffer_create(C.byref(delta), 4 * voxels, 3), "buffer_create")
-            L.check(L.lib.ohmhip_buffer_create(C.byref(obs), voxels, 3), "buffer_create")
-            d_delta, d_obs = L._vp(), L._vp()
-            L.check(L.lib.ohmhip_buffer_ptr(delta, C.byref(d_delta)))
-            L.check(L.lib.ohmhip_buffer_ptr(obs, C.byref(d_obs)))
-            L.check(L.lib.ohmhip_map_merge_pack(gm._handle, shared.ctypes.data, n, d_delta, d_obs), "merge_pack")
-            # reduce through host tensors: works for every backend (the RCCL path of the library stays on the device)
-            h_delta = np.zeros(voxels, dtype=np.float32)
-            h_obs = np.zeros(voxels, dtype=np.uint8)
-            L.check(L.lib.ohmhip_buffer_read(delta, h_delta.ctypes.data, 4 * voxels, 0, None, None, None))
-            L.check(L.lib.ohmhip_buffer_read(obs, h_obs.ctypes.data, voxels, 0, None, None, None))
+            try:
+                delta, obs = L._vp(), L._vp()
+                L.check(L.lib.ohmhip_buffer_create(C.byref(delta), 4 * voxels, 3), "buffer_create")
+                L.check(L.lib.ohmhip_buffer_create(C.byref(obs), voxels, 3), "buffer_create")
+                d_delta, d_obs = L._vp(), L._vp()
+                L.check(L.lib.ohmhip_buffer_ptr(delta, C.byref(d_delta)))
+                L.check(L.lib.ohmhip_buffer_ptr(obs, C.byref(d_obs)))
+                L.check(L.lib.ohmhip_map_merge_pack(gm._handle, shared.ctypes.data, n, d_delta, d_obs), "merge_pack")
+                # reduce through host tensors: works for every backend (the RCCL path of the library stays on the device)
+                L.check(L.lib.ohmhip_buffer_read(delta, h_delta.ctypes.data, 4 * voxels, 0, None, None, None))
+                L.check(L.lib.ohmhip_buffer_read(obs, h_obs.ctypes.data, voxels, 0, None, None, None))
+            except Exception as exc:
+                local_err = exc
+        # the ranks agree on the outcome of the local steps before the payload collective
+        status = torch.tensor([1 if local_err else 0], dtype=torch.int32)
+        dist.all_reduce(status, op=dist.ReduceOp.MAX, group=self.group)
+        if int(status.item()):
+            for b in (delta, obs):
+                if b:
+                    L.lib.ohmhip_buffer_destroy(b)
+            raise local_err if local_err else L.OhmHipError(L.ERR_PEER, "merge_pack failed on another rank")
+        if n:
             t_delta = torch.from_numpy(h_delta)
-            t_obs = torch.from_numpy(h_obs.astype(np.int32))
+            t_obs = torch.from_numpy(h_obs)
             dist.all_reduce(t_delta, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(t_obs, op=dist.ReduceOp.SUM, group=self.group)
-            h_obs = np.minimum(t_obs.numpy(), 255).astype(np.uint8)
+            dist.all_reduce(t_obs, op=dist.ReduceOp.MAX, group=self.group)  # as the library: only non-zero matters
             L.check(L.lib.ohmhip_buffer_write(delta, t_delta.numpy().ctypes.data, 4 * voxels, 0, None, None, None))
-            L.check(L.lib.ohmhip_buffer_write(obs, h_obs.ctypes.data, voxels, 0, None, None, None))
+            L.check(L.lib.ohmhip_buffer_write(obs, t_obs.numpy().ctypes.data, voxels, 0, None, None, None))
             L.check(L.lib.ohmhip_map_merge_apply(gm._handle, shared.ctypes.data, n, d_delta, d_obs), "merge_apply")
             L.lib.ohmhip_buffer_destroy(delta)
             L.lib.ohmhip_buffer_destroy(obs)
-        L.check(L.lib.ohmhip_map_merge_finish(gm._handle), "merge_finish")
         gm.wait()
         return {"regions_local": len(local), "regions_union": len(counts), "regions_shared": n,
                 "payload_bytes": 5 * voxels}
+
+
+def merge_in_process(gpu_maps, full_union=False, chunk_regions=256):
+    """The replica merge for several merge-enabled GpuMaps living in ONE process (stand-ins for ranks on a single GPU:
+    tests, and the C4 deviation figure of bench.py at --gpus 1).  Same library steps as ReplicaMerger -- merge_keys ->
+    agreed list -> merge_pack on every map -> payloads summed (deltas, in rank order) / max-ed (observer flags) on the
+    host -> merge_apply on EVERY map.  Returns (exchanged_keys (n, 3) int16, stats dict)."""
+    import ctypes as C
+    from . import _lib as L
+    pend = []
+    for gm in gpu_maps:
+        n = C.c_size_t(0)
+        L.check(L.lib.ohmhip_map_merge_keys(gm._handle, None, 0, C.byref(n)), "merge_keys")
+        keys = np.zeros((max(n.value, 1), 3), dtype=np.int16)
+        L.check(L.lib.ohmhip_map_merge_keys(gm._handle, keys.ctypes.data, n.value, C.byref(n)), "merge_keys")
+        pend.append(_pack_keys(keys[:n.value]).tolist())
+    counts = {}
+    for lst in pend:
+        for k in lst:
+            counts[k] = counts.get(k, 0) + 1
+    need = 0 if full_union else 1
+    picked = np.array(sorted(k for k, c in counts.items() if c > need), dtype=np.int64)
+    shared = np.ascontiguousarray(_unpack_keys(picked).reshape(-1, 3), dtype=np.int16)
+    voxels_per_region = int(np.prod(gpu_maps[0]._map.region_voxel_dimensions))
+    for at in range(0, len(shared), chunk_regions):
+        part = np.ascontiguousarray(shared[at:at + chunk_regions])
+        n = len(part)
+        voxels = n * voxels_per_region
+        delta, obs, d_delta, d_obs = L._vp(), L._vp(), L._vp(), L._vp()
+        L.check(L.lib.ohmhip_buffer_create(C.byref(delta), 4 * voxels, 3), "buffer_create")
+        L.check(L.lib.ohmhip_buffer_create(C.byref(obs), voxels, 3), "buffer_create")
+        L.check(L.lib.ohmhip_buffer_ptr(delta, C.byref(d_delta)))
+        L.check(L.lib.ohmhip_buffer_ptr(obs, C.byref(d_obs)))
+        d_sum = np.zeros(voxels, dtype=np.float32)
+        o_max = np.zeros(voxels, dtype=np.uint8)
+        h_d = np.zeros(voxels, dtype=np.float32)
+        h_o = np.zeros(voxels, dtype=np.uint8)
+        for gm in gpu_maps:
+            L.check(L.lib.ohmhip_map_merge_pack(gm._handle, part.ctypes.data, n, d_delta, d_obs), "merge_pack")
+            L.check(L.lib.ohmhip_buffer_read(delta, h_d.ctypes.data, 4 * voxels, 0, None, None, None))
+            L.check(L.lib.ohmhip_buffer_read(obs, h_o.ctypes.data, voxels, 0, None, None, None))
+            d_sum += h_d
+            np.maximum(o_max, h_o, out=o_max)
+        L.check(L.lib.ohmhip_buffer_write(delta, d_sum.ctypes.data, 4 * voxels, 0, None, None, None))
+        L.check(L.lib.ohmhip_buffer_write(obs, o_max.ctypes.data, voxels, 0, None, None, None))
+        for gm in gpu_maps:
+            L.check(L.lib.ohmhip_map_merge_apply(gm._handle, part.ctypes.data, n, d_delta, d_obs), "merge_apply")
+        L.lib.ohmhip_buffer_destroy(delta)
+        L.lib.ohmhip_buffer_destroy(obs)
+    for gm in gpu_maps:
+        gm.wait()
+    return shared, {"regions_pending": [len(p) for p in pend], "regions_union": len(counts),
+                    "regions_shared": len(shared), "payload_bytes_per_rank": 5 * len(shared) * voxels_per_region}
+
+
+def merge_deviation(merged_chunks, sequential_chunks, keys=None, rel=1e-5):
+    """Replica-merged occupancy vs the SEQUENTIAL integration of the same rays (the additive rule is exact
+    only while no clamp engages between the shards' updates -- 'must be stated with results').  Both arguments are
+    {key: {'occupancy': float32[...]}} host maps; `keys` restricts the comparison (default: regions of both).
+    Counts voxels whose observed-state differs, whose values differ at all (float summation order counts) and beyond
+    `rel`, and the largest |difference|."""
+    if keys is None:
+        keys = sorted(set(merged_chunks) & set(sequential_chunks))
+    out = {"regions_compared": 0, "voxels_compared": 0, "voxels_observed": 0, "voxels_state_differs": 0,
+           "voxels_value_differs": 0, "voxels_beyond_rel": 0, "max_abs_delta": 0.0, "rel": rel}
+    for key in keys:
+        key = tuple(int(v) for v in key)
+        a = merged_chunks[key]["occupancy"].reshape(-1)
+        b = sequential_chunks[key]["occupancy"].reshape(-1)
+        fa, fb = np.isfinite(a), np.isfinite(b)
+        both = fa & fb
+        d = np.abs(a[both].astype(np.float64) - b[both].astype(np.float64))
+        out["regions_compared"] += 1
+        out["voxels_compared"] += int(a.size)
+        out["voxels_observed"] += int(fb.sum())
+        out["voxels_state_differs"] += int((fa != fb).sum())
+        out["voxels_value_differs"] += int((d > 0).sum())
+        out["voxels_beyond_rel"] += int((d > rel * np.maximum(1.0, np.abs(b[both]))).sum())
+        if d.size:
+            out["max_abs_delta"] = max(out["max_abs_delta"], float(d.max()))
+    return out

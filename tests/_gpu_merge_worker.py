@@ -35,10 +35,16 @@ def main():
         st = merger.merge()
         n = st["regions_local"]
         assert n == len(gm.regionKeys()) and st["regions_union"] == n and st["regions_shared"] == 0
-        # with one rank nothing is shared: the merge only rebases; a second round on a non-trivial base
+        # with one rank nothing is shared: every region stays pending on its (unobserved) shared base ...
+        assert len(merger.local_keys()) == n
         gm.integrateRays(rays[:2000])
         st = merger.merge()
-        assert 0 < st["regions_local"] <= n and st["payload_bytes"] == 0
+        assert st["regions_local"] == n and st["payload_bytes"] == 0
+        # ... until a full-union merge exchanges it (with itself here: merged = clamp(base + own delta) = own value)
+        from ohm_amd import _lib as LL
+        LL.check(LL.lib.ohmhip_map_set_merge_mode(gm._handle, LL.MERGE_FULL_UNION), "merge_mode")
+        st = merger.merge()
+        assert st["regions_shared"] == n and st["payload_bytes"] == 5 * n * 32 ** 3
         assert len(merger.local_keys()) == 0
         comm.close()
         gm.syncVoxels()

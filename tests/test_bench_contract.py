@@ -54,3 +54,23 @@ def test_traffic_file_matches_the_profile_it_cites():
     avg_us = float(row[3])
     assert abs(avg_us * 1e-3 - line["roofline"]["kernel_ms"]) / line["roofline"]["kernel_ms"] < 0.05
     assert f"{traffic['fetch_size_kb']:.1f}" in summary and f"{traffic['write_size_kb']:.1f}" in summary
+
+
+def test_gpus_n_without_a_launcher_environment_starts_n_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start two ranks itself (VERDICT r2 missing 2).  With every GPU
+    hidden the product path cannot run -- there is no CPU fallback -- so the ranks only rendezvous (gloo, 127.0.0.1),
+    count each other and rank 0 prints a line with n_gpus = 2, value = null and the reason."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo"
+    assert line["value"] is None and "no HIP device" in line["error"]

@@ -120,3 +120,125 @@ def test_c4_shard_origin_on_voxel_boundaries_matches_oracle(gpu):
         om.integrate_occupancy(rays)
         assert om.visit_count() == gm.stats()["voxel_visits"]
         assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
+
+
+def test_c0_100k_uniform_10m_rays_vs_oracle(gpu):
+    """BASELINE configs[0] on its own rays: 100 k uniform 10 m rays from one origin, 0.1 m voxels, 32^3 regions."""
+    rays = synth.rays_c0()
+    assert rays.shape[0] == 200_000
+    map_ = OccupancyMap(0.1, layers=("occupancy", "mean"))
+    gm = GpuMap(map_)
+    assert gm.integrateRays(rays) == rays.shape[0]
+    gm.syncVoxels()
+    om = make_oracle(map_)
+    om.integrate_occupancy(rays)
+    assert om.visit_count() == gm.stats()["voxel_visits"] == expected_visits(rays, 0.1, False)
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
+
+
+def test_c4_full_8_shards_owner_computes_and_replica_merge(gpu):
+    """BASELINE configs[4] at full size on the one test GPU: 8 x 1 M rays from 8 sensor origins.
+
+    (1) ONE map integrating the 8 shards in rank order -- the sequential result, checked against the CPU oracle on a
+        100 k-ray-per-shard subsample integrated the same way (bit exact);
+    (2) owner computes: 8 maps standing in for 8 ranks, each given the whole 8 M-ray stream and keeping only its own
+        regions -> their union is bit-identical to (1);
+    (3) replica merge: 8 merge-enabled maps, each integrating its own shard, merged once through the library's steps ->
+        every exchanged region bit-identical on all replicas, and its deviation from (1) COUNTED (the additive rule is
+        exact only where no clamp engaged between the shards: SURVEY 8e says to state it with the results)."""
+    from ohm_amd import _lib as L
+    from ohm_amd import distributed as D
+    n = 1_000_000
+    shards = [synth.rays_c4_shard(r, n=n) for r in range(8)]
+    # (1) sequential, full size
+    seq_map = OccupancyMap(0.1, layers=("occupancy",))
+    seq = GpuMap(seq_map, gpu_mem_size=16 << 30)
+    for s in shards:
+        assert seq.integrateRays(s) == s.shape[0]
+    seq.syncVoxels()
+    seq.close()
+    # ... and the same at 100 k rays per shard against the oracle
+    sub_map = OccupancyMap(0.1, layers=("occupancy",))
+    sub = GpuMap(sub_map, gpu_mem_size=4 << 30)
+    om = make_oracle(sub_map)
+    for r in range(8):
+        part = synth.rays_c4_shard(r, n=100_000)
+        assert sub.integrateRays(part) == part.shape[0]
+        om.integrate_occupancy(part)
+    sub.syncVoxels()
+    sub.close()
+    assert_parity(compare_maps(om.chunks(), sub_map.chunks, ["occupancy"], exact_float=True))
+    del om, sub_map
+    # (2) owner computes, 8 maps, the whole stream each
+    stream = np.concatenate(shards)
+    owned = {}
+    for rank in range(8):
+        m = OccupancyMap(0.1, layers=("occupancy",))
+        g = GpuMap(m, gpu_mem_size=4 << 30)
+        g.setRegionOwnership(8, rank, 0)
+        for i in range(0, stream.shape[0], 2 * n):  # the same 1 M-ray batches as (1)
+            assert g.integrateRays(stream[i:i + 2 * n]) == 2 * n
+        g.syncVoxels()
+        g.close()
+        keys = np.array(sorted(m.chunks), dtype=np.int16).reshape(-1, 3)
+        assert np.all(D.region_owner(keys, 8, 0) == rank)
+        for k, c in m.chunks.items():
+            assert k not in owned
+            owned[k] = c
+    del stream
+    assert set(owned) == set(seq_map.chunks) and len(owned) > 5000
+    for k, c in seq_map.chunks.items():
+        assert np.array_equal(c["occupancy"].view(np.uint32), owned[k]["occupancy"].view(np.uint32)), k
+    del owned
+    # (3) replica merge
+    maps = [OccupancyMap(0.1, layers=("occupancy",)) for _ in range(8)]
+    gms = [GpuMap(m, gpu_mem_size=2 << 30) for m in maps]
+    for g, s in zip(gms, shards):
+        L.check(L.lib.ohmhip_map_enable_merge(g._handle), "enable_merge")
+        assert g.integrateRays(s) == s.shape[0]
+    shared, stats = D.merge_in_process(gms)
+    assert stats["regions_shared"] == len(shared) > 500 and stats["regions_union"] == len(seq_map.chunks)
+    keys = [tuple(k) for k in shared.tolist()]
+    for g in gms:
+        g.syncVoxels()
+        g.close()
+    for k in keys:  # every replica holds every exchanged region, bit-identical
+        for m in maps[1:]:
+            assert np.array_equal(maps[0].chunks[k]["occupancy"].view(np.uint32), m.chunks[k]["occupancy"].view(np.uint32))
+    dev = D.merge_deviation(maps[0].chunks, seq_map.chunks, keys=keys)
+    print("C4 replica merge vs sequential:", dev, stats)
+    assert dev["regions_compared"] == len(keys) and dev["voxels_state_differs"] == 0
+    # the statement, as measured: only a small fraction of the observed voxels of the overlap differ beyond 1e-5 (clamp
+    # interplay); the rest agree to float summation order
+    assert dev["voxels_beyond_rel"] <= 0.05 * dev["voxels_observed"]
+    # regions only one shard touched are exact on that replica
+    shared_set = set(keys)
+    for r, m in enumerate(maps):
+        for k, c in m.chunks.items():
+            if k not in shared_set:
+                assert np.array_equal(c["occupancy"].view(np.uint32), seq_map.chunks[k]["occupancy"].view(np.uint32)), (r, k)
+
+
+def test_bench_gpus_2_launches_two_ranks_on_the_one_gpu(gpu):
+    """`python bench.py --gpus 2` (no launcher environment): two ranks are started, share the one GPU (gloo control plane,
+    staged merge), and the line reports n_gpus = 2 with merge statistics and the merge-vs-sequential deviation."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--rays", "200000"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["devices_visible"] >= 1
+    assert line["value"] > 0 and line["config"]["rays_per_step_per_gpu"] == 200000
+    assert "error" not in line["merge"], line["merge"]
+    assert line["merge"]["per_step"]["regions_union"] >= line["merge"]["per_step"]["regions_local"] > 0
+    dev = line["merge"]["deviation"]
+    assert "error" not in dev and dev["regions_compared"] > 0 and dev["voxels_state_differs"] == 0
