@@ -55,6 +55,7 @@ typedef struct ohmhip_device_info
 int ohmhip_device_count(int *count);                            /* gputil/cuda/gpuDevice.cpp:108-115 */
 int ohmhip_device_select(int device);                           /* gputil/cuda/gpuKernel.cpp:33 (cudaSetDevice) */
 int ohmhip_device_get_info(int device, ohmhip_device_info *info);
+int ohmhip_device_synchronize(void);                            /* cudaDeviceSynchronize, gputil/cuda/gpuBuffer.cpp (pin) */
 
 int ohmhip_stream_create(ohmhip_stream_t *stream);              /* gputil/cuda/gpuDevice.cpp:156 */
 int ohmhip_stream_destroy(ohmhip_stream_t stream);              /* gputil/cuda/gpuQueue.cpp:22  */
@@ -85,6 +86,15 @@ int ohmhip_buffer_read(ohmhip_buffer_t buffer, void *dst, size_t bytes, size_t s
                        ohmhip_event_t block_on, ohmhip_event_t completion);
 int ohmhip_buffer_fill(ohmhip_buffer_t buffer, int byte_value, size_t bytes, size_t offset,
                        ohmhip_stream_t stream);                                  /* gputil/cuda/gpuBuffer.cpp:206 */
+/* Buffer::fill / fillPartial with an arbitrary pattern (gputil/gpuBuffer.h:199-236): `bytes` from `offset` are filled
+ * with repetitions of the pattern, the last one cut short if it does not fit.  Asynchronous when `stream` is given. */
+int ohmhip_buffer_fill_pattern(ohmhip_buffer_t buffer, const void *pattern, size_t pattern_size, size_t bytes,
+                               size_t offset, ohmhip_stream_t stream, ohmhip_event_t block_on,
+                               ohmhip_event_t completion);
+/* gputil::copyBuffer (gputil/gpuBuffer.h:459-510): device-side copy between two buffers. */
+int ohmhip_buffer_copy(ohmhip_buffer_t dst, size_t dst_offset, ohmhip_buffer_t src, size_t src_offset, size_t bytes,
+                       ohmhip_stream_t stream, ohmhip_event_t block_on, ohmhip_event_t completion);
+int ohmhip_buffer_flags(ohmhip_buffer_t buffer, unsigned *flags);                /* Buffer::flags */
 /* Pinned host staging memory (gputil::PinnedBuffer, gputil/cuda/gpuPinnedBuffer.cpp:66-131). */
 int ohmhip_host_alloc(void **ptr, size_t bytes);
 int ohmhip_host_free(void *ptr);

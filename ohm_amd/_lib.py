@@ -102,6 +102,10 @@ _sigs = {
     "ohmhip_buffer_write": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp]),
     "ohmhip_buffer_read": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp]),
     "ohmhip_buffer_fill": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, _vp]),
+    "ohmhip_device_synchronize": (C.c_int, []),
+    "ohmhip_buffer_fill_pattern": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]),
+    "ohmhip_buffer_copy": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp]),
+    "ohmhip_buffer_flags": (C.c_int, [_vp, C.POINTER(C.c_uint)]),
     "ohmhip_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "ohmhip_host_free": (C.c_int, [_vp]),
     "ohmhip_layer_voxel_bytes": (C.c_size_t, [C.c_int]),

@@ -2,6 +2,7 @@
 // ray-integration path uses; see include/ohmhip.h for the reference citations).  gfx950 / ROCm only.
 #include "ohmhip_internal.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -239,6 +240,14 @@ try
 }
 OHMHIP_ABI_CATCH
 
+int ohmhip_device_synchronize(void)
+try
+{
+  OHMHIP_CHECK(hipDeviceSynchronize());
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
 int ohmhip_buffer_create(ohmhip_buffer_t *buffer, size_t bytes, unsigned flags)
 try
 {
@@ -424,6 +433,110 @@ try
   {
     OHMHIP_CHECK(hipMemset(static_cast<char *>(buffer->ptr) + offset, byte_value, bytes));
   }
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+namespace
+{
+struct FillPattern
+{
+  unsigned char bytes[64];
+};
+
+__global__ void k_fill_pattern(unsigned char *dst, FillPattern pattern, uint32_t pattern_size, size_t count)
+{
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
+  {
+    dst[i] = pattern.bytes[i % pattern_size];
+  }
+}
+}  // namespace
+
+int ohmhip_buffer_fill_pattern(ohmhip_buffer_t buffer, const void *pattern, size_t pattern_size, size_t bytes,
+                               size_t offset, ohmhip_stream_t stream, ohmhip_event_t block_on,
+                               ohmhip_event_t completion)
+try
+{
+  if (!buffer || !pattern || pattern_size == 0 || offset + bytes > buffer->bytes)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (pattern_size > sizeof(FillPattern))
+  {
+    return OHMHIP_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = stream ? stream->stream : nullptr;
+  if (block_on && block_on->recorded)
+  {
+    if (stream)
+    {
+      OHMHIP_CHECK(hipStreamWaitEvent(s, block_on->event, 0));
+    }
+    else
+    {
+      OHMHIP_CHECK(hipEventSynchronize(block_on->event));
+    }
+  }
+  unsigned char *dst = static_cast<unsigned char *>(buffer->ptr) + offset;
+  if (bytes)
+  {
+    if (buffer->flags & OHMHIP_BF_HOST_ACCESS)
+    {
+      if (stream)
+      {
+        OHMHIP_CHECK(hipStreamSynchronize(s));  // host-side fill: ordered behind what the stream already holds
+      }
+      const unsigned char *p = static_cast<const unsigned char *>(pattern);
+      for (size_t i = 0; i < bytes; ++i)
+      {
+        dst[i] = p[i % pattern_size];
+      }
+    }
+    else
+    {
+      FillPattern fp;
+      std::memcpy(fp.bytes, pattern, pattern_size);
+      const unsigned blocks = unsigned(std::min<size_t>((bytes + 255) / 256, 4096));
+      hipLaunchKernelGGL(k_fill_pattern, dim3(blocks), dim3(256), 0, s, dst, fp, uint32_t(pattern_size), bytes);
+      OHMHIP_CHECK(hipGetLastError());
+    }
+  }
+  if (completion)
+  {
+    OHMHIP_CHECK(hipEventRecord(completion->event, s));
+    completion->recorded = true;
+  }
+  if (!stream)
+  {
+    OHMHIP_CHECK(hipStreamSynchronize(nullptr));
+  }
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_buffer_copy(ohmhip_buffer_t dst, size_t dst_offset, ohmhip_buffer_t src, size_t src_offset, size_t bytes,
+                       ohmhip_stream_t stream, ohmhip_event_t block_on, ohmhip_event_t completion)
+try
+{
+  if (!dst || !src || dst_offset + bytes > dst->bytes || src_offset + bytes > src->bytes)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  return copyCommon(static_cast<char *>(dst->ptr) + dst_offset, static_cast<const char *>(src->ptr) + src_offset, bytes,
+                    hipMemcpyDefault, stream, block_on, completion);
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_buffer_flags(ohmhip_buffer_t buffer, unsigned *flags)
+try
+{
+  if (!buffer || !flags)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  *flags = buffer->flags;
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH

@@ -47,6 +47,16 @@ struct QueueDetail
   }
 };
 
+/// gputil::Buffer: one C-ABI buffer (device memory, or -- kBfHostAccess -- pinned host memory the device maps) plus
+/// the size the caller asked for (the allocation itself is padded).
+struct BufferDetail
+{
+  ohmhip_buffer_t buffer = nullptr;
+  size_t requested = 0;
+  unsigned flags = 0;
+  int device = -1;
+};
+
 /// Reference counted event (gputil::Event is copyable; copies share the underlying event).
 struct EventDetail
 {
