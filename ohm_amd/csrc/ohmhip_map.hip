@@ -166,6 +166,12 @@ struct ohmhip_map_s
   size_t pending_calls = 0;
   unsigned pending_flags = 0;
   bool pending_intens = false, pending_times = false, pending_fflags = false;
+  /// The pending rays were presented through the device-pointer entry point: they sit in the filling slot's DEVICE
+  /// buffers already (copied there device to device), the pinned block is not used.
+  bool pending_on_device = false;
+  uint32_t *h_passed = nullptr;      ///< pinned, device visible: per-call filter count of a deferred device-pointer batch
+  uint32_t *h_passed_dev = nullptr;
+  hipEvent_t ev_passed = nullptr;
   /// Host-pointer batches smaller than this are collected and run as one device batch (0: every host batch is launched
   /// by the call that presents it).  On by default: the reference tools present 4096 rays per call.
   size_t coalesce_min_rays = size_t(1) << 16;
@@ -183,10 +189,23 @@ struct ohmhip_map_s
   /// into the pool when a batch (or an upload) touches it.
   struct SpilledRegion
   {
-    std::vector<char> layer[OHMHIP_LID_COUNT];
-    std::vector<uint32_t> mask_row;  ///< NDT / TSDF: the persistent per-voxel replay mask
+    /// One record of the pinned host store: the region's block of every enabled layer, in layer-id order, followed by
+    /// its row of the NDT / TSDF replay mask (layerOffset / maskOffset below).  Pinned, so evictions and re-admissions
+    /// are single asynchronous copies straight between the pool and the record -- no staging pass on either side.
+    char *record = nullptr;
     uint32_t dirty = 0;
   };
+  /// Pinned host store: slabs of fixed-size records, handed out from a free list.
+  struct HostStore
+  {
+    size_t record_bytes = 0;
+    size_t layer_offset[OHMHIP_LID_COUNT] = {};
+    size_t mask_offset = 0;
+    size_t mask_bytes = 0;
+    std::vector<void *> slabs;
+    std::vector<char *> free_records;
+    size_t records_total = 0;
+  } store;
   std::unordered_map<uint64_t, SpilledRegion> spilled;
   bool spill_enabled = false;
   uint64_t evictions = 0, readmissions = 0;
@@ -194,7 +213,9 @@ struct ohmhip_map_s
 
 // Defined further down (they use the region read / remove machinery of the C ABI section).
 int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed);
-int evictColdRegions(ohmhip_map_t m, uint32_t want_free);
+int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict = 0xffffffffu);
+int makeRoomForNamedRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count);
+int growPoolForNamedRegions(ohmhip_map_t m, uint32_t total, uint32_t keep);
 int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot);
 int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count);
 
@@ -560,6 +581,12 @@ int rollbackTable(ohmhip_map_t m)
   {
     OHMHIP_CHECK(hipMemsetAsync(m->d_slot_keys + keep, 0, sizeof(uint64_t) * (m->slot_capacity - keep), s));
   }
+  if (m->slot_capacity > keep)
+  {
+    // the slots the failed batch handed out go back to the pristine state: no modified flags, no use stamp
+    OHMHIP_CHECK(hipMemsetAsync(m->d_dirty + keep, 0, sizeof(uint32_t) * (m->slot_capacity - keep), s));
+    OHMHIP_CHECK(hipMemsetAsync(m->d_last_use + keep, 0, sizeof(uint32_t) * (m->slot_capacity - keep), s));
+  }
   OHMHIP_CHECK(hipMemcpyAsync(m->d_n_slots, &keep, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   if (keep)
   {
@@ -645,6 +672,75 @@ int ensureStage(ohmhip_map_t m, size_t bytes)
   OHMHIP_CHECK(hipHostMalloc(&m->h_stage, bytes, hipHostMallocDefault));
   m->h_stage_bytes = bytes;
   return OHMHIP_OK;
+}
+
+/// Lay out the host store's records for this map's layer set (once) and make sure at least `records` are free.
+int reserveStoreRecords(ohmhip_map_t m, size_t records)
+{
+  ohmhip_map_s::HostStore &st = m->store;
+  if (st.record_bytes == 0)
+  {
+    const size_t rv = size_t(m->mc.region_voxels);
+    size_t at = 0;
+    for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+    {
+      st.layer_offset[l] = at;
+      if (m->layers[l])
+      {
+        at += (rv * kLayerBytes[l] + 255) & ~size_t(255);
+      }
+    }
+    st.mask_offset = at;
+    st.mask_bytes = ((rv + 31) / 32) * sizeof(uint32_t);
+    at += (st.mask_bytes + 255) & ~size_t(255);
+    st.record_bytes = at;
+  }
+  while (st.free_records.size() < records)
+  {
+    // slabs of about 64 MiB, at least the shortfall (one pinning call for a large reservation)
+    const size_t want = std::max<size_t>(records - st.free_records.size(), (size_t(64) << 20) / st.record_bytes + 1);
+    void *slab = nullptr;
+    if (hipHostMalloc(&slab, want * st.record_bytes, hipHostMallocDefault) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      return OHMHIP_ERR_CAPACITY;
+    }
+    st.slabs.push_back(slab);
+    for (size_t i = 0; i < want; ++i)
+    {
+      st.free_records.push_back(static_cast<char *>(slab) + i * st.record_bytes);
+    }
+    st.records_total += want;
+  }
+  return OHMHIP_OK;
+}
+
+char *takeStoreRecord(ohmhip_map_t m)
+{
+  if (m->store.free_records.empty() && reserveStoreRecords(m, 1) != OHMHIP_OK)
+  {
+    return nullptr;
+  }
+  char *rec = m->store.free_records.back();
+  m->store.free_records.pop_back();
+  return rec;
+}
+
+void releaseStoreRecord(ohmhip_map_t m, char *record)
+{
+  if (record)
+  {
+    m->store.free_records.push_back(record);
+  }
+}
+
+void freeHostStore(ohmhip_map_t m)
+{
+  for (void *slab : m->store.slabs)
+  {
+    (void)hipHostFree(slab);
+  }
+  m->store = ohmhip_map_s::HostStore{};
 }
 
 /// Highest key bit the sorts need: the slot field only uses log2(slots) + 1 bits (invalid keys are all ones).  `slots`:
@@ -1301,28 +1397,39 @@ int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
   ohmhip_map_s::RaySlot &sl = m->ray_slots[m->fill_slot];
   m->pending_rays = 0;
   m->pending_calls = 0;
-  OHMHIP_CHECK(sl.d_rays.ensure(n * 48, false, m->stream));
-  OHMHIP_CHECK(hipMemcpyAsync(sl.d_rays.ptr, slotRays(sl), n * 48, hipMemcpyHostToDevice, m->copy_stream));
+  const bool on_device = m->pending_on_device;
+  m->pending_on_device = false;
   const double *d_ts = nullptr;
   const float *d_int = nullptr;
-  if (m->pending_times)
-  {
-    OHMHIP_CHECK(sl.d_times.ensure(n * 8, false, m->stream));
-    OHMHIP_CHECK(hipMemcpyAsync(sl.d_times.ptr, slotTimes(sl), n * 8, hipMemcpyHostToDevice, m->copy_stream));
-    d_ts = static_cast<const double *>(sl.d_times.ptr);
-  }
-  if (m->pending_intens)
-  {
-    OHMHIP_CHECK(sl.d_intens.ensure(n * 4, false, m->stream));
-    OHMHIP_CHECK(hipMemcpyAsync(sl.d_intens.ptr, slotIntens(sl), n * 4, hipMemcpyHostToDevice, m->copy_stream));
-    d_int = static_cast<const float *>(sl.d_intens.ptr);
-  }
   const unsigned char *d_ff = nullptr;
-  if (m->pending_fflags)
+  if (on_device)
   {
-    OHMHIP_CHECK(sl.d_fflags.ensure(n, false, m->stream));
-    OHMHIP_CHECK(hipMemcpyAsync(sl.d_fflags.ptr, slotFilterFlags(sl), n, hipMemcpyHostToDevice, m->copy_stream));
-    d_ff = static_cast<const unsigned char *>(sl.d_fflags.ptr);
+    // (device-pointer calls: the copy stream has the device-to-device copies queued already)
+    d_ts = m->pending_times ? static_cast<const double *>(sl.d_times.ptr) : nullptr;
+    d_int = m->pending_intens ? static_cast<const float *>(sl.d_intens.ptr) : nullptr;
+  }
+  else
+  {
+    OHMHIP_CHECK(sl.d_rays.ensure(n * 48, false, m->stream));
+    OHMHIP_CHECK(hipMemcpyAsync(sl.d_rays.ptr, slotRays(sl), n * 48, hipMemcpyHostToDevice, m->copy_stream));
+    if (m->pending_times)
+    {
+      OHMHIP_CHECK(sl.d_times.ensure(n * 8, false, m->stream));
+      OHMHIP_CHECK(hipMemcpyAsync(sl.d_times.ptr, slotTimes(sl), n * 8, hipMemcpyHostToDevice, m->copy_stream));
+      d_ts = static_cast<const double *>(sl.d_times.ptr);
+    }
+    if (m->pending_intens)
+    {
+      OHMHIP_CHECK(sl.d_intens.ensure(n * 4, false, m->stream));
+      OHMHIP_CHECK(hipMemcpyAsync(sl.d_intens.ptr, slotIntens(sl), n * 4, hipMemcpyHostToDevice, m->copy_stream));
+      d_int = static_cast<const float *>(sl.d_intens.ptr);
+    }
+    if (m->pending_fflags)
+    {
+      OHMHIP_CHECK(sl.d_fflags.ensure(n, false, m->stream));
+      OHMHIP_CHECK(hipMemcpyAsync(sl.d_fflags.ptr, slotFilterFlags(sl), n, hipMemcpyHostToDevice, m->copy_stream));
+      d_ff = static_cast<const unsigned char *>(sl.d_fflags.ptr);
+    }
   }
   OHMHIP_CHECK(hipEventRecord(sl.uploaded, m->copy_stream));
   OHMHIP_CHECK(hipStreamWaitEvent(m->stream, sl.uploaded, 0));
@@ -1521,6 +1628,12 @@ try
     return fail(err);
   }
   std::memset(m->h_info, 0, 2 * sizeof(BatchInfo));
+  if ((err = hipHostMalloc(reinterpret_cast<void **>(&m->h_passed), 64, hipHostMallocMapped | hipHostMallocCoherent)) != 0 ||
+      (err = hipHostGetDevicePointer(reinterpret_cast<void **>(&m->h_passed_dev), m->h_passed, 0)) != 0 ||
+      (err = hipEventCreateWithFlags(&m->ev_passed, hipEventDisableTiming)) != 0)
+  {
+    return fail(err);
+  }
 
   uint32_t capacity = m->config.region_capacity;
   if (capacity == 0)
@@ -1645,10 +1758,19 @@ try
   {
     (void)hipHostFree(m->h_info);
   }
+  if (m->h_passed)
+  {
+    (void)hipHostFree(m->h_passed);
+  }
+  if (m->ev_passed)
+  {
+    (void)hipEventDestroy(m->ev_passed);
+  }
   if (m->h_stage)
   {
     (void)hipHostFree(m->h_stage);
   }
+  freeHostStore(m);
   for (auto &sl : m->ray_slots)
   {
     sl.d_rays.release();
@@ -1810,8 +1932,90 @@ try
   {
     *integrated = 0;
   }
-  OHMHIP_SETTLE(m);  // batches presented earlier through the host entry point come first
-  return integrateRaysDevice(m, d_rays, element_count, d_intensities, d_timestamps, ray_flags, integrated);
+  const size_t n_rays = element_count / 2;
+  // Small device-pointer batches (the f4 pipeline: GpuTransformSamples output presented 4096 rays at a time) are
+  // collected like small host batches: copied device to device behind the rays already waiting in the filling slot and
+  // run as one device batch once coalesce_min_rays have accumulated, or as soon as anything observes the map.  The
+  // call's own count of integrated rays comes from a one-workgroup pass of the map's ray filter over its staged rays.
+  const bool defer = m && d_rays && n_rays > 0 && m->coalesce_min_rays > 0 && n_rays < m->coalesce_min_rays &&
+                     !m->layers[OHMHIP_LID_TRAVERSAL] && !m->spill_enabled;
+  if (!defer)
+  {
+    OHMHIP_SETTLE(m);  // batches presented earlier come first
+    return integrateRaysDevice(m, d_rays, element_count, d_intensities, d_timestamps, ray_flags, integrated);
+  }
+  OHMHIP_CHECK(validateBatchRequest(m, ray_flags));
+  if (m->pending_rays &&
+      (!m->pending_on_device || m->pending_flags != ray_flags || m->pending_intens != (d_intensities != nullptr) ||
+       m->pending_times != (d_timestamps != nullptr) || m->pending_fflags))
+  {
+    OHMHIP_SETTLE(m);
+  }
+  ohmhip_map_s::RaySlot &sl = m->ray_slots[m->fill_slot];
+  if (m->pending_rays == 0)
+  {
+    if (sl.in_flight)
+    {
+      OHMHIP_CHECK(hipEventSynchronize(sl.done));  // the batch before last still owns this slot's buffers
+      sl.in_flight = false;
+    }
+    // room for every call up to the flush (DevBuf::ensure does not keep contents: sized before the first append)
+    const size_t cap = 2 * m->coalesce_min_rays;
+    OHMHIP_CHECK(sl.d_rays.ensure(cap * 48, false, m->stream));
+    if (d_timestamps)
+    {
+      OHMHIP_CHECK(sl.d_times.ensure(cap * 8, false, m->stream));
+    }
+    if (d_intensities)
+    {
+      OHMHIP_CHECK(sl.d_intens.ensure(cap * 4, false, m->stream));
+    }
+  }
+  hipStream_t cs = m->copy_stream;
+  double *staged = static_cast<double *>(sl.d_rays.ptr) + m->pending_rays * 6;
+  OHMHIP_CHECK(hipMemcpyAsync(staged, d_rays, n_rays * 48, hipMemcpyDeviceToDevice, cs));
+  if (d_timestamps)
+  {
+    OHMHIP_CHECK(hipMemcpyAsync(static_cast<double *>(sl.d_times.ptr) + m->pending_rays, d_timestamps, n_rays * 8,
+                                hipMemcpyDeviceToDevice, cs));
+    if (m->first_ray_time < 0)
+    {
+      double first = 0;  // OccupancyMap::updateFirstRayTime(*timestamps) (ohm/OccupancyMap.cpp:343-347)
+      OHMHIP_CHECK(hipMemcpyAsync(&first, d_timestamps, sizeof(double), hipMemcpyDeviceToHost, cs));
+      OHMHIP_CHECK(hipStreamSynchronize(cs));
+      m->first_ray_time = first;
+    }
+  }
+  if (d_intensities)
+  {
+    OHMHIP_CHECK(hipMemcpyAsync(static_cast<float *>(sl.d_intens.ptr) + m->pending_rays, d_intensities, n_rays * 4,
+                                hipMemcpyDeviceToDevice, cs));
+  }
+  if (integrated)
+  {
+    hipLaunchKernelGGL(k_count_passed, dim3(1), dim3(1024), 0, cs, m->mc, static_cast<const double *>(staged),
+                       uint32_t(n_rays), ray_flags, m->h_passed_dev);
+    OHMHIP_CHECK(hipEventRecord(m->ev_passed, cs));
+    OHMHIP_CHECK(hipEventSynchronize(m->ev_passed));  // (also: the caller's arrays have been copied)
+    *integrated = size_t(*m->h_passed) * 2;
+  }
+  m->pending_flags = ray_flags;
+  m->pending_fflags = false;
+  m->pending_intens = d_intensities != nullptr;
+  m->pending_times = d_timestamps != nullptr;
+  m->pending_on_device = true;
+  m->pending_rays += n_rays;
+  m->pending_calls += 1;
+  if (m->pending_rays < m->coalesce_min_rays)
+  {
+    return OHMHIP_OK;  // deferred
+  }
+  const int err = flushPendingRays(m);
+  if (err != OHMHIP_OK && integrated)
+  {
+    *integrated = 0;
+  }
+  return err;
 }
 OHMHIP_ABI_CATCH
 
@@ -1987,7 +2191,7 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
   // carried from ray to ray WITHIN one call (secondary_device.h: lastExitRange), so its batches are never merged.
   const bool coalesce = m->coalesce_min_rays > 0 && !m->layers[OHMHIP_LID_TRAVERSAL];
   if (m->pending_rays &&
-      (!coalesce || m->pending_flags != ray_flags || m->pending_intens != (intensities != nullptr) ||
+      (!coalesce || m->pending_on_device || m->pending_flags != ray_flags || m->pending_intens != (intensities != nullptr) ||
        m->pending_times != (timestamps != nullptr) || m->pending_fflags != (filter_flags != nullptr) ||
        m->pending_rays + n_rays >= (size_t(1) << (kHitRayBits - 1))))
   {
@@ -2287,6 +2491,12 @@ try
   m->spill_enabled = enable != 0;
   if (m->spill_enabled)
   {
+    // The host store is pinned memory: reserve what the pool can hold now (pinning is slow -- of the order of a second
+    // per few GB -- and belongs here, not into the first batch that overflows the pool).  It grows by slabs on demand.
+    const uint64_t per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
+    const uint64_t pool_regions =
+      m->memory_limit ? std::min<uint64_t>(m->memory_limit / per_region, kMaxRegionSlots) : m->slot_capacity;
+    OHMHIP_CHECK(reserveStoreRecords(m, size_t(std::min<uint64_t>(pool_regions, 8192))));
     // A collected batch touches the regions of all its calls at once -- more than any one of them, possibly more than
     // the limit holds: with spilling on every call runs as its own device batch (the caller may still set a threshold).
     m->coalesce_min_rays = 0;
@@ -2500,11 +2710,7 @@ try
       const auto it = m->spilled.find(packRegionKey(key[0], key[1], key[2]));
       if (it != m->spilled.end())
       {
-        if (it->second.layer[layer_id].size() != stride)
-        {
-          return OHMHIP_ERR_INTERNAL;
-        }
-        std::memcpy(dsts[k], it->second.layer[layer_id].data(), stride);
+        std::memcpy(dsts[k], it->second.record + m->store.layer_offset[layer_id], stride);
       }
       else
       {
@@ -2643,6 +2849,7 @@ try
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   OHMHIP_CHECK(readmitSpilledKeys(m, keys_xyz, count));  // (an upload edits the region where it lives: in the pool)
+  OHMHIP_CHECK(makeRoomForNamedRegions(m, keys_xyz, count));
   int err = refreshHostRegionTable(m);
   if (err)
   {
@@ -2667,8 +2874,7 @@ try
     const uint32_t old = m->slots_committed;
     if (total > m->slot_capacity)
     {
-      uint32_t cap = 0;
-      err = grownCapacity(m->slot_capacity, total, cap) ? allocPool(m, cap, old) : OHMHIP_ERR_CAPACITY;
+      err = growPoolForNamedRegions(m, total, old);
       if (err)
       {
         dropHostRegions(m, old);  // the device never saw them
@@ -2733,6 +2939,7 @@ try
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   OHMHIP_CHECK(readmitSpilledKeys(m, keys_xyz, count));
+  OHMHIP_CHECK(makeRoomForNamedRegions(m, keys_xyz, count));
   int err = refreshHostRegionTable(m);
   if (err)
   {
@@ -2758,8 +2965,7 @@ try
   {
     if (total > m->slot_capacity)
     {
-      uint32_t cap = 0;
-      err = grownCapacity(m->slot_capacity, total, cap) ? allocPool(m, cap, old) : OHMHIP_ERR_CAPACITY;
+      err = growPoolForNamedRegions(m, total, old);
       if (err)
       {
         dropHostRegions(m, old);  // the device never saw them
@@ -2794,7 +3000,13 @@ try
   size_t forgotten = 0;
   for (size_t i = 0; i < count && !m->spilled.empty(); ++i)
   {
-    forgotten += m->spilled.erase(packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]));
+    const auto it = m->spilled.find(packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]));
+    if (it != m->spilled.end())
+    {
+      releaseStoreRecord(m, it->second.record);
+      m->spilled.erase(it);
+      ++forgotten;
+    }
   }
   size_t resident_removed = 0;
   const int err = removeResidentRegions(m, keys_xyz, count, &resident_removed);
@@ -2935,7 +3147,7 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
 /// Spill to host, first half: copy the least recently used resident regions into the host store and drop them from the
 /// pool, so that at least `want_free` slots become free (a quarter of the pool at a time, so evictions are rare).
 /// Regions the current batch attempt touched carry the newest stamp (k_plan) and go last.
-int evictColdRegions(ohmhip_map_t m, uint32_t want_free)
+int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
 {
   hipStream_t s = m->stream;
   OHMHIP_CHECK(hipStreamSynchronize(s));
@@ -2945,7 +3157,7 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free)
   {
     return OHMHIP_ERR_CAPACITY;  // nothing to evict / replica-merge maps keep a base copy per region: not spilled
   }
-  const uint32_t k = std::min(n, std::max(want_free, n / 4u));
+  const uint32_t k = std::min(std::min(n, std::max(want_free, n / 4u)), std::max(want_free, max_evict));
   std::vector<uint32_t> stamps(n), dirty(n);
   OHMHIP_CHECK(hipMemcpy(stamps.data(), m->d_last_use, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
   OHMHIP_CHECK(hipMemcpy(dirty.data(), m->d_dirty, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
@@ -2956,94 +3168,229 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free)
   }
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return stamps[a] < stamps[b]; });
   const size_t rv = size_t(m->mc.region_voxels);
-  const size_t mask_words = (rv + 31) / 32;
   const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;  // (transient in occupancy mode: empty between batches)
-  // The victims' content: every layer through the pinned, double-buffered read path (ohmhip_map_read_regions -- the
-  // entries join the store only afterwards, so that path still sees them as resident), the mask rows out of one copy
-  // of the whole mask.
+  // The victims' content goes straight from the pool into pinned store records: one asynchronous copy per region and
+  // layer on the copy stream, all of them queued before the one wait (the compute stream is idle here -- it was drained
+  // above -- so the copies have the device's copy engines and the PCIe link to themselves).
+  OHMHIP_CHECK(reserveStoreRecords(m, k));
   std::vector<int16_t> victim_keys(3 * size_t(k));
   std::vector<ohmhip_map_s::SpilledRegion> content(k);
+  const ohmhip_map_s::HostStore &st = m->store;
+  auto giveBack = [&]() {
+    for (auto &c : content)
+    {
+      releaseStoreRecord(m, c.record);
+      c.record = nullptr;
+    }
+  };
   for (uint32_t v = 0; v < k; ++v)
   {
-    unpackRegionKey(m->slot_keys_host[order[v]], &victim_keys[3 * size_t(v)]);
-    content[v].dirty = dirty[order[v]];
-  }
-  std::vector<void *> dsts(k);
-  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
-  {
-    if (!m->layers[l])
+    const uint32_t slot = order[v];
+    unpackRegionKey(m->slot_keys_host[slot], &victim_keys[3 * size_t(v)]);
+    content[v].dirty = dirty[slot];
+    content[v].record = takeStoreRecord(m);
+    if (!content[v].record)
     {
-      continue;
+      giveBack();
+      return OHMHIP_ERR_CAPACITY;
     }
-    const size_t stride = rv * kLayerBytes[l];
-    for (uint32_t v = 0; v < k; ++v)
+    int err = OHMHIP_OK;
+    for (int l = 0; l < OHMHIP_LID_COUNT && !err; ++l)
     {
-      content[v].layer[l].resize(stride);
-      dsts[v] = content[v].layer[l].data();
+      if (m->layers[l])
+      {
+        const size_t stride = rv * kLayerBytes[l];
+        err = int(hipMemcpyAsync(content[v].record + st.layer_offset[l],
+                                 static_cast<const char *>(m->layers[l]) + stride * slot, stride, hipMemcpyDeviceToHost,
+                                 m->copy_stream));
+      }
     }
-    OHMHIP_CHECK(ohmhip_map_read_regions(m, l, victim_keys.data(), k, dsts.data()));
-  }
-  if (keep_mask)
-  {
-    std::vector<uint32_t> all_rows(mask_words * n);
-    OHMHIP_CHECK(hipMemcpy(all_rows.data(), m->d_hit_mask, sizeof(uint32_t) * all_rows.size(), hipMemcpyDeviceToHost));
-    for (uint32_t v = 0; v < k; ++v)
+    if (!err)
     {
-      content[v].mask_row.assign(all_rows.begin() + mask_words * order[v], all_rows.begin() + mask_words * (order[v] + 1));
+      if (keep_mask)
+      {
+        err = int(hipMemcpyAsync(content[v].record + st.mask_offset,
+                                 reinterpret_cast<const char *>(m->d_hit_mask) + st.mask_bytes * slot, st.mask_bytes,
+                                 hipMemcpyDeviceToHost, m->copy_stream));
+      }
+      else
+      {
+        std::memset(content[v].record + st.mask_offset, 0, st.mask_bytes);
+      }
+    }
+    if (err)
+    {
+      (void)hipStreamSynchronize(m->copy_stream);
+      giveBack();
+      return err;
+    }
+  }
+  {
+    const int err = int(hipStreamSynchronize(m->copy_stream));
+    if (err)
+    {
+      giveBack();
+      return err;
     }
   }
   size_t removed = 0;
-  OHMHIP_CHECK(removeResidentRegions(m, victim_keys.data(), k, &removed));
+  {
+    const int err = removeResidentRegions(m, victim_keys.data(), k, &removed);
+    if (err)
+    {
+      giveBack();  // the regions are still resident: nothing is lost
+      return err;
+    }
+  }
   for (uint32_t v = 0; v < k; ++v)
   {
     m->spilled[packRegionKey(victim_keys[3 * size_t(v)], victim_keys[3 * size_t(v) + 1], victim_keys[3 * size_t(v) + 2])] =
-      std::move(content[v]);
+      content[v];
   }
   m->evictions += removed;
   return OHMHIP_OK;
 }
 
+/// Pool growth on behalf of regions created by name (ohmhip_map_write_regions / ohmhip_map_ensure_regions): the same
+/// budget rules as a batch's growth (rollbackAndGrow) -- the map's memory limit and the device's free memory.
+int growPoolForNamedRegions(ohmhip_map_t m, uint32_t total, uint32_t keep)
+{
+  uint32_t cap = 0;
+  if (!grownCapacity(m->slot_capacity, total, cap))
+  {
+    return OHMHIP_ERR_CAPACITY;
+  }
+  const size_t per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
+  if (m->memory_limit)
+  {
+    const uint64_t allowed = m->memory_limit / per_region;
+    if (allowed < total)
+    {
+      return OHMHIP_ERR_CAPACITY;
+    }
+    cap = uint32_t(std::min<uint64_t>(cap, allowed));
+  }
+  size_t free_b = 0, total_b = 0;
+  OHMHIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  if (per_region * size_t(cap) > free_b)
+  {
+    return OHMHIP_ERR_CAPACITY;
+  }
+  ++m->cache_full;
+  return allocPool(m, cap, keep);
+}
+
+/// Before regions are created by name under a memory limit: if the named keys that are not resident yet would push the
+/// pool past the limit, the least recently used OTHER regions go to the host store first (spill to host) -- or the
+/// call fails with OHMHIP_ERR_CAPACITY and changes nothing.
+int makeRoomForNamedRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count)
+{
+  if (!m->memory_limit || count == 0)
+  {
+    return OHMHIP_OK;
+  }
+  OHMHIP_CHECK(refreshHostRegionTable(m));
+  const uint64_t per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
+  const uint64_t allowed = std::min<uint64_t>(m->memory_limit / per_region, kMaxRegionSlots);
+  std::vector<uint32_t> named_resident;
+  std::vector<uint64_t> fresh;
+  for (size_t i = 0; i < count; ++i)
+  {
+    const uint64_t key = packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]);
+    const auto it = m->region_slots.find(key);
+    if (it != m->region_slots.end())
+    {
+      named_resident.push_back(it->second);
+    }
+    else if (std::find(fresh.begin(), fresh.end(), key) == fresh.end())
+    {
+      fresh.push_back(key);
+    }
+  }
+  const uint64_t wanted = uint64_t(m->slots_committed) + fresh.size();
+  if (wanted <= allowed)
+  {
+    return OHMHIP_OK;
+  }
+  const uint64_t need = wanted - allowed;
+  std::sort(named_resident.begin(), named_resident.end());
+  named_resident.erase(std::unique(named_resident.begin(), named_resident.end()), named_resident.end());
+  const uint64_t evictable = uint64_t(m->slots_committed) - named_resident.size();
+  if (!m->spill_enabled || m->d_merge_base || need > evictable)
+  {
+    return OHMHIP_ERR_CAPACITY;
+  }
+  if (!named_resident.empty())
+  {
+    // the named regions are in use now: newest stamp, so the eviction below takes others
+    OHMHIP_CHECK(m->merge_slots.ensure(sizeof(uint32_t) * named_resident.size(), false, m->stream));
+    OHMHIP_CHECK(hipMemcpy(m->merge_slots.ptr, named_resident.data(), sizeof(uint32_t) * named_resident.size(),
+                           hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_at_u32, dim3(64), dim3(256), 0, m->stream, m->d_last_use,
+                       static_cast<const uint32_t *>(m->merge_slots.ptr), named_resident.size(),
+                       uint32_t(m->batch_seq + 1u));
+    OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  }
+  return evictColdRegions(m, uint32_t(need), uint32_t(evictable));
+}
+
 namespace
 {
-/// Put a stored region's content into pool slot `slot` (which holds a fresh, unobserved region of the same key).
-int uploadSpilledRegion(ohmhip_map_t m, uint32_t slot, const ohmhip_map_s::SpilledRegion &store)
+/// Queue the copies that put stored regions back into pool slots (each slot holds a fresh, unobserved region of the
+/// same key): layers and mask rows straight from the pinned records on the copy stream, the dirty bits OR-ed in by one
+/// small kernel per bit pattern behind them.  Returns with everything QUEUED; the caller waits for the copy stream.
+int queueReadmission(ohmhip_map_t m, const std::vector<std::pair<uint32_t, ohmhip_map_s::SpilledRegion>> &back)
 {
   const size_t rv = size_t(m->mc.region_voxels);
-  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  const ohmhip_map_s::HostStore &st = m->store;
+  const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;
+  std::vector<uint32_t> dirty_slots[4];
+  for (const auto &entry : back)
   {
-    if (m->layers[l] && !store.layer[l].empty())
+    const uint32_t slot = entry.first;
+    const char *record = entry.second.record;
+    for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
     {
-      const size_t stride = rv * kLayerBytes[l];
-      OHMHIP_CHECK(hipMemcpy(static_cast<char *>(m->layers[l]) + stride * slot, store.layer[l].data(), stride,
-                             hipMemcpyHostToDevice));
+      if (m->layers[l])
+      {
+        const size_t stride = rv * kLayerBytes[l];
+        OHMHIP_CHECK(hipMemcpyAsync(static_cast<char *>(m->layers[l]) + stride * slot, record + st.layer_offset[l], stride,
+                                    hipMemcpyHostToDevice, m->copy_stream));
+      }
+    }
+    if (keep_mask)
+    {
+      OHMHIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(m->d_hit_mask) + st.mask_bytes * slot, record + st.mask_offset,
+                                  st.mask_bytes, hipMemcpyHostToDevice, m->copy_stream));
+    }
+    dirty_slots[entry.second.dirty & (kDirtySync | kDirtyMerge)].push_back(slot);
+  }
+  // (k_plan may be OR-ing this batch's bits into the same words: atomic ORs, from a persistent index scratch)
+  size_t n_index = dirty_slots[1].size() + dirty_slots[2].size() + dirty_slots[3].size();
+  if (n_index)
+  {
+    OHMHIP_CHECK(m->merge_slots.ensure(sizeof(uint32_t) * n_index, false, m->copy_stream));
+    uint32_t *d_index = static_cast<uint32_t *>(m->merge_slots.ptr);
+    for (uint32_t bits = 1; bits < 4; ++bits)
+    {
+      if (dirty_slots[bits].empty())
+      {
+        continue;
+      }
+      OHMHIP_CHECK(hipMemcpy(d_index, dirty_slots[bits].data(), sizeof(uint32_t) * dirty_slots[bits].size(),
+                             hipMemcpyHostToDevice));  // (blocking: the vector goes out of scope; a few hundred bytes)
+      hipLaunchKernelGGL(k_or_at_u32, dim3(64), dim3(256), 0, m->copy_stream, m->d_dirty, d_index,
+                         dirty_slots[bits].size(), bits);
+      d_index += dirty_slots[bits].size();
     }
   }
-  if (!store.mask_row.empty())
-  {
-    OHMHIP_CHECK(hipMemcpy(m->d_hit_mask + store.mask_row.size() * slot, store.mask_row.data(),
-                           sizeof(uint32_t) * store.mask_row.size(), hipMemcpyHostToDevice));
-  }
-  if (store.dirty)
-  {
-    // (k_plan may be OR-ing this batch's bits into the same word: an atomic OR from a one-thread kernel)
-    uint32_t *d_index = nullptr;
-    OHMHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_index), sizeof(uint32_t)));
-    int err = int(hipMemcpy(d_index, &slot, sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (!err)
-    {
-      hipLaunchKernelGGL(k_or_at_u32, dim3(1), dim3(1), 0, m->stream, m->d_dirty, d_index, size_t(1),
-                         store.dirty & (kDirtySync | kDirtyMerge));
-      err = int(hipStreamSynchronize(m->stream));
-    }
-    (void)hipFree(d_index);
-    OHMHIP_CHECK(err);
-  }
-  return OHMHIP_OK;
+  return hipGetLastError();
 }
 }  // namespace
 
 /// Spill to host, second half: a batch's set-up pass has just created the slots [first_slot, end_slot); those whose key
-/// is in the host store get their content back before anything reads or updates the layers.
+/// is in the host store get their content back before anything reads or updates the layers.  Entries leave the store
+/// only once their content is safely back in the pool (a failure on the way must not lose a region).
 int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot)
 {
   if (m->spilled.empty() || end_slot <= first_slot)
@@ -3059,82 +3406,28 @@ int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot)
     const auto it = m->spilled.find(keys[i]);
     if (it != m->spilled.end())
     {
-      back.emplace_back(first_slot + uint32_t(i), std::move(it->second));
-      m->spilled.erase(it);
+      back.emplace_back(first_slot + uint32_t(i), it->second);
     }
   }
   if (back.empty())
   {
     return OHMHIP_OK;
   }
-  // Layers: through the pinned staging block in bursts, runs of consecutive slots as one copy.
-  const size_t rv = size_t(m->mc.region_voxels);
-  const size_t burst = 64;
-  for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+  int err = queueReadmission(m, back);
+  const int sync_err = int(hipStreamSynchronize(m->copy_stream));
+  err = err ? err : sync_err;
+  if (err)
   {
-    if (!m->layers[l])
-    {
-      continue;
-    }
-    const size_t stride = rv * kLayerBytes[l];
-    OHMHIP_CHECK(ensureStage(m, std::max(m->h_stage_bytes, burst * stride)));
-    char *stage = static_cast<char *>(m->h_stage);
-    for (size_t base = 0; base < back.size(); base += burst)
-    {
-      const size_t n = std::min(burst, back.size() - base);
-      for (size_t i = 0; i < n; ++i)
-      {
-        if (back[base + i].second.layer[l].size() != stride)
-        {
-          return OHMHIP_ERR_INTERNAL;
-        }
-        std::memcpy(stage + i * stride, back[base + i].second.layer[l].data(), stride);
-      }
-      for (size_t i = 0; i < n;)
-      {
-        size_t run = 1;
-        while (i + run < n && back[base + i + run].first == back[base + i].first + uint32_t(run))
-        {
-          ++run;
-        }
-        OHMHIP_CHECK(hipMemcpyAsync(static_cast<char *>(m->layers[l]) + stride * back[base + i].first, stage + i * stride,
-                                    run * stride, hipMemcpyHostToDevice, m->copy_stream));
-        i += run;
-      }
-      OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));  // (the staging block is reused by the next burst)
-    }
+    return err;  // the store still holds every region; the batch fails and is rolled back by the caller
   }
-  // Mask rows and dirty bits: small, per region.
-  std::vector<uint32_t> dirty_slots[4];
-  for (const auto &entry : back)
+  for (size_t i = 0; i < keys.size(); ++i)
   {
-    const ohmhip_map_s::SpilledRegion &store = entry.second;
-    if (!store.mask_row.empty())
+    const auto it = m->spilled.find(keys[i]);
+    if (it != m->spilled.end())
     {
-      OHMHIP_CHECK(hipMemcpy(m->d_hit_mask + store.mask_row.size() * entry.first, store.mask_row.data(),
-                             sizeof(uint32_t) * store.mask_row.size(), hipMemcpyHostToDevice));
+      releaseStoreRecord(m, it->second.record);
+      m->spilled.erase(it);
     }
-    dirty_slots[store.dirty & (kDirtySync | kDirtyMerge)].push_back(entry.first);
-  }
-  for (uint32_t bits = 1; bits < 4; ++bits)
-  {
-    if (dirty_slots[bits].empty())
-    {
-      continue;
-    }
-    // (k_plan may be OR-ing this batch's bits into the same words: atomic ORs)
-    uint32_t *d_index = nullptr;
-    OHMHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_index), sizeof(uint32_t) * dirty_slots[bits].size()));
-    int err = int(hipMemcpy(d_index, dirty_slots[bits].data(), sizeof(uint32_t) * dirty_slots[bits].size(),
-                            hipMemcpyHostToDevice));
-    if (!err)
-    {
-      hipLaunchKernelGGL(k_or_at_u32, dim3(64), dim3(256), 0, m->stream, m->d_dirty, d_index,
-                         dirty_slots[bits].size(), bits);
-      err = int(hipStreamSynchronize(m->stream));
-    }
-    (void)hipFree(d_index);
-    OHMHIP_CHECK(err);
   }
   m->readmissions += back.size();
   return OHMHIP_OK;
@@ -3149,35 +3442,73 @@ int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count)
     return OHMHIP_OK;
   }
   std::vector<int16_t> wanted;
+  std::vector<uint64_t> wanted_packed;
   for (size_t i = 0; i < count; ++i)
   {
-    if (m->spilled.count(packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2])))
+    const uint64_t packed = packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]);
+    if (m->spilled.count(packed) && std::find(wanted_packed.begin(), wanted_packed.end(), packed) == wanted_packed.end())
     {
       wanted.insert(wanted.end(), keys_xyz + 3 * i, keys_xyz + 3 * i + 3);
+      wanted_packed.push_back(packed);
     }
   }
   if (wanted.empty())
   {
     return OHMHIP_OK;
   }
-  // Take the entries out of the store first: ensure_regions would otherwise come straight back here.
-  std::vector<ohmhip_map_s::SpilledRegion> content(wanted.size() / 3);
+  // Take the entries out of the store while ensure_regions runs (it would otherwise come straight back here); they go
+  // back in if anything fails before their content is in the pool.
+  std::vector<ohmhip_map_s::SpilledRegion> content(wanted_packed.size());
   for (size_t i = 0; i < content.size(); ++i)
   {
-    const auto it = m->spilled.find(packRegionKey(wanted[3 * i], wanted[3 * i + 1], wanted[3 * i + 2]));
-    if (it != m->spilled.end())  // (a key listed twice)
+    const auto it = m->spilled.find(wanted_packed[i]);
+    content[i] = it->second;
+    m->spilled.erase(it);
+  }
+  auto putBack = [&]() {
+    for (size_t i = 0; i < content.size(); ++i)
     {
-      content[i] = std::move(it->second);
-      m->spilled.erase(it);
+      m->spilled[wanted_packed[i]] = content[i];
     }
-  }
+  };
   std::vector<uint32_t> slots(content.size());
-  OHMHIP_CHECK(ohmhip_map_ensure_regions(m, wanted.data(), content.size(), slots.data()));
+  int err = ohmhip_map_ensure_regions(m, wanted.data(), content.size(), slots.data());
+  if (err)
+  {
+    // ensure_regions created some of the regions fresh before it failed: those must not shadow the stored content
+    size_t removed = 0;
+    (void)removeResidentRegions(m, wanted.data(), content.size(), &removed);
+    putBack();
+    return err;
+  }
+  std::vector<std::pair<uint32_t, ohmhip_map_s::SpilledRegion>> back;
   for (size_t i = 0; i < content.size(); ++i)
   {
-    OHMHIP_CHECK(uploadSpilledRegion(m, slots[i], content[i]));
-    ++m->readmissions;
+    back.emplace_back(slots[i], content[i]);
   }
+  err = queueReadmission(m, back);
+  const int sync_err = int(hipStreamSynchronize(m->copy_stream));
+  err = err ? err : sync_err;
+  if (err)
+  {
+    size_t removed = 0;
+    (void)removeResidentRegions(m, wanted.data(), content.size(), &removed);
+    putBack();
+    return err;
+  }
+  // re-admitted by name: they are in use NOW -- stamp them so the next eviction does not pick them first
+  {
+    OHMHIP_CHECK(m->merge_slots.ensure(sizeof(uint32_t) * slots.size(), false, m->stream));
+    OHMHIP_CHECK(hipMemcpy(m->merge_slots.ptr, slots.data(), sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_at_u32, dim3(64), dim3(256), 0, m->stream, m->d_last_use,
+                       static_cast<const uint32_t *>(m->merge_slots.ptr), slots.size(), uint32_t(m->batch_seq + 1u));
+    OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  }
+  for (auto &c : content)
+  {
+    releaseStoreRecord(m, c.record);
+  }
+  m->readmissions += content.size();
   return OHMHIP_OK;
 }
 
@@ -3308,6 +3639,10 @@ try
   m->slots_committed = 0;
   m->region_slots.clear();
   m->slot_keys_host.clear();
+  for (auto &entry : m->spilled)
+  {
+    releaseStoreRecord(m, entry.second.record);
+  }
   m->spilled.clear();
   return allocPool(m, m->slot_capacity, 0);
 }

@@ -156,3 +156,55 @@ def test_deferred_calls_report_their_own_filter_count(gpu):
     assert gm.stats()["rays_integrated"] * 2 == total  # the three calls ran as one device batch
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
+
+
+def test_small_device_pointer_batches_are_collected_and_report_their_own_counts(gpu):
+    """Device-pointer calls of 4096 rays (the f4 pipeline: GpuTransformSamples output presented as the reference tools
+    present host rays) are collected on the device like small host batches: copied behind the rays already waiting and run
+    as one device batch per 65 536 rays.  Every call still returns ITS count (one-workgroup filter pass over its staged
+    rays), the caller may overwrite its array once the call has returned a count, host and device calls keep their order,
+    and the result is the CPU oracle's for the same sequence of calls."""
+    import ctypes as C
+    from ohm_amd import _lib as L
+    layers = ("occupancy", "mean")
+    map_ = OccupancyMap(0.1, layers=layers)
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    rays = synth.rays_c1(n=40 * 4096, max_range=11.0, seed=77)
+    bad = [5, 4096 + 17, 9 * 4096 + 4000]
+    for b in bad:
+        rays[2 * b + 1] = np.nan  # the default filter rejects these: one per affected call
+    scratch = L._vp()
+    L.check(L.lib.ohmhip_buffer_create(C.byref(scratch), 2 * 4096 * 24, 3))
+    ptr = L._vp()
+    L.check(L.lib.ohmhip_buffer_ptr(scratch, C.byref(ptr)))
+    device_batches = 0
+    last_seen = None
+    for call in range(40):
+        part = np.ascontiguousarray(rays[2 * 4096 * call:2 * 4096 * (call + 1)])
+        if call == 20:
+            # a host call in the middle: what waits on the device runs first
+            expect = part.shape[0] - 2 * sum(1 for b in bad if b // 4096 == call)
+            assert gm.integrateRays(part) == expect
+        else:
+            # the SAME device array is overwritten for every call: the library has taken its copy when the call returns
+            L.check(L.lib.ohmhip_buffer_write(scratch, part.ctypes.data, part.nbytes, 0, None, None, None))
+            expect = part.shape[0] - 2 * sum(1 for b in bad if b // 4096 == call)
+            assert gm.integrateRaysDevice(ptr, part.shape[0]) == expect, call
+        om.integrate_occupancy(part)
+    st = gm.stats()  # observing the map flushes what is pending
+    assert st["rays_in"] in (16 * 4096, 3 * 4096), st["rays_in"]  # 20 calls -> 16 + 4 (flushed by the host call); 19 -> 16 + 3
+    gm.syncVoxels()
+    L.lib.ohmhip_buffer_destroy(scratch)
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
+    # one device batch per call when coalescing is off
+    gm2 = GpuMap(OccupancyMap(0.1, layers=("occupancy",)))
+    gm2.setBatchCoalescing(0)
+    buf = L._vp()
+    L.check(L.lib.ohmhip_buffer_create(C.byref(buf), 2 * 4096 * 24, 3))
+    L.check(L.lib.ohmhip_buffer_write(buf, rays.ctypes.data, 2 * 4096 * 24, 0, None, None, None))
+    p2 = L._vp()
+    L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(p2)))
+    assert gm2.integrateRaysDevice(p2, 2 * 4096) == 2 * 4096 - 2
+    assert gm2.stats()["rays_in"] == 4096
+    L.lib.ohmhip_buffer_destroy(buf)
