@@ -437,7 +437,8 @@ def main():
                 "regions_in_host_store": int(cs["regions_spilled"]), "evictions": int(cs["evictions"]),
                 "readmissions": int(cs["readmissions"]),
                 "note": "first pass over a fresh map: includes pool growth to the limit and every eviction / "
-                        "re-admission copy (pinned staging, synchronous with the batch)"}
+                        "re-admission (pinned host store; one device kernel per eviction / re-admission moves all "
+                        "regions over PCIe, synchronous with the batch)"}
             L.lib.ohmhip_buffer_destroy(b4)
             g4.close()
             del r4

@@ -9,6 +9,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -128,6 +129,7 @@ struct ohmhip_map_s
   /// Traversal layer only: per-voxel fixed-point sum of a batch's ray lengths (zero between batches).
   unsigned long long *d_traversal_acc = nullptr;
   DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;
+  DevBuf copy_jobs;  ///< job list of k_copy_jobs (spill to host, compaction)
   DevBuf stop_a, stop_b;  ///< kRfStopOnFirstOccupied: per-ray stop positions (current / candidate)
   uint32_t *d_event_count = nullptr;  ///< per parity: [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count, [3] stop iteration flag
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
@@ -209,6 +211,7 @@ struct ohmhip_map_s
   std::unordered_map<uint64_t, SpilledRegion> spilled;
   bool spill_enabled = false;
   uint64_t evictions = 0, readmissions = 0;
+  double spill_ms[6] = { 0, 0, 0, 0, 0, 0 };  ///< OHMHIP_DEBUG_FLAGS & 512: evict select / copy / compact, readmit copy, failed attempts, store growth
 };
 
 // Defined further down (they use the region read / remove machinery of the C ABI section).
@@ -741,6 +744,20 @@ void freeHostStore(ohmhip_map_t m)
     (void)hipHostFree(slab);
   }
   m->store = ohmhip_map_s::HostStore{};
+}
+
+/// Run a list of byte copies as one kernel on `stream` (k_copy_jobs); returns with the launch queued.
+int launchCopyJobs(ohmhip_map_t m, const std::vector<CopyJob> &jobs, hipStream_t stream)
+{
+  if (jobs.empty())
+  {
+    return OHMHIP_OK;
+  }
+  OHMHIP_CHECK(m->copy_jobs.ensure(sizeof(CopyJob) * jobs.size(), false, stream));
+  OHMHIP_CHECK(hipMemcpy(m->copy_jobs.ptr, jobs.data(), sizeof(CopyJob) * jobs.size(), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_copy_jobs, dim3(uint32_t(jobs.size()) * kCopyBlocksPerJob), dim3(256), 0, stream,
+                     static_cast<const CopyJob *>(m->copy_jobs.ptr), uint32_t(jobs.size()));
+  return hipGetLastError();
 }
 
 /// Highest key bit the sorts need: the slot field only uses log2(slots) + 1 bits (invalid keys are all ones).  `slots`:
@@ -1770,6 +1787,14 @@ try
   {
     (void)hipHostFree(m->h_stage);
   }
+  if (m->debug_flags & 512u)
+  {
+    std::fprintf(stderr,
+                 "[ohmhip spill] evictions %llu readmissions %llu | ms: select %.1f copy-out %.1f compact %.1f copy-in %.1f "
+                 "store-growth %.1f\n",
+                 (unsigned long long)m->evictions, (unsigned long long)m->readmissions, m->spill_ms[0], m->spill_ms[1],
+                 m->spill_ms[2], m->spill_ms[3], m->spill_ms[5]);
+  }
   freeHostStore(m);
   for (auto &sl : m->ray_slots)
   {
@@ -2496,7 +2521,8 @@ try
     const uint64_t per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
     const uint64_t pool_regions =
       m->memory_limit ? std::min<uint64_t>(m->memory_limit / per_region, kMaxRegionSlots) : m->slot_capacity;
-    OHMHIP_CHECK(reserveStoreRecords(m, size_t(std::min<uint64_t>(pool_regions, 8192))));
+    // (what the pool holds + the quarter an eviction moves out while as much again may still be waiting in the store)
+    OHMHIP_CHECK(reserveStoreRecords(m, size_t(std::min<uint64_t>(pool_regions + pool_regions / 2 + 64, 16384))));
     // A collected batch touches the regions of all its calls at once -- more than any one of them, possibly more than
     // the limit holds: with spilling on every call runs as its own device batch (the caller may still set a threshold).
     m->coalesce_min_rays = 0;
@@ -3060,6 +3086,7 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
   const size_t rv = size_t(m->mc.region_voxels);
   const size_t mask_row = ((rv + 31) / 32) * sizeof(uint32_t);
   uint32_t src = new_n;
+  std::vector<CopyJob> jobs;
   for (uint32_t dst = 0; dst < new_n; ++dst)
   {
     if (!drop[dst])
@@ -3070,29 +3097,31 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
     {
       ++src;
     }
+    // (source slots lie in the tail [new_n, n), destinations below new_n: no job reads what another writes)
     for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
     {
       if (m->layers[l])
       {
         const size_t stride = rv * kLayerBytes[l];
-        OHMHIP_CHECK(hipMemcpyAsync(static_cast<char *>(m->layers[l]) + stride * dst,
-                                    static_cast<const char *>(m->layers[l]) + stride * src, stride,
-                                    hipMemcpyDeviceToDevice, s));
+        jobs.push_back(CopyJob{ static_cast<const char *>(m->layers[l]) + stride * src,
+                                static_cast<char *>(m->layers[l]) + stride * dst, stride });
       }
     }
-    OHMHIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(m->d_hit_mask) + mask_row * dst,
-                                reinterpret_cast<const char *>(m->d_hit_mask) + mask_row * src, mask_row,
-                                hipMemcpyDeviceToDevice, s));
-    OHMHIP_CHECK(hipMemcpyAsync(m->d_dirty + dst, m->d_dirty + src, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    OHMHIP_CHECK(hipMemcpyAsync(m->d_last_use + dst, m->d_last_use + src, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_hit_mask) + mask_row * src,
+                            reinterpret_cast<char *>(m->d_hit_mask) + mask_row * dst, mask_row });
+    jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_dirty + src), reinterpret_cast<char *>(m->d_dirty + dst),
+                            sizeof(uint32_t) });
+    jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_last_use + src),
+                            reinterpret_cast<char *>(m->d_last_use + dst), sizeof(uint32_t) });
     if (m->d_merge_base)
     {
-      OHMHIP_CHECK(hipMemcpyAsync(m->d_merge_base + rv * dst, m->d_merge_base + rv * src, sizeof(float) * rv,
-                                  hipMemcpyDeviceToDevice, s));
+      jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_merge_base + rv * src),
+                              reinterpret_cast<char *>(m->d_merge_base + rv * dst), sizeof(float) * rv });
     }
     m->slot_keys_host[dst] = m->slot_keys_host[src];
     ++src;
   }
+  OHMHIP_CHECK(launchCopyJobs(m, jobs, s));
   for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
   {
     if (!m->layers[l])
@@ -3149,6 +3178,13 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
 /// Regions the current batch attempt touched carry the newest stamp (k_plan) and go last.
 int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
 {
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&](int slot, std::chrono::steady_clock::time_point &from) {
+    const auto now = std::chrono::steady_clock::now();
+    m->spill_ms[slot] += std::chrono::duration<double, std::milli>(now - from).count();
+    from = now;
+  };
+  auto t_mark = t_begin;
   hipStream_t s = m->stream;
   OHMHIP_CHECK(hipStreamSynchronize(s));
   OHMHIP_CHECK(refreshHostRegionTable(m));
@@ -3169,10 +3205,11 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return stamps[a] < stamps[b]; });
   const size_t rv = size_t(m->mc.region_voxels);
   const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;  // (transient in occupancy mode: empty between batches)
-  // The victims' content goes straight from the pool into pinned store records: one asynchronous copy per region and
-  // layer on the copy stream, all of them queued before the one wait (the compute stream is idle here -- it was drained
-  // above -- so the copies have the device's copy engines and the PCIe link to themselves).
+  // The victims' content goes straight from the pool into pinned store records, all regions and layers by ONE kernel
+  // that writes the mapped host memory itself (k_copy_jobs); the compute stream is idle here -- it was drained above.
+  lap(0, t_mark);
   OHMHIP_CHECK(reserveStoreRecords(m, k));
+  lap(5, t_mark);
   std::vector<int16_t> victim_keys(3 * size_t(k));
   std::vector<ohmhip_map_s::SpilledRegion> content(k);
   const ohmhip_map_s::HostStore &st = m->store;
@@ -3183,6 +3220,8 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
       c.record = nullptr;
     }
   };
+  std::vector<CopyJob> jobs;
+  jobs.reserve(size_t(k) * 2);
   for (uint32_t v = 0; v < k; ++v)
   {
     const uint32_t slot = order[v];
@@ -3194,30 +3233,27 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
       giveBack();
       return OHMHIP_ERR_CAPACITY;
     }
-    int err = OHMHIP_OK;
-    for (int l = 0; l < OHMHIP_LID_COUNT && !err; ++l)
+    for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
     {
       if (m->layers[l])
       {
         const size_t stride = rv * kLayerBytes[l];
-        err = int(hipMemcpyAsync(content[v].record + st.layer_offset[l],
-                                 static_cast<const char *>(m->layers[l]) + stride * slot, stride, hipMemcpyDeviceToHost,
-                                 m->copy_stream));
+        jobs.push_back(CopyJob{ static_cast<const char *>(m->layers[l]) + stride * slot,
+                                content[v].record + st.layer_offset[l], stride });
       }
     }
-    if (!err)
+    if (keep_mask)
     {
-      if (keep_mask)
-      {
-        err = int(hipMemcpyAsync(content[v].record + st.mask_offset,
-                                 reinterpret_cast<const char *>(m->d_hit_mask) + st.mask_bytes * slot, st.mask_bytes,
-                                 hipMemcpyDeviceToHost, m->copy_stream));
-      }
-      else
-      {
-        std::memset(content[v].record + st.mask_offset, 0, st.mask_bytes);
-      }
+      jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_hit_mask) + st.mask_bytes * slot,
+                              content[v].record + st.mask_offset, st.mask_bytes });
     }
+    else
+    {
+      std::memset(content[v].record + st.mask_offset, 0, st.mask_bytes);
+    }
+  }
+  {
+    const int err = launchCopyJobs(m, jobs, m->copy_stream);
     if (err)
     {
       (void)hipStreamSynchronize(m->copy_stream);
@@ -3233,6 +3269,7 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
       return err;
     }
   }
+  lap(1, t_mark);
   size_t removed = 0;
   {
     const int err = removeResidentRegions(m, victim_keys.data(), k, &removed);
@@ -3242,6 +3279,7 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
       return err;
     }
   }
+  lap(2, t_mark);
   for (uint32_t v = 0; v < k; ++v)
   {
     m->spilled[packRegionKey(victim_keys[3 * size_t(v)], victim_keys[3 * size_t(v) + 1], victim_keys[3 * size_t(v) + 2])] =
@@ -3345,6 +3383,8 @@ int queueReadmission(ohmhip_map_t m, const std::vector<std::pair<uint32_t, ohmhi
   const ohmhip_map_s::HostStore &st = m->store;
   const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;
   std::vector<uint32_t> dirty_slots[4];
+  std::vector<CopyJob> jobs;
+  jobs.reserve(back.size() * 2);
   for (const auto &entry : back)
   {
     const uint32_t slot = entry.first;
@@ -3354,17 +3394,17 @@ int queueReadmission(ohmhip_map_t m, const std::vector<std::pair<uint32_t, ohmhi
       if (m->layers[l])
       {
         const size_t stride = rv * kLayerBytes[l];
-        OHMHIP_CHECK(hipMemcpyAsync(static_cast<char *>(m->layers[l]) + stride * slot, record + st.layer_offset[l], stride,
-                                    hipMemcpyHostToDevice, m->copy_stream));
+        jobs.push_back(CopyJob{ record + st.layer_offset[l], static_cast<char *>(m->layers[l]) + stride * slot, stride });
       }
     }
     if (keep_mask)
     {
-      OHMHIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(m->d_hit_mask) + st.mask_bytes * slot, record + st.mask_offset,
-                                  st.mask_bytes, hipMemcpyHostToDevice, m->copy_stream));
+      jobs.push_back(CopyJob{ record + st.mask_offset, reinterpret_cast<char *>(m->d_hit_mask) + st.mask_bytes * slot,
+                              st.mask_bytes });
     }
     dirty_slots[entry.second.dirty & (kDirtySync | kDirtyMerge)].push_back(slot);
   }
+  OHMHIP_CHECK(launchCopyJobs(m, jobs, m->copy_stream));
   // (k_plan may be OR-ing this batch's bits into the same words: atomic ORs, from a persistent index scratch)
   size_t n_index = dirty_slots[1].size() + dirty_slots[2].size() + dirty_slots[3].size();
   if (n_index)
@@ -3413,9 +3453,11 @@ int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot)
   {
     return OHMHIP_OK;
   }
+  const auto t_begin = std::chrono::steady_clock::now();
   int err = queueReadmission(m, back);
   const int sync_err = int(hipStreamSynchronize(m->copy_stream));
   err = err ? err : sync_err;
+  m->spill_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (err)
   {
     return err;  // the store still holds every region; the batch fails and is rolled back by the caller
