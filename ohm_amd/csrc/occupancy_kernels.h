@@ -1830,28 +1830,6 @@ constexpr uint32_t kWalkCursorWords = 24;  ///< l_cursor[]: see k_region_walk
 #define OHMHIP_WALK_UNROLL 2
 #endif
 constexpr int kWalkUnroll = OHMHIP_WALK_UNROLL;  ///< walk steps per loop trip (see the loop)
-/// In-wave combining of visits to one voxel (k_region_walk, "leader group"): 0 off, 1 adaptive per wave, 2 always.
-#ifndef OHMHIP_WALK_COMBINE
-#define OHMHIP_WALK_COMBINE 0
-#endif
-#ifndef OHMHIP_WALK_SCRAMBLE
-#define OHMHIP_WALK_SCRAMBLE 0
-#endif
-#ifndef OHMHIP_COMBINE_MIN
-#define OHMHIP_COMBINE_MIN 4
-#endif
-constexpr int kWalkCombine = OHMHIP_WALK_COMBINE;
-constexpr uint32_t kCombineWindow = 32;                          ///< steps per evaluation window of the adaptive switch
-constexpr uint32_t kCombineMinSum = OHMHIP_COMBINE_MIN * kCombineWindow;  ///< keep combining while the groups average this size
-
-/// value << (shift & 31) with a wave-uniform value (the hardware shift only reads the low five bits of `shift`).
-__device__ inline uint32_t shiftUniform(uint32_t shift, uint32_t value)
-{
-  uint32_t r;
-  asm("v_lshlrev_b32_e64 %0, %1, %2" : "=v"(r) : "v"(shift), "s"(value));
-  return r;
-}
-
 /// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
 /// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every iteration
 /// of an active lane is a miss.
@@ -2226,15 +2204,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // kWalkUnroll steps per lane: one refill / exit test per trip, the steps' LDS adds in flight together, their
     // returned flags tested after the last step.  A lane whose segment ends inside a trip idles for the rest of it.
     int refill_threshold = refill_min_idle;  // idle lanes that trigger a refill; 64 once the chunk has no segments left
-    // In-wave combining (wave-uniform state).  Rays that enter a region through the same voxel in nearly the same
-    // direction -- every ray of a scan inside the sensor's own region, neighbouring beams further out -- stand in the
-    // same voxel at the same step, and a returning LDS add to one address serialises over its lanes (the sensor's
-    // region: ~57 LDS cycles per wave step instead of ~6, scripts/sim_walk_conflicts.py).  Each step the lanes standing
-    // in the voxel of the FIRST visiting lane form a group: its first lane adds the group's size in one operation and
-    // shares the returned word, the others aim at their scratch words.  Adaptive: a wave stops looking for groups once
-    // they average fewer than OHMHIP_COMBINE_MIN lanes over a window of steps, until its next chunk.
-    bool combine = kWalkCombine != 0 && !kTraversal;
-    uint32_t combine_sum = 0, combine_steps = 0;
     while (true)
     {
       // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
@@ -2263,15 +2232,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           base + __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
         if (left <= 0 && mine < n_seg)
         {
-#if OHMHIP_WALK_SCRAMBLE
-          // Lanes refilled together take segments OHMHIP_WALK_SCRAMBLE apart in the length-sorted order instead of
-          // consecutive ones (a bijection inside every full window of 1024): neighbours in that order are neighbouring
-          // rays, which stand in the same voxels at the same steps.
-          const uint32_t pick = (mine < (n_seg & ~1023u)) ? ((mine & ~1023u) | ((mine * uint32_t(OHMHIP_WALK_SCRAMBLE)) & 1023u)) : mine;
-#else
-          const uint32_t pick = mine;
-#endif
-          const uint4 *rec = reinterpret_cast<const uint4 *>(chunk_segments + l_order[pick]);
+          const uint4 *rec = reinterpret_cast<const uint4 *>(chunk_segments + l_order[mine]);
           const uint4 ra = rec[0];
           const uint4 rb = rec[1];
           f0 = ra.x;
@@ -2332,8 +2293,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 
       uint32_t olds[kWalkUnroll];     // tile word returned by each step's LDS add
       uint32_t visited[kWalkUnroll];  // `va` of each step's voxel
-      uint32_t group_lane[kWalkUnroll];            // combining: the group's first lane (wave-uniform) ...
-      unsigned long long group_mask[kWalkUnroll];  // ... and the lanes that rode along with it (0: no group this step)
 #pragma unroll
       for (int u = 0; u < kWalkUnroll; ++u)
       {
@@ -2350,8 +2309,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         const bool at_end = kSpecial && end_last && left == 1;
         const bool visit = kSpecial ? (left > 0 && (at_end || !skip)) : (left > 0);
         visited[u] = va;
-        group_lane[u] = 0;
-        group_mask[u] = 0;
 #ifdef OHMHIP_ABL_NOLDS
         olds[u] = 0;
 #elif defined(OHMHIP_ABL_LINEAR)
@@ -2359,31 +2316,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #elif defined(OHMHIP_ABL_RANDOM)
         olds[u] = tileAdd((((va * 2654435761u) ^ (ray * 0x9E3779B1u)) >> 16) & 0xfffcu, shiftOne(va << 3));
 #else
-        uint32_t add_address = visit ? tileAddress(va) : idle_address;
-        uint32_t add_value = shiftOne(va << 3);
-        if (kWalkCombine != 0 && !kTraversal && combine)
-        {
-          const unsigned long long vm = __ballot(visit);
-          if (vm)
-          {
-            const uint32_t first = uint32_t(__builtin_ctzll(vm));
-            const uint32_t v0 = uint32_t(__builtin_amdgcn_readlane(int(va), int(first)));
-            const unsigned long long same = __ballot(visit && va == v0);
-            const uint32_t members = uint32_t(__popcll(same));
-            combine_sum += members;
-            if (members > 1u)
-            {
-              const unsigned long long followers = same & ~(1ull << first);
-              group_lane[u] = first;
-              group_mask[u] = followers;
-              const bool follower = (followers >> lane) & 1ull;
-              add_address = follower ? idle_address : add_address;
-              // (every lane of the group holds the same `va`, hence the same shift: the leader adds members << shift)
-              add_value = (lane == first) ? shiftUniform(va << 3, members) : add_value;
-            }
-          }
-        }
-        olds[u] = tileAdd(add_address, add_value);
+        olds[u] = tileAdd(visit ? tileAddress(va) : idle_address, shiftOne(va << 3));
 #endif
         if (kSpecial)
         {
@@ -2488,26 +2421,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       for (int u = 0; u < kWalkUnroll; ++u)
       {
         olds[u] = waitTile(olds[u]);  // (the first one waits; LDS operations return in order)
-      }
-      if (kWalkCombine != 0 && !kTraversal && combine)
-      {
-#pragma unroll
-        for (int u = 0; u < kWalkUnroll; ++u)
-        {
-          if (group_mask[u])
-          {
-            // the group's lanes stand in one voxel: the word its first lane got back carries their flag too
-            const uint32_t shared = uint32_t(__builtin_amdgcn_readlane(int(olds[u]), int(group_lane[u])));
-            olds[u] = ((group_mask[u] >> lane) & 1ull) ? shared : olds[u];
-          }
-        }
-        combine_steps += uint32_t(kWalkUnroll);
-        if (kWalkCombine == 1 && combine_steps >= kCombineWindow)
-        {
-          combine = combine_sum >= kCombineMinSum * combine_steps / kCombineWindow;
-          combine_sum = 0;
-          combine_steps = 0;
-        }
       }
 #ifdef OHMHIP_ABL_NOFLAG
       if (olds[0] == 0x12345u)
