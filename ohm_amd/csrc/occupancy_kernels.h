@@ -23,6 +23,10 @@
 #ifndef OHMHIP_OCCUPANCY_KERNELS_H
 #define OHMHIP_OCCUPANCY_KERNELS_H
 
+#ifndef OHMHIP_BIN_FUSE_STEPS
+#define OHMHIP_BIN_FUSE_STEPS 1  // k_ray_bin: sample key emitted in the segment loop (one RayWalk load per ray)
+#endif
+
 #include "secondary_device.h"
 #include "walk_device.h"
 
@@ -1088,9 +1092,7 @@ __global__ void __launch_bounds__(kBinThreads)
   __syncthreads();
   // Step 2: sample keys and mask bits.  bucket_hits: the keys go straight into their region's range of the sample
   // list (k_sort_region_hits orders each range); otherwise they are written in ray order for a device-wide sort.
-  for (uint32_t ray = first + threadIdx.x; ray < last; ray += blockDim.x)
-  {
-    const RayWalk rw = walks[ray];
+  auto emitSample = [&](uint32_t ray, const RayWalk &rw) {
     unsigned long long hk = kHitInvalid;
     uint32_t pos = ray;
     if ((rw.flags & kRwValid) && (rw.flags & kRwApplySample))
@@ -1131,7 +1133,13 @@ __global__ void __launch_bounds__(kBinThreads)
     {
       hit_keys[pos] = hk;
     }
+  };
+#if !OHMHIP_BIN_FUSE_STEPS
+  for (uint32_t ray = first + threadIdx.x; ray < last; ray += blockDim.x)
+  {
+    emitSample(ray, walks[ray]);
   }
+#endif
   // Step 3: scatter, rays visited by descending extent (see RayOrder).
   __shared__ RayOrder order;
   const uint32_t n_local = last - first;
@@ -1144,6 +1152,9 @@ __global__ void __launch_bounds__(kBinThreads)
   {
     const uint32_t ray = first + order.perm[idx];
     const RayWalk rw = walks[ray];
+#if OHMHIP_BIN_FUSE_STEPS
+    emitSample(ray, rw);  // (the ray's record is loaded once for both its sample key and its segments)
+#endif
     const RayFix rf = rayFix(mc, rw);
     forEachSegment(mc, rw, true, [&](uint64_t key, const SegmentEntry &entry) {
       const uint32_t e = ltabFind(tab, key, tab_mask);
