@@ -272,19 +272,39 @@ def main():
     rays_ok = int(st["rays_integrated"])
     # Algorithmic bytes: 44 B per ray + 8 B per voxel visit (4 B read + 4 B write of the log-odds).
     b_alg = 44.0 * rays_ok + 8.0 * visits
-    # Measured HBM traffic of the dominant kernel: from the committed PMC profile of this same command (separate
-    # rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); bench.py itself cannot run the profiler.
-    traffic = traffic_lower = None
+    # Measured HBM traffic: from the committed PMC profile of this same command (separate rocprofv3 --pmc passes,
+    # profiles/r03_traffic.json <- scripts/traffic_json.py; bench.py itself cannot run the profiler).  FETCH_SIZE counts
+    # 64-byte requests: x2 for coalesced streams (the guide's correction), x1 for the kernel's 32-byte record gathers
+    # (profiles/r02_fetch_calibration.txt) -- the two figures bracket the bytes moved.
+    traffic = traffic_lower = batch_traffic = batch_traffic_lower = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
             tj = json.load(fh)
         if world == 1 and n_rays == 1_000_000:
-            # FETCH_SIZE counts 64-byte requests: x2 for coalesced streams (the guide's correction), x1 for the kernel's
-            # 32-byte record gathers (profiles/r02_fetch_calibration.txt) -- the two figures bracket the bytes moved.
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_lower = tj["traffic_bytes_per_launch_lower"]
+            traffic = tj["kernels"]["k_region_walk"]["bytes_upper"]
+            traffic_lower = tj["kernels"]["k_region_walk"]["bytes_lower"]
+            batch_traffic = tj["batch_bytes_upper"]
+            batch_traffic_lower = tj["batch_bytes_lower"]
     except Exception:
-        traffic = traffic_lower = None
+        traffic = traffic_lower = batch_traffic = batch_traffic_lower = None
+    # Measured ceiling next to the nominal peak: a device-to-device copy of 1 GiB (read + write).
+    copy_gbps = None
+    try:
+        nbytes = 1 << 30
+        ca, cb = L._vp(), L._vp()
+        L.check(L.lib.ohmhip_buffer_create(C.byref(ca), nbytes, 3), "buffer_create")
+        L.check(L.lib.ohmhip_buffer_create(C.byref(cb), nbytes, 3), "buffer_create")
+        L.check(L.lib.ohmhip_buffer_copy(cb, 0, ca, 0, nbytes, None, None, None), "buffer_copy")
+        gm.wait()
+        reps = 5
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            L.check(L.lib.ohmhip_buffer_copy(cb, 0, ca, 0, nbytes, None, None, None), "buffer_copy")
+        copy_gbps = 2.0 * nbytes * reps / (time.perf_counter() - t1) / 1e9
+        L.lib.ohmhip_buffer_destroy(ca)
+        L.lib.ohmhip_buffer_destroy(cb)
+    except Exception:
+        copy_gbps = None
     t_walk = float(np.mean(walk_ms)) * 1e-3
     t_dev = float(np.mean(total_ms)) * 1e-3
     achieved = b_alg / t_walk / 1e9
@@ -305,7 +325,8 @@ def main():
                    "regions": int(st["regions_resident"]), "ray_region_segments": int(st["ray_region_segments"])},
         "roofline": {"bound": "hbm", "kernel": "k_region_walk", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_lower": traffic_lower,
+                     "traffic_lower": traffic_lower, "pipeline_traffic": batch_traffic,
+                     "pipeline_traffic_lower": batch_traffic_lower, "peak_measured_copy": copy_gbps,
                      "algorithmic_bytes_per_launch": b_alg, "kernel_ms": t_walk * 1e3,
                      "pipeline_ms": t_dev * 1e3, "pipeline_frac": b_alg / t_dev / 1e9 / HBM_PEAK_GBPS},
         "device_ms": {"setup_bin": float(np.mean([t["ms_setup"] for t in timings])), "walk": float(np.mean(walk_ms)),
@@ -393,12 +414,20 @@ def main():
                 b_alg2 = 16.0 * v2 + 68.0 * n2
             dev2 = float(np.mean([t["ms_total"] for t in tm2])) * 1e-3
             walk2 = float(np.mean([t["ms_walk"] for t in tm2])) * 1e-3
+            tr2 = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r03_traffic_c2_ndt.json" if cls is ohm_amd.GpuNdtMap
+                                       else "r03_traffic_c3_tsdf.json")) as fh:
+                    tj2 = json.load(fh)
+                tr2 = {"pipeline_traffic": tj2["batch_bytes_upper"], "pipeline_traffic_lower": tj2["batch_bytes_lower"]}
+            except Exception:
+                tr2 = None
             extra[name] = {"rays_per_s": (r2.shape[0] // 2) / dt, "ms_per_step": dt * 1e3, "rays": r2.shape[0] // 2,
                            "voxel_visits": v2, "regions": int(st2["regions_resident"]),
                            "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": b_alg2, "peak": HBM_PEAK_GBPS,
                                         "unit": "GB/s", "pipeline_ms": dev2 * 1e3,
                                         "achieved": b_alg2 / dev2 / 1e9, "frac": b_alg2 / dev2 / 1e9 / HBM_PEAK_GBPS,
-                                        "walk_kernel_ms": walk2 * 1e3,
+                                        "walk_kernel_ms": walk2 * 1e3, "counter_traffic": tr2,
                                         "note": "frac is over the whole device pipeline of a batch (walk + event order + "
                                                 "ordered replay).  The formula charges every voxel visit with the "
                                                 "layer bytes the reference formulation would move; this design only "

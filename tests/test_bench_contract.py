@@ -1,4 +1,4 @@
-"""CPU: the committed default bench line (profiles/r02_bench_default.json, produced by `python bench.py` on an MI355X)
+"""CPU: the committed default bench line (profiles/r03_bench_default.json, produced by `python bench.py` on an MI355X)
 carries every field the bench contract names, with consistent arithmetic."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_default.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_default.json")) as fh:
         line = json.load(fh)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -20,10 +20,13 @@ def test_committed_bench_line_has_the_contract_fields():
     roof = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_lower"):
         assert key in roof, key
-    with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
         traffic = json.load(fh)
-    assert roof["traffic"] == traffic["traffic_bytes_per_launch"]
-    assert roof["traffic_lower"] == traffic["traffic_bytes_per_launch_lower"]
+    walk = traffic["kernels"]["k_region_walk"]
+    assert roof["traffic"] == walk["bytes_upper"] and roof["traffic_lower"] == walk["bytes_lower"]
+    assert roof["pipeline_traffic"] == traffic["batch_bytes_upper"]
+    assert roof["pipeline_traffic_lower"] == traffic["batch_bytes_lower"]
+    assert 2000.0 < roof["peak_measured_copy"] < roof["peak"]  # a device-to-device copy, GB/s read + write
     # north_star: the dominant kernel at >= 0.40 of the HBM roofline
     assert roof["frac"] >= 0.40
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
@@ -36,24 +39,36 @@ def test_committed_bench_line_has_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] == 1 and cpu["unit"] == "rays/s"
+    # the other CPU legs SURVEY 8d asks for: C0 on its own rays, and replicas over all physical cores
+    assert cpu["c0"]["cores"] == 1 and cpu["c0"]["value"] > 0 and "C0" in cpu["c0"]["sample"]
+    assert cpu["all_cores"]["cores"] > 1 and cpu["all_cores"]["value"] > cpu["value"]
+    # every BASELINE config has a line: C0, C2, C3 (+ cache stress), C4 (one-GPU stand-in with the merge deviation)
+    other = line["other_configs"]
+    for key in ("C0_100k_rays_10m", "C2_ndt_1M_rays_0.2m", "C3_tsdf_4M_rays_0.05m", "C3_tsdf_cache_stress_1GiB",
+                "C4_8_shards_one_gpu_replica_merge", "C1_4096_ray_batches"):
+        assert key in other and "error" not in other[key], key
+    dev = other["C4_8_shards_one_gpu_replica_merge"]["deviation_vs_sequential"]
+    assert dev["voxels_state_differs"] == 0 and dev["regions_compared"] > 1000
+    assert "walk_kernel_frac" not in other["C2_ndt_1M_rays_0.2m"]["roofline"]
 
 
 def test_traffic_file_matches_the_profile_it_cites():
-    with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
         traffic = json.load(fh)
-    expect = (traffic["fetch_size_kb"] * traffic["fetch_correction"] + traffic["write_size_kb"]) * 1024.0
-    assert abs(traffic["traffic_bytes_per_launch"] - expect) < 1.0
-    lower = (traffic["fetch_size_kb"] * traffic["fetch_correction_lower"] + traffic["write_size_kb"]) * 1024.0
-    assert abs(traffic["traffic_bytes_per_launch_lower"] - lower) < 1.0
-    summary = open(os.path.join(ROOT, "profiles", "r02_profile_final.txt")).read()
+    walk = traffic["kernels"]["k_region_walk"]
+    assert abs(walk["bytes_upper"] - (2.0 * walk["fetch_size_kb"] + walk["write_size_kb"]) * 1024.0) < 1024.0
+    assert abs(walk["bytes_lower"] - (walk["fetch_size_kb"] + walk["write_size_kb"]) * 1024.0) < 1024.0
+    total = sum(k["bytes_upper"] * k["launches_per_batch"] for k in traffic["kernels"].values())
+    assert abs(total - traffic["batch_bytes_upper"]) < 1e-6 * total
+    summary = open(os.path.join(ROOT, "profiles", "r03_profile_final.txt")).read()
     assert "k_region_walk" in summary and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary
     # the profile's average duration of the dominant kernel agrees with the bench line's HIP-event figure
-    with open(os.path.join(ROOT, "profiles", "r02_bench_default.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_default.json")) as fh:
         line = json.load(fh)
     row = [ln for ln in summary.splitlines() if ln.strip().startswith("k_region_walk")][0].split()
     avg_us = float(row[3])
     assert abs(avg_us * 1e-3 - line["roofline"]["kernel_ms"]) / line["roofline"]["kernel_ms"] < 0.05
-    assert f"{traffic['fetch_size_kb']:.1f}" in summary and f"{traffic['write_size_kb']:.1f}" in summary
+    assert f"{walk['fetch_size_kb']:.1f}" in summary and f"{walk['write_size_kb']:.1f}" in summary
 
 
 def test_gpus_n_without_a_launcher_environment_starts_n_ranks():
