@@ -23,6 +23,9 @@
 #ifndef OHMHIP_OCCUPANCY_KERNELS_H
 #define OHMHIP_OCCUPANCY_KERNELS_H
 
+#ifndef OHMHIP_COLD_HINTS
+#define OHMHIP_COLD_HINTS 1  // k_region_walk: branch hints on the rare blocks of the loop (experiment)
+#endif
 #ifndef OHMHIP_BIN_FUSE_STEPS
 #define OHMHIP_BIN_FUSE_STEPS 1  // k_ray_bin: sample key emitted in the segment loop (one RayWalk load per ray)
 #endif
@@ -2220,7 +2223,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
       const unsigned long long am = __ballot(left > 0);
       const int n_idle = 64 - __popcll(am);
+#if OHMHIP_COLD_HINTS
+      if (__builtin_expect(n_idle >= refill_threshold, 0))
+#else
       if (n_idle >= refill_threshold)
+#endif
       {
         if (exhausted)
         {
@@ -2399,7 +2406,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #else
           const unsigned long long slow = __ballot(left > 0) & ~certain;
 #endif
+#if OHMHIP_COLD_HINTS
+          if (__builtin_expect(slow != 0, 0))
+#else
           if (slow)
+#endif
           {
             int axis = 1;
             if ((slow >> lane) & 1ull)
