@@ -295,11 +295,12 @@ def main():
         L.check(L.lib.ohmhip_buffer_create(C.byref(ca), nbytes, 3), "buffer_create")
         L.check(L.lib.ohmhip_buffer_create(C.byref(cb), nbytes, 3), "buffer_create")
         L.check(L.lib.ohmhip_buffer_copy(cb, 0, ca, 0, nbytes, None, None, None), "buffer_copy")
-        gm.wait()
+        L.check(L.lib.ohmhip_device_synchronize(), "device_synchronize")
         reps = 5
         t1 = time.perf_counter()
         for _ in range(reps):
             L.check(L.lib.ohmhip_buffer_copy(cb, 0, ca, 0, nbytes, None, None, None), "buffer_copy")
+        L.check(L.lib.ohmhip_device_synchronize(), "device_synchronize")
         copy_gbps = 2.0 * nbytes * reps / (time.perf_counter() - t1) / 1e9
         L.lib.ohmhip_buffer_destroy(ca)
         L.lib.ohmhip_buffer_destroy(cb)
@@ -592,6 +593,55 @@ def main():
             host_small[label] = {"rays_per_s": n_calls * small / dt, "ms_per_call": dt * 1e3 / n_calls}
             g6.close()
         extra["C1_4096_ray_host_batches"] = host_small
+        # C1 with a traversal layer (sum of ray lengths per voxel): the exact-fp64 walk instantiation with one global
+        # integer atomic per visit -- a secondary layer, never the headline.
+        try:
+            mt = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy", "traversal"))
+            gt = ohm_amd.GpuMap(mt, gpu_mem_size=8 << 30)
+            gt.integrateRaysDevice(dptr, rays.shape[0])
+            gt.wait()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                gt.integrateRaysDevice(dptr, rays.shape[0])
+            gt.wait()
+            dt = (time.perf_counter() - t1) / 5
+            extra["C1_with_traversal_layer"] = {"rays_per_s": n_rays / dt, "ms_per_step": dt * 1e3,
+                                                "walk_ms": float(gt.stats()["ms_walk"])}
+            gt.close()
+        except Exception as exc:
+            extra["C1_with_traversal_layer"] = {"error": repr(exc)}
+        # A moving sensor (what a real stream looks like: every batch creates regions at the frontier, so the pool grows
+        # and the speculative binning -- which keys on the previous batch -- sometimes has to repeat its passes).
+        try:
+            mm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+            gmv = ohm_amd.GpuMap(mm, gpu_mem_size=8 << 30)
+            n_mov = 8
+            bufs = []
+            for b in range(n_mov + 1):
+                rb = synth.rays_c1(n=n_rays, origin=(0.05 + 0.4 * b, 0.05 + 0.1 * b, 0.05), first=b * 997)
+                hb = L._vp()
+                L.check(L.lib.ohmhip_buffer_create(C.byref(hb), rb.nbytes, 3), "buffer_create")
+                L.check(L.lib.ohmhip_buffer_write(hb, rb.ctypes.data, rb.nbytes, 0, None, None, None), "buffer_write")
+                pb = L._vp()
+                L.check(L.lib.ohmhip_buffer_ptr(hb, C.byref(pb)), "buffer_ptr")
+                bufs.append((hb, pb, rb.shape[0]))
+                del rb
+            gmv.integrateRaysDevice(bufs[0][1], bufs[0][2])  # first batch: pool allocation, not timed
+            gmv.wait()
+            t1 = time.perf_counter()
+            for hb, pb, cnt in bufs[1:]:
+                gmv.integrateRaysDevice(pb, cnt)
+            gmv.wait()
+            dt = (time.perf_counter() - t1) / n_mov
+            stm = gmv.stats()
+            extra["C1_moving_sensor"] = {"rays_per_s": n_rays / dt, "ms_per_step": dt * 1e3, "batches": n_mov,
+                                         "sensor_step_m": 0.41, "regions_at_end": int(stm["regions_resident"]),
+                                         "note": "the C1 sweep from an origin that advances 0.41 m per batch"}
+            for hb, _, _ in bufs:
+                L.lib.ohmhip_buffer_destroy(hb)
+            gmv.close()
+        except Exception as exc:
+            extra["C1_moving_sensor"] = {"error": repr(exc)}
         # (iii) exact multi-GPU mode ("owner computes"): what ONE rank of an 8-way region partition spends
         # on the full C1 stream -- the per-ray front half is repeated on every rank, the line walk is partitioned.
         per_rank = []
