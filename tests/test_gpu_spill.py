@@ -175,3 +175,69 @@ def test_a_batch_larger_than_the_limit_still_fails_cleanly(gpu):
     assert gm.integrateRays(big) == 0
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+
+
+def test_regions_created_by_name_obey_the_limit(gpu):
+    """uploads (write_regions) and ensure_regions used to grow the pool past the memory limit.  Now they make
+    room first -- the least recently used OTHER regions go to the store -- or fail and change nothing without spilling."""
+    import ctypes as C
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm = limited_map(map_, 40)
+    gm.setSpillToHost(True)
+    om = make_oracle(map_)
+    rays = sensor_rays((0.0, 0.0, 0.0), 6000, seed=21, max_range=3.5)
+    assert gm.integrateRays(rays) == rays.shape[0]
+    om.integrate_occupancy(rays)
+    gm.syncVoxels()
+    before = gm.cacheStats()
+    assert 20 < before["regions_resident"] <= 40
+    # upload 30 regions far away (new keys): the pool would need 30 more slots than the limit allows
+    far = np.array([[40 + i, 0, 0] for i in range(30)], dtype=np.int16)
+    block = np.full(32 ** 3, np.float32(0.25), dtype=np.float32)
+    for k in far:
+        map_.chunks[tuple(int(v) for v in k)] = {"occupancy": block.copy()}
+    assert gm.uploadRegions(far) == 30
+    st = gm.cacheStats()
+    assert st["regions_resident"] <= 40 and st["regions_spilled"] >= before["regions_resident"] + 30 - 40
+    assert st["evictions"] >= st["regions_spilled"]
+    # everything is still there and correct: the rays' regions (some from the store) and the uploaded blocks
+    keys = {tuple(int(v) for v in k) for k in gm.regionKeys()}
+    assert keys == set(om.chunks().keys()) | {tuple(int(v) for v in k) for k in far}
+    ks = np.array(sorted(keys), dtype=np.int16)
+    out = np.zeros((len(ks), 32 ** 3), dtype=np.float32)
+    ptrs = (C.c_void_p * len(ks))(*[out[i].ctypes.data for i in range(len(ks))])
+    L.check(L.lib.ohmhip_map_read_regions(gm._handle, L.LID_OCCUPANCY, ks.ctypes.data, len(ks), ptrs))
+    got = {tuple(int(v) for v in k): out[i] for i, k in enumerate(ks)}
+    for k, layers in om.chunks().items():
+        assert np.array_equal(got[k].view(np.uint32), layers["occupancy"].reshape(-1).view(np.uint32)), k
+    for k in far:
+        assert np.all(got[tuple(int(v) for v in k)] == np.float32(0.25))
+    # without spilling the same request fails cleanly
+    map2 = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm2 = limited_map(map2, 40)
+    assert gm2.integrateRays(rays) == rays.shape[0]
+    gm2.syncVoxels()
+    n_before = len(gm2.regionKeys())
+    slots = np.zeros(30, dtype=np.uint32)
+    assert L.lib.ohmhip_map_ensure_regions(gm2._handle, far.ctypes.data, 30, slots.ctypes.data) == L.ERR_CAPACITY
+    assert len(gm2.regionKeys()) == n_before and gm2.cacheStats()["regions_resident"] == n_before
+
+
+def test_a_rejected_batch_leaves_no_modified_flags(gpu):
+    """a batch that fails with OHMHIP_ERR_CAPACITY must leave the map exactly as it was -- also the
+    'modified since the last sync' flags of the resident regions it would have touched."""
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm = limited_map(map_, 30)  # no spilling: the batch below cannot run
+    gm.setBatchCoalescing(0)    # every call launches (and answers for) its own device batch
+    small = sensor_rays((0.0, 0.0, 0.0), 3000, seed=31, max_range=2.5)
+    assert gm.integrateRays(small) == small.shape[0]
+    gm.syncVoxels()
+    assert len(gm.regionKeys(dirty_only=True)) == 0
+    n_regions = len(gm.regionKeys())
+    big = sensor_rays((0.0, 0.0, 0.0), 5000, seed=32, min_range=5.0, max_range=9.0)  # crosses the resident regions too
+    assert gm.integrateRays(big) == 0
+    assert len(gm.regionKeys(dirty_only=True)) == 0, "the rejected batch marked regions as modified"
+    assert len(gm.regionKeys()) == n_regions
+    # and a batch that fits afterwards is tracked normally
+    assert gm.integrateRays(small) == small.shape[0]
+    assert 0 < len(gm.regionKeys(dirty_only=True)) <= n_regions
