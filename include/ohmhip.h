@@ -132,7 +132,7 @@ enum ohmhip_map_mode
 #define OHMHIP_RF_DEFAULT 0u
 #define OHMHIP_RF_END_POINT_AS_FREE (1u << 0)
 #define OHMHIP_RF_STOP_ON_FIRST_OCCUPIED (1u << 1) /* exact, via per-ray stop iteration over the sorted visits of the
-                                                      batch (slow path); refused with a traversal layer */
+                                                      batch (slow path); also with a traversal layer */
 #define OHMHIP_RF_EXCLUDE_ORIGIN (1u << 2)
 #define OHMHIP_RF_EXCLUDE_SAMPLE (1u << 3)
 #define OHMHIP_RF_EXCLUDE_RAY (1u << 4)

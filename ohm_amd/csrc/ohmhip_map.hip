@@ -1378,10 +1378,12 @@ struct BatchRun
       if (info.n_touched)
       {
         // nothing was counted (every visit was an event): this clears the sample mask and the per-batch scratch
+        // (with a traversal layer: the ray lengths the walk summed per voxel -- stopped rays keep adding theirs,
+        // ohm/RayMapperOccupancy.cpp:166-173 runs for null updates too -- go into the layer here)
         hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
                            batchScratch(m), ray_flags, m->d_miss_counts, m->d_hit_mask, occ, 1,
-                           static_cast<uint32_t *>(nullptr), 0u, 1, static_cast<float *>(nullptr),
-                           static_cast<unsigned long long *>(nullptr));
+                           static_cast<uint32_t *>(nullptr), 0u, 1, sec.traversal,
+                           sec.traversal ? m->d_traversal_acc : static_cast<unsigned long long *>(nullptr));
       }
     }
     else if (ndt_mode)
@@ -2154,13 +2156,7 @@ namespace
 /// run later with a collected batch.
 int validateBatchRequest(ohmhip_map_t m, unsigned ray_flags)
 {
-  if ((ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED) && m->config.mode == OHMHIP_MODE_OCCUPANCY &&
-      m->layers[OHMHIP_LID_TRAVERSAL])
-  {
-    // A stopped ray keeps adding its path lengths to the traversal layer on the CPU (ohm/RayMapperOccupancy.cpp:
-    // 166-173 runs for null updates too); the stop replay carries no ray ranges.  Not combined here.
-    return OHMHIP_ERR_UNSUPPORTED;
-  }
+  (void)ray_flags;  // (every RayFlag combination of the CPU mappers is supported since round 3)
   switch (m->config.mode)
   {
   case OHMHIP_MODE_OCCUPANCY:

@@ -373,8 +373,10 @@ __global__ void __launch_bounds__(128)
     double centre[3] = { 0, 0, 0 };
     uint32_t packed_normal = 0;
     uint32_t last_sample_ray = kNoStop;
+    float traversal = 0.0f;
     if (kCommit)
     {
+      traversal = sec.traversal ? sec.traversal[gi] : 0.0f;
       if (mean)
       {
         mcoord = mean[2 * gi];
@@ -405,6 +407,15 @@ __global__ void __launch_bounds__(128)
         if (kCommit)
         {
           last_sample_ray = ray;
+          if (sec.traversal)
+          {
+            // ohm/RayMapperOccupancy.cpp:299-305: remaining ray length inside the sample voxel (only for a ray that
+            // applies its sample, i.e. one that was not stopped).
+            const double dx = rays[size_t(ray) * 6 + 3] - rays[size_t(ray) * 6 + 0];
+            const double dy = rays[size_t(ray) * 6 + 4] - rays[size_t(ray) * 6 + 1];
+            const double dz = rays[size_t(ray) * 6 + 5] - rays[size_t(ray) * 6 + 2];
+            traversal += float(sqrt((dx * dx + dy * dy) + dz * dz) - lastExitRange(walks, ray));
+          }
           if (sec.incident)
           {
             const float dir[3] = { float(rays[size_t(ray) * 6 + 0] - rays[size_t(ray) * 6 + 3]),
@@ -446,6 +457,10 @@ __global__ void __launch_bounds__(128)
       if (sec.incident)
       {
         sec.incident[gi] = packed_normal;
+      }
+      if (sec.traversal && last_sample_ray != kNoStop)
+      {
+        sec.traversal[gi] = traversal;
       }
       if (sec.touch_time && sec.timestamps && last_sample_ray != kNoStop)
       {
