@@ -24,7 +24,7 @@
 #define OHMHIP_OCCUPANCY_KERNELS_H
 
 #ifndef OHMHIP_COLD_HINTS
-#define OHMHIP_COLD_HINTS 1  // k_region_walk: branch hints on the rare blocks of the loop (experiment)
+#define OHMHIP_COLD_HINTS 3  // k_region_walk: branch hints on the rare blocks of the loop (1: exact step, 2: lane refill)
 #endif
 #ifndef OHMHIP_BIN_FUSE_STEPS
 #define OHMHIP_BIN_FUSE_STEPS 1  // k_ray_bin: sample key emitted in the segment loop (one RayWalk load per ray)
@@ -455,7 +455,10 @@ __device__ inline RayFix rayFix(const MapConst &mc, const RayWalk &rw)
       e[a] = !(ex >= 1.0) ? 0u : ((ex >= double(kFixMaxDelta)) ? kFixMaxDelta : uint32_t(ex));
       const double tl = stepTime(rw.init[a], rw.delta[a], rw.total[a]);
       const double tp = rw.init[a] + rw.delta[a] * double(rw.total[a]);
-      rf.poison = rf.poison || !(tl >= 0.0) || !(tp >= tl);
+      // (a start point ON a voxel face -- every ray of a sensor standing on the voxel lattice -- can give a first
+      // crossing time that rounds to -1e-18 instead of 0: anything above minus one predictor unit quantises to 0 within
+      // the predictor's one-unit error per value, so only times below that poison the ray)
+      rf.poison = rf.poison || !(tl * mc.fix_scale > -1.0) || !(tp >= tl);
       t_last = (tl > t_last) ? tl : t_last;
       t_phantom = (tp < t_phantom) ? tp : t_phantom;
     }
@@ -484,8 +487,8 @@ __device__ inline bool fixTime(const MapConst &mc, double init, double delta, in
   }
   const double t = (k == 0) ? init : init + delta * double(k);
   const double x = (t - t_base) * mc.fix_scale;
-  const bool ok = x >= 0.0;  // (false for NaN)
-  f = !ok ? 0u : ((x >= double(kFixFar)) ? kFixFar : uint32_t(x));
+  const bool ok = x > -1.0;  // (false for NaN; (-1, 0) quantises to 0, still within one unit of the true time)
+  f = !(x >= 1.0) ? 0u : ((x >= double(kFixFar)) ? kFixFar : uint32_t(x));
   return ok;
 }
 
@@ -2207,6 +2210,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     uint32_t qcount = 0;     // wave-uniform
     bool exhausted = false;  // wave-uniform
     uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0, dbg_slow = 0;  // wave-uniform (kTrace)
+    uint32_t dbg_s2 = 0, dbg_s3 = 0, dbg_sl = 0, dbg_sp = 0;
     unsigned long long clk_loop = 0;
     if (kTrace)
     {
@@ -2223,7 +2227,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
       const unsigned long long am = __ballot(left > 0);
       const int n_idle = 64 - __popcll(am);
-#if OHMHIP_COLD_HINTS
+#if OHMHIP_COLD_HINTS & 2
       if (__builtin_expect(n_idle >= refill_threshold, 0))
 #else
       if (n_idle >= refill_threshold)
@@ -2404,9 +2408,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           const unsigned long long slow = 0;
           (void)certain;
 #else
-          const unsigned long long slow = __ballot(left > 0) & ~certain;
+          // (a lane on its segment's LAST voxel takes a step nobody uses -- its predictors are parked when the ray ends
+          // there, which would send every ray of a TSDF / end-point-as-free batch through the exact path once for nothing)
+          const unsigned long long slow = __ballot(left > 1) & ~certain;
 #endif
-#if OHMHIP_COLD_HINTS
+#if OHMHIP_COLD_HINTS & 1
           if (__builtin_expect(slow != 0, 0))
 #else
           if (slow)
@@ -2424,6 +2430,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
             if (kTrace)
             {
               ++dbg_slow;
+              dbg_s2 += uint32_t(__popcll(slow & __ballot(left == 2)));
+              dbg_s3 += uint32_t(__popcll(slow & __ballot(left == 3)));
+              dbg_sl += uint32_t(__popcll(slow));
+              dbg_sp += uint32_t(__popcll(slow & __ballot((d0 | d1 | d2) == 0u)));
             }
           }
           const unsigned long long a1 = ~(a0 | a2);
@@ -2507,6 +2517,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         atomicAdd(&args.dbg_counters[2], (unsigned long long)dbg_refills);
         atomicAdd(&args.dbg_counters[3], (unsigned long long)dbg_fm);
         atomicAdd(&args.dbg_counters[4], (unsigned long long)dbg_slow);
+        atomicAdd(&args.dbg_counters[5], (unsigned long long)dbg_s2);
+        atomicAdd(&args.dbg_counters[6], (unsigned long long)dbg_s3);
+        atomicAdd(&args.dbg_counters[7], (unsigned long long)dbg_sl);
+        atomicAdd(&args.dbg_counters[8], (unsigned long long)dbg_sp);
       }
     }
     // Final queue flush.

@@ -2471,8 +2471,9 @@ try
     static unsigned long long c[kDbgWords];
     OHMHIP_CHECK(hipMemcpy(c, m->d_dbg, sizeof(c), hipMemcpyDeviceToHost));
     std::fprintf(stderr,
-                 "[ohmhip dbg] wave-steps %llu visits %llu refills %llu flagged wave-steps %llu exact wave-steps %llu\n",
-                 c[0], c[1], c[2], c[3], c[4]);
+                 "[ohmhip dbg] wave-steps %llu visits %llu refills %llu flagged wave-steps %llu exact wave-steps %llu "
+                 "(exact lane-steps %llu: %llu with 2 voxels left, %llu with 3, %llu on poisoned segments)\n",
+                 c[0], c[1], c[2], c[3], c[4], c[7], c[5], c[6], c[8]);
     if (const char *path = std::getenv("OHMHIP_DEBUG_TRACE"))
     {
       if (FILE *f = std::fopen(path, "w"))
