@@ -235,7 +235,11 @@ int ohmhip_map_integrate_rays_filtered(ohmhip_map_t map, const double *rays, siz
  * it.  Default min_rays: 65536; 0 launches every call's batch in that call. */
 int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
 /* Same with rays (and optional intensities/timestamps) already resident in device memory.  The arrays must be COMPLETE
- * when the call is made (not merely enqueued on some stream): the map reads them on streams of its own. */
+ * when the call is made (not merely enqueued on some stream): the map reads them on streams of its own.  Calls below
+ * the coalescing threshold are collected like small host batches (round 3): their arrays are copied device to device
+ * behind the rays already waiting and run as one batch once min_rays have accumulated or anything observes the map.
+ * With `integrated` non-NULL the call waits for that copy (it reports its own count from a filter pass over the copy),
+ * so the caller's arrays are free when it returns; with NULL they must stay valid until the next ohmhip_map_sync. */
 int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, size_t element_count,
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
                                      size_t *integrated);

@@ -318,20 +318,32 @@ try
   }
   hipStream_t s = m->stream;
   const int world = comm->world;
-  // 1. this rank's modified regions
+  // 1. this rank's pending regions.  A failure here does not leave the call: it travels as a negative count in the
+  //    first collective, so that every rank returns together (a rank that returned early would leave its peers blocked).
   size_t n_local = 0;
-  OHMHIP_CHECK(ohmhip_map_merge_keys(m, nullptr, 0, &n_local));
-  std::vector<int16_t> local_keys(3 * std::max<size_t>(n_local, 1));
-  OHMHIP_CHECK(ohmhip_map_merge_keys(m, local_keys.data(), n_local, &n_local));
+  int keys_err = ohmhip_map_merge_keys(m, nullptr, 0, &n_local);
+  std::vector<int16_t> local_keys(3 * std::max<size_t>(keys_err ? 0 : n_local, 1));
+  if (!keys_err)
+  {
+    keys_err = ohmhip_map_merge_keys(m, local_keys.data(), n_local, &n_local);
+  }
+  if (keys_err)
+  {
+    n_local = 0;
+  }
   // 2. all-gather the key lists: counts first (one word per rank), then the lists padded to the longest.
   OHMHIP_CHECK(m->merge_keys_dev.ensure(sizeof(int64_t) * size_t(world + 1), false, s));
   int64_t *d_counts = static_cast<int64_t *>(m->merge_keys_dev.ptr);
-  const int64_t my_count = int64_t(n_local);
+  const int64_t my_count = keys_err ? int64_t(-1) : int64_t(n_local);
   OHMHIP_CHECK(hipMemcpyAsync(d_counts + world, &my_count, sizeof(int64_t), hipMemcpyHostToDevice, s));
   OHMHIP_CHECK(ncclStatus(ncclAllGather(d_counts + world, d_counts, 1, ncclInt64, comm->comm, s)));
   std::vector<int64_t> counts(size_t(world), 0);
   OHMHIP_CHECK(hipMemcpyAsync(counts.data(), d_counts, sizeof(int64_t) * size_t(world), hipMemcpyDeviceToHost, s));
   OHMHIP_CHECK(hipStreamSynchronize(s));
+  if (*std::min_element(counts.begin(), counts.end()) < 0)
+  {
+    return keys_err ? keys_err : OHMHIP_ERR_PEER;  // some rank could not list its regions: nobody merges
+  }
   const size_t longest = size_t(*std::max_element(counts.begin(), counts.end()));
   size_t n_union = 0;
   std::vector<int16_t> shared_keys;
