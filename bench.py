@@ -593,8 +593,8 @@ def main():
             host_small[label] = {"rays_per_s": n_calls * small / dt, "ms_per_call": dt * 1e3 / n_calls}
             g6.close()
         extra["C1_4096_ray_host_batches"] = host_small
-        # C1 with a traversal layer (sum of ray lengths per voxel): the exact-fp64 walk instantiation with one global
-        # integer atomic per visit -- a secondary layer, never the headline.
+        # C1 with a traversal layer (sum of ray lengths per voxel): the count walk plus k_region_traversal, a second fp64
+        # walk into a 32-bit LDS tile -- a secondary layer, never the headline.
         try:
             mt = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy", "traversal"))
             gt = ohm_amd.GpuMap(mt, gpu_mem_size=8 << 30)

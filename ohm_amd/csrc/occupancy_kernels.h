@@ -1818,9 +1818,6 @@ struct WalkArgs
   float *occupancy;  ///< non-null: single-chunk regions are applied straight from LDS
   unsigned ray_flags;
   unsigned long long *dbg_counters;
-  /// kTraversal instantiations: per-voxel sum of the ray lengths of this batch's visits, in fixed point
-  /// (kTraversalScale units per metre): integer atomics, so the sum does not depend on the order of the adds.
-  unsigned long long *traversal_acc;
   float *tsdf;       ///< non-null (TSDF mode): single-chunk regions are applied straight from LDS
   uint32_t *chunk_cursor;  ///< device-wide next-chunk cursor (zeroed before the launch)
   uint32_t n_chunks;
@@ -1850,14 +1847,9 @@ constexpr int kWalkUnroll = OHMHIP_WALK_UNROLL;  ///< walk steps per loop trip (
 /// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
 /// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every iteration
 /// of an active lane is a miss.
-/// kTraversal: also accumulate the ray length inside every visited voxel (traversal layer, ohm/RayMapperOccupancy.cpp:
-/// 166-173).  That needs the exact fp64 time of every step, so these instantiations run the reference's fp64 step for
-/// every lane instead of the fixed-point predictor.  The lengths of a batch are summed exactly (integer atomics on a
-/// fixed-point accumulator, applied by applyCounts): deterministic, and equal to the CPU's ray-by-ray float sum up to
-/// that sum's own rounding (the tests hold it to 1e-5 relative).
 /// kTrace: development instrumentation (OHMHIP_DEBUG_FLAGS 64 / 128): per-chunk time stamps and loop counters.  Compiled
 /// out of the production instantiations.
-template <bool kSpecial, bool kTraversal, bool kTrace>
+template <bool kSpecial, bool kTrace>
 __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -2185,7 +2177,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     uint2 *queue = l_queues + wave * kQueueCap;
     const int dimx = mc.dim[0];
     const int dimxy = mc.dim[0] * mc.dim[1];
-    const double inf = dInf();
     const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
     const int ray_shift = args.ray_shift;
     const int refill_min_idle = args.refill_min_idle;
@@ -2201,12 +2192,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     uint32_t ray = 0;
     uint32_t skip = 0;      // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
     uint32_t end_last = 0;  // kSpecial only: the segment's last voxel is the ray's end voxel
-    // kTraversal only: the reference's fp64 walk state.
-    double i0 = 0, i1 = 0, i2 = 0, e0 = 0, e1 = 0, e2 = 0;  // initial exit time / step delta per axis
-    double t0 = 0, t1 = 0, t2 = 0;                          // time_next per axis
-    int k0 = 0, k1 = 0, k2 = 0, tot0 = 0, tot1 = 0, tot2 = 0;  // steps taken / steps in the whole ray per axis
-    double t_enter = 0;     // range at which the current voxel was entered
-    double ray_len = 0;     // kSpecial: exit range of the end voxel
     uint32_t qcount = 0;     // wave-uniform
     bool exhausted = false;  // wave-uniform
     uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0, dbg_slow = 0;  // wave-uniform (kTrace)
@@ -2274,31 +2259,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
             skip = (rb.w & kSegSkipFirst) ? 1u : 0u;
             end_last = (rb.w & kSegEnd) ? 1u : 0u;
           }
-          if (kTraversal)
-          {
-            const RayWalk rw = args.walks[ray];
-            stepsAtVoxel(mc, rw, region_x, region_y, region_z, va >> 1, k0, k1, k2);
-            i0 = rw.init[0];
-            i1 = rw.init[1];
-            i2 = rw.init[2];
-            e0 = rw.delta[0];
-            e1 = rw.delta[1];
-            e2 = rw.delta[2];
-            tot0 = rw.total[0];
-            tot1 = rw.total[1];
-            tot2 = rw.total[2];
-            t0 = timeNext(i0, e0, k0, tot0);
-            t1 = timeNext(i1, e1, k1, tot1);
-            t2 = timeNext(i2, e2, k2, tot2);
-            // The step which entered this region is the latest step taken so far.
-            double te = (k0 > 0) ? stepTime(i0, e0, k0) : 0.0;
-            const double te1 = (k1 > 0) ? stepTime(i1, e1, k1) : 0.0;
-            const double te2 = (k2 > 0) ? stepTime(i2, e2, k2) : 0.0;
-            te = (te1 > te) ? te1 : te;
-            te = (te2 > te) ? te2 : te;
-            t_enter = te;
-            ray_len = rw.length;
-          }
           left = refill_only ? 0 : left;
         }
         if (!prefetched)
@@ -2351,47 +2311,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         }
 
         int stride;
-        if (kTraversal)
-        {
-          const bool active = left > 0;
-          // exit range of this voxel == time of the next step (the ray's length at its end voxel)
-          const double tm01 = (t0 < t1) ? t0 : t1;
-          double t_exit = (tm01 < t2) ? tm01 : t2;
-          if (kSpecial)
-          {
-            t_exit = at_end ? ray_len : t_exit;
-          }
-          if (visit)
-          {
-            // (the CPU mapper adds float(exit - enter), ohm/RayMapperOccupancy.cpp:166-173: that float is what is summed)
-            atomicAdd(&args.traversal_acc[size_t(chunk.slot) * size_t(mc.region_voxels) + (va >> 1)],
-                      (unsigned long long)(double(float(t_exit - t_enter)) * kTraversalScale));
-          }
-          t_enter = active ? t_exit : t_enter;
-          // ---- the reference's fp64 step, branch free, taken by every lane (an idle lane's state is dead, and the
-          // ---- step after a segment's last voxel is never used).  walkSelectNextAxis (ohm/LineWalkCompute.h:282-289):
-          // ---- ties go to the higher axis.  time_next is recomputed from the step count, never accumulated (:299-301).
-          const unsigned long long m01 = __builtin_amdgcn_fcmp(t0, t1, kFcmpOlt);
-          const double t01 = selectD(m01, t0, t1);
-          const unsigned long long m2 = __builtin_amdgcn_fcmp(t01, t2, kFcmpOlt);
-          const unsigned long long a0 = m2 & m01;
-          const unsigned long long a1 = m2 & ~m01;
-          const unsigned long long a2 = ~m2;
-          k0 = addMask(k0, a0);
-          k1 = addMask(k1, a1);
-          k2 = addMask(k2, a2);
-          const unsigned long long g0 = __builtin_amdgcn_sicmp(k0, tot0, kIcmpSlt);
-          const unsigned long long g1 = __builtin_amdgcn_sicmp(k1, tot1, kIcmpSlt);
-          const unsigned long long g2 = __builtin_amdgcn_sicmp(k2, tot2, kIcmpSlt);
-          const double n0 = selectD(g0, i0 + e0 * double(k0), inf);
-          const double n1 = selectD(g1, i1 + e1 * double(k1), inf);
-          const double n2 = selectD(g2, i2 + e2 * double(k2), inf);
-          t0 = selectD(a0, n0, t0);
-          t1 = selectD(a1, n1, t1);
-          t2 = selectD(a2, n2, t2);
-          stride = selectI(a2, sz, selectI(a0, sx, sy));
-        }
-        else
         {
           // ---- one walk step from the fixed-point predictor (see Segment), taken by every lane.  The smallest
           // ---- candidate is trusted when it lies inside the region's range (below kFixMaxDelta) and leads the second
@@ -2991,7 +2910,7 @@ __device__ inline void applyCounts(uint32_t region_index, const MapConst &mc, co
   }
   if (traversal_acc)
   {
-    // This batch's ray lengths through the region's voxels (k_region_walk<.., kTraversal>), summed exactly.
+    // This batch's ray lengths through the region's voxels (k_region_traversal, traversal_kernels.h), summed exactly.
     for (uint32_t vi = threadIdx.x; vi < uint32_t(mc.region_voxels); vi += blockDim.x)
     {
       const unsigned long long sum = traversal_acc[base + vi];

@@ -5,6 +5,7 @@
 
 #include "occupancy_kernels.h"
 #include "replay_kernels.h"
+#include "traversal_kernels.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -1212,7 +1213,6 @@ struct BatchRun
         wa.ray_flags = ray_flags;
         const bool trace = (m->debug_flags & (16u | 64u | 128u)) != 0;
         wa.dbg_counters = trace ? m->d_dbg : nullptr;
-        wa.traversal_acc = sec.traversal ? m->d_traversal_acc : nullptr;
         wa.chunk_cursor = batchEventCount(m) + 1;
         wa.n_chunks = info.n_chunks;
         // A repeated walk (NDT / TSDF event list overflow) must not apply anything twice: single-chunk regions were
@@ -1224,34 +1224,39 @@ struct BatchRun
                           !sec.incident && !m->layers[OHMHIP_LID_INTENSITY] && !m->layers[OHMHIP_LID_HIT_MISS]) ?
                            1 :
                            0;
-        const bool walk_traversal = sec.traversal != nullptr && walk_attempt == 0;
-        // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited) or the
-        // traversal layer needs the exit range of an end voxel that is part of the walk.  (An end voxel that is walked --
-        // kRfEndPointAsFree, clipped rays, TSDF -- is simply one more voxel of the ray's last segment.)
-        const bool end_walked = (ray_flags & OHMHIP_RF_END_POINT_AS_FREE) || m->mc.filter_mode == OHMHIP_FILTER_CLIP ||
-                                m->mc.batch_filter_flags != nullptr;
-        const bool special = (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) || (walk_traversal && end_walked);
+        // Traversal layer: its own fp64 pass over the chunk list after the count walk (traversal_kernels.h).
+        const bool traversal_pass = sec.traversal != nullptr && walk_attempt == 0;
+        // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited).  (An end
+        // voxel that is walked -- kRfEndPointAsFree, clipped rays, TSDF -- is simply one more voxel of the ray's last
+        // segment.)
+        const bool special = (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) != 0;
         const dim3 wgrid(std::min<uint32_t>(info.n_chunks, m->walk_workgroups)), wblock(kWalkThreads);
         const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments);
-        if (special && walk_traversal)
+        if (special)
         {
-          hipLaunchKernelGGL((k_region_walk<true, true, false>), wgrid, wblock, wlds, s, wa);
-        }
-        else if (special)
-        {
-          hipLaunchKernelGGL((k_region_walk<true, false, false>), wgrid, wblock, wlds, s, wa);
-        }
-        else if (walk_traversal)
-        {
-          hipLaunchKernelGGL((k_region_walk<false, true, false>), wgrid, wblock, wlds, s, wa);
+          hipLaunchKernelGGL((k_region_walk<true, false>), wgrid, wblock, wlds, s, wa);
         }
         else if (trace)
         {
-          hipLaunchKernelGGL((k_region_walk<false, false, true>), wgrid, wblock, wlds, s, wa);
+          hipLaunchKernelGGL((k_region_walk<false, true>), wgrid, wblock, wlds, s, wa);
         }
         else
         {
-          hipLaunchKernelGGL((k_region_walk<false, false, false>), wgrid, wblock, wlds, s, wa);
+          hipLaunchKernelGGL((k_region_walk<false, false>), wgrid, wblock, wlds, s, wa);
+        }
+        if (traversal_pass)
+        {
+          TraversalArgs ta;
+          ta.mc = m->mc;
+          ta.chunks = wa.chunks;
+          ta.segments = wa.segments;
+          ta.walks = wa.walks;
+          ta.slot_keys = m->d_slot_keys;
+          ta.traversal_acc = m->d_traversal_acc;
+          ta.unit_bits = traversalUnitBits(m->mc.resolution);
+          ta.refill_min_idle = 16;  // (8: +8 %, 32: the same, measured on C1)
+          hipLaunchKernelGGL(k_region_traversal, dim3(info.n_chunks), dim3(kWalkThreads), traversalLdsBytes(m->mc), s,
+                             ta);
         }
         OHMHIP_CHECK(hipEventRecord(tev[3], s));
         if (occupancy_mode)
@@ -1798,17 +1803,20 @@ try
     m->chunk_segments /= 2;
   }
   const size_t lds_bytes = walkLdsBytes(mc, m->chunk_segments);
-  const void *walk_kernels[5] = { reinterpret_cast<const void *>(k_region_walk<false, false, false>),
-                                  reinterpret_cast<const void *>(k_region_walk<false, true, false>),
-                                  reinterpret_cast<const void *>(k_region_walk<true, false, false>),
-                                  reinterpret_cast<const void *>(k_region_walk<true, true, false>),
-                                  reinterpret_cast<const void *>(k_region_walk<false, false, true>) };
+  const void *walk_kernels[3] = { reinterpret_cast<const void *>(k_region_walk<false, false>),
+                                  reinterpret_cast<const void *>(k_region_walk<true, false>),
+                                  reinterpret_cast<const void *>(k_region_walk<false, true>) };
   for (const void *kernel : walk_kernels)
   {
     if ((err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
     {
       return fail(err);
     }
+  }
+  if ((err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_traversal),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(traversalLdsBytes(mc)))) != 0)
+  {
+    return fail(err);
   }
   if (const char *env = std::getenv("OHMHIP_DEBUG_FLAGS"))
   {
