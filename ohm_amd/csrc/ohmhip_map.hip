@@ -18,6 +18,11 @@
 #include <limits>
 #include <new>
 #include <unordered_map>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -72,6 +77,88 @@ struct DevBuf
 constexpr uint32_t kTimingRing = 32;
 constexpr uint32_t kDirtySync = 1u;   ///< d_dirty bit: modified since the last syncVoxels() (ohmhip_map_clear_dirty)
 constexpr uint32_t kDirtyMerge = 2u;  ///< d_dirty bit: modified since the last replica merge (merge_impl.h)
+
+/// A few host threads that stay around for the life of a map: staging a large host ray block into pinned memory is a
+/// memcpy one core cannot do at PCIe speed, and starting threads per call costs as much as the copy of a small batch.
+class StagePool
+{
+public:
+  explicit StagePool(unsigned n_threads)
+  {
+    for (unsigned i = 0; i < n_threads; ++i)
+    {
+      threads_.emplace_back([this, i] { loop(i); });
+    }
+  }
+  ~StagePool()
+  {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      stop_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto &t : threads_)
+    {
+      t.join();
+    }
+  }
+  unsigned size() const { return unsigned(threads_.size()); }
+  /// Start job(worker index) on the first `n_workers` threads; returns at once.
+  void start(unsigned n_workers, std::function<void(unsigned)> job)
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    job_ = std::move(job);
+    active_ = std::min<unsigned>(n_workers, size());
+    running_ = active_;
+    ++generation_;
+    cv_work_.notify_all();
+  }
+  /// Block until every worker of the last start() has returned.
+  void wait()
+  {
+    std::unique_lock<std::mutex> lock(mu_);
+    cv_done_.wait(lock, [this] { return running_ == 0; });
+  }
+
+private:
+  void loop(unsigned index)
+  {
+    uint64_t seen = 0;
+    for (;;)
+    {
+      std::function<void(unsigned)> job;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_work_.wait(lock, [&] { return stop_ || generation_ != seen; });
+        if (stop_)
+        {
+          return;
+        }
+        seen = generation_;
+        if (index >= active_)
+        {
+          continue;
+        }
+        job = job_;
+      }
+      job(index);
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (--running_ == 0)
+        {
+          cv_done_.notify_all();
+        }
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::function<void(unsigned)> job_;
+  uint64_t generation_ = 0;
+  unsigned active_ = 0, running_ = 0;
+  bool stop_ = false;
+};
 
 struct ohmhip_map_s
 {
@@ -163,7 +250,9 @@ struct ohmhip_map_s
     hipEvent_t uploaded = nullptr;  ///< H2D copies done (copy stream)
     hipEvent_t done = nullptr;      ///< the batch reading the device copies has finished (compute stream)
     bool in_flight = false;
+    bool rays_uploaded = false;     ///< the rays' H2D copies were queued piece by piece while the block was staged
   } ray_slots[2];
+  std::unique_ptr<StagePool> stage_pool;  ///< created by the first large host batch
   int fill_slot = 0;
   size_t pending_rays = 0;
   size_t pending_calls = 0;
@@ -1536,8 +1625,12 @@ int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
   }
   else
   {
-    OHMHIP_CHECK(sl.d_rays.ensure(n * 48, false, m->stream));
-    OHMHIP_CHECK(hipMemcpyAsync(sl.d_rays.ptr, slotRays(sl), n * 48, hipMemcpyHostToDevice, m->copy_stream));
+    if (!sl.rays_uploaded)
+    {
+      OHMHIP_CHECK(sl.d_rays.ensure(n * 48, false, m->stream));
+      OHMHIP_CHECK(hipMemcpyAsync(sl.d_rays.ptr, slotRays(sl), n * 48, hipMemcpyHostToDevice, m->copy_stream));
+    }
+    sl.rays_uploaded = false;
     if (m->pending_times)
     {
       OHMHIP_CHECK(sl.d_times.ensure(n * 8, false, m->stream));
@@ -2245,55 +2338,133 @@ size_t copyRaysCountInRange(double *dst, const double *rays, size_t n_rays, doub
   return passed;
 }
 
-/// Stage a host ray block into the pinned slot and count the rays the filter accepts in the same sweep: the block is
-/// cut into pieces that stay in the core's L2 between the copy and the count, and large blocks are shared between a
-/// few threads (one core copies ~10 GB/s; PCIe Gen5 takes ~55).
-size_t stageRaysAndCount(const MapConst &mc, char *dst, const double *rays, size_t n_rays, bool caller_filtered)
+/// Copy rays [first, last) of a host block into the pinned block at `dst` and count the rays the filter accepts in the
+/// same sweep: the range is cut into pieces that stay in the core's L2 between the copy and the count.
+size_t stageRayRange(const MapConst &mc, char *dst, const double *rays, size_t first, size_t last, bool caller_filtered)
 {
-  static constexpr size_t kPiece = 4096;            // rays per copy+count piece (192 KiB)
-  static constexpr size_t kPerThread = size_t(1) << 16;  // rays before another thread is worth starting
+  static constexpr size_t kPiece = 4096;  // rays per copy+count piece (192 KiB)
   const double range2 = mc.filter_range * mc.filter_range;
-  const bool in_range_only =
-    !caller_filtered && mc.filter_mode == OHMHIP_FILTER_GOOD && mc.filter_range > 0 && std::isfinite(range2);
-  auto run = [&mc, dst, rays, caller_filtered, in_range_only, range2](size_t first, size_t last) {
-    if (in_range_only)
-    {
-      return copyRaysCountInRange(reinterpret_cast<double *>(dst + first * 48), rays + first * 6, last - first, range2);
-    }
-    size_t passed = 0;
-    for (size_t at = first; at < last; at += kPiece)
-    {
-      const size_t n = std::min<size_t>(kPiece, last - at);
-      std::memcpy(dst + at * 48, rays + at * 6, n * 48);
-      passed += hostFilterCount(mc, rays + at * 6, n, caller_filtered);
-    }
-    return passed;
-  };
-  const unsigned n_threads = unsigned(std::min<size_t>(4, n_rays / kPerThread));
-  if (n_threads <= 1)
+  if (!caller_filtered && mc.filter_mode == OHMHIP_FILTER_GOOD && mc.filter_range > 0 && std::isfinite(range2))
   {
-    return run(0, n_rays);
+    return copyRaysCountInRange(reinterpret_cast<double *>(dst + first * 48), rays + first * 6, last - first, range2);
   }
-  const size_t part = (n_rays + n_threads - 1) / n_threads;
-  std::vector<size_t> counts(n_threads, 0);
-  std::vector<std::thread> workers;
-  for (unsigned t = 1; t < n_threads; ++t)
-  {
-    workers.emplace_back([&counts, &run, t, part, n_rays] {
-      counts[t] = run(std::min(n_rays, t * part), std::min(n_rays, (t + 1) * part));
-    });
-  }
-  counts[0] = run(0, std::min(n_rays, part));
   size_t passed = 0;
-  for (unsigned t = 0; t < n_threads; ++t)
+  for (size_t at = first; at < last; at += kPiece)
   {
-    if (t)
-    {
-      workers[t - 1].join();
-    }
-    passed += counts[t];
+    const size_t n = std::min<size_t>(kPiece, last - at);
+    std::memcpy(dst + at * 48, rays + at * 6, n * 48);
+    passed += hostFilterCount(mc, rays + at * 6, n, caller_filtered);
   }
   return passed;
+}
+
+constexpr unsigned kStageThreads = 8;                  // pool threads of a map (one core copies ~10 GB/s; PCIe Gen5 takes ~55)
+constexpr size_t kStagePerThread = size_t(1) << 16;    // rays before another thread is worth waking
+constexpr size_t kUploadPiece = size_t(1) << 15;       // rays per host-to-device copy of a staged block (1.5 MiB)
+
+StagePool &stagePool(ohmhip_map_t m)
+{
+  if (!m->stage_pool)
+  {
+    m->stage_pool.reset(new StagePool(kStageThreads));
+  }
+  return *m->stage_pool;
+}
+
+/// Stage a host ray block into the pinned slot and count the rays the filter accepts; large blocks are shared between
+/// the map's pool threads and the caller.
+size_t stageRaysAndCount(ohmhip_map_t m, char *dst, const double *rays, size_t n_rays, bool caller_filtered)
+{
+  const MapConst &mc = m->mc;
+  const unsigned n_workers = unsigned(std::min<size_t>(kStageThreads, n_rays / kStagePerThread));
+  if (n_workers <= 1)
+  {
+    return stageRayRange(mc, dst, rays, 0, n_rays, caller_filtered);
+  }
+  const size_t n_pieces = (n_rays + kUploadPiece - 1) / kUploadPiece;
+  std::atomic<size_t> next(0), passed(0);
+  auto work = [&](unsigned) {
+    for (size_t p = next.fetch_add(1); p < n_pieces; p = next.fetch_add(1))
+    {
+      passed.fetch_add(stageRayRange(mc, dst, rays, p * kUploadPiece, std::min(n_rays, (p + 1) * kUploadPiece),
+                                     caller_filtered));
+    }
+  };
+  StagePool &pool = stagePool(m);
+  pool.start(n_workers - 1, work);
+  work(0);
+  pool.wait();
+  return passed.load();
+}
+
+/// The same for a block that is a device batch on its own, with the rays' host-to-device copies queued piece by piece
+/// as the pieces are staged: the PCIe transfer runs beside the staging of the rest, not after it (a 1 M-ray call was
+/// stage 1.2 ms, then copy 1.0 ms; the flush that follows finds RaySlot::rays_uploaded set).
+int stageRaysAndUpload(ohmhip_map_t m, ohmhip_map_s::RaySlot &sl, const double *rays, size_t n_rays,
+                       bool caller_filtered, size_t *passed_out)
+{
+  const MapConst &mc = m->mc;
+  OHMHIP_CHECK(sl.d_rays.ensure(n_rays * 48, false, m->stream));
+  char *dst = slotRays(sl);
+  char *d_dst = static_cast<char *>(sl.d_rays.ptr);
+  const size_t n_pieces = (n_rays + kUploadPiece - 1) / kUploadPiece;
+  std::unique_ptr<std::atomic<unsigned char>[]> done(new std::atomic<unsigned char>[n_pieces]);
+  for (size_t p = 0; p < n_pieces; ++p)
+  {
+    done[p].store(0, std::memory_order_relaxed);
+  }
+  std::atomic<size_t> next(0), passed(0);
+  auto stage_piece = [&](size_t p) {
+    passed.fetch_add(stageRayRange(mc, dst, rays, p * kUploadPiece, std::min(n_rays, (p + 1) * kUploadPiece),
+                                   caller_filtered));
+    done[p].store(1, std::memory_order_release);
+  };
+  auto work = [&](unsigned) {
+    for (size_t p = next.fetch_add(1); p < n_pieces; p = next.fetch_add(1))
+    {
+      stage_piece(p);
+    }
+  };
+  StagePool &pool = stagePool(m);
+  pool.start(unsigned(std::min<size_t>(kStageThreads, std::max<size_t>(1, n_pieces / 2))), work);
+  // The caller sends what is staged, in order, and stages pieces itself while nothing is ready to go.
+  hipError_t copy_err = hipSuccess;
+  for (size_t p = 0; p < n_pieces;)
+  {
+    if (!done[p].load(std::memory_order_acquire))
+    {
+      const size_t q = next.fetch_add(1);
+      if (q < n_pieces)
+      {
+        stage_piece(q);
+      }
+      else
+      {
+        while (!done[p].load(std::memory_order_acquire))
+        {
+          std::this_thread::yield();
+        }
+      }
+      continue;
+    }
+    size_t e = p + 1;
+    while (e < n_pieces && e - p < 8 && done[e].load(std::memory_order_acquire))
+    {
+      ++e;
+    }
+    const size_t first = p * kUploadPiece, last = std::min(n_rays, e * kUploadPiece);
+    if (copy_err == hipSuccess)
+    {
+      copy_err = hipMemcpyAsync(d_dst + first * 48, dst + first * 48, (last - first) * 48, hipMemcpyHostToDevice,
+                                m->copy_stream);
+    }
+    p = e;
+  }
+  pool.wait();  // (the workers hold references to this frame)
+  OHMHIP_CHECK(copy_err);
+  sl.rays_uploaded = true;
+  *passed_out = passed.load();
+  return OHMHIP_OK;
 }
 
 int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, const float *intensities,
@@ -2346,8 +2517,17 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
   // A call that is a device batch on its own gets the count from the device (k_ray_setup counts what its filter passes
   // and the batch summary reaches the host inside this call anyway); calls that share a batch are counted here.
   const bool device_counts = m->pending_rays == 0 && (!coalesce || n_rays >= m->coalesce_min_rays);
-  const size_t passed = stageRaysAndCount(m->mc, slotRays(sl) + m->pending_rays * 48, rays, n_rays,
-                                          filter_flags != nullptr || device_counts);
+  size_t passed = 0;
+  const auto t_stage = std::chrono::steady_clock::now();
+  if (device_counts && n_rays >= 4 * kUploadPiece)
+  {
+    OHMHIP_CHECK(stageRaysAndUpload(m, sl, rays, n_rays, true, &passed));
+  }
+  else
+  {
+    passed = stageRaysAndCount(m, slotRays(sl) + m->pending_rays * 48, rays, n_rays,
+                               filter_flags != nullptr || device_counts);
+  }
   if (timestamps)
   {
     std::memcpy(slotTimes(sl) + m->pending_rays * 8, timestamps, n_rays * 8);
@@ -2378,7 +2558,15 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
   {
     return OHMHIP_OK;  // deferred: runs with the following calls' rays, or as soon as anything observes the map
   }
+  const auto t_flush = std::chrono::steady_clock::now();
   err = flushPendingRays(m, device_counts ? integrated : nullptr);
+  if (m->debug_flags & 2048u)
+  {
+    const auto t_end = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[ohmhip dbg] host batch of %zu rays: staged (+ upload queued) %.3f ms, launched %.3f ms\n", n_rays,
+                 std::chrono::duration<double, std::milli>(t_flush - t_stage).count(),
+                 std::chrono::duration<double, std::milli>(t_end - t_flush).count());
+  }
   if (err != OHMHIP_OK && integrated)
   {
     *integrated = 0;
@@ -2892,26 +3080,27 @@ try
     if (pending_n[b])
     {
       OHMHIP_CHECK(hipEventSynchronize(done[b]));
-      // The host-side scatter into the callers' blocks is memory-bandwidth work: a few threads share a large burst.
+      // The host-side scatter into the callers' blocks is memory-bandwidth work: the map's pool threads share a large
+      // burst (one core copies ~10 GB/s, the link delivers ~50).
       const size_t n = pending_n[b];
-      const size_t workers = (n * stride >= (size_t(4) << 20)) ? 4 : 1;
-      if (workers == 1)
+      const size_t workers = std::min<size_t>(kStageThreads, (n * stride) >> 20);
+      if (workers <= 1)
       {
         scatter(b, 0, n);
       }
       else
       {
-        std::vector<std::thread> pool;
-        const size_t per = (n + workers - 1) / workers;
-        for (size_t w = 1; w < workers; ++w)
-        {
-          pool.emplace_back(scatter, b, std::min(n, w * per), std::min(n, (w + 1) * per));
-        }
-        scatter(b, 0, std::min(n, per));
-        for (auto &t : pool)
-        {
-          t.join();
-        }
+        std::atomic<size_t> next(0);
+        auto work = [&](unsigned) {
+          for (size_t k = next.fetch_add(1); k < n; k = next.fetch_add(1))
+          {
+            scatter(b, k, k + 1);
+          }
+        };
+        StagePool &pool = stagePool(m);
+        pool.start(unsigned(workers - 1), work);
+        work(0);
+        pool.wait();
       }
       pending_n[b] = 0;
     }

@@ -1,10 +1,9 @@
 #!/bin/bash
-# Usage (on the GPU box): scripts/ab_trav.sh <tag>[:IDLE] ...  -- k_region_traversal time per library variant / refill threshold
+# Usage (on the GPU box): scripts/ab_trav.sh <tag> ...  -- k_region_traversal time per library variant (scripts/build_variant.sh)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 for SPEC in "$@"; do
-  TAG=${SPEC%%:*}; IDLE=${SPEC#*:}
-  if [ "$IDLE" = "$SPEC" ]; then unset OHMHIP_TRAV_IDLE; else export OHMHIP_TRAV_IDLE=$IDLE; fi
+  TAG=$SPEC
   if [ "$TAG" = "default" ]; then unset OHMHIP_LIB; else export OHMHIP_LIB=$PWD/ohm_amd/lib/variants/libohmhip_$TAG.so; fi
   echo "== $SPEC"
   timeout 250 scripts/prof_cmd.sh scripts/traversal_probe.py < /dev/null 2>&1 | grep -E "k_region_traversal|traversal:"
