@@ -208,3 +208,28 @@ def test_small_device_pointer_batches_are_collected_and_report_their_own_counts(
     assert gm2.integrateRaysDevice(p2, 2 * 4096) == 2 * 4096 - 2
     assert gm2.stats()["rays_in"] == 4096
     L.lib.ohmhip_buffer_destroy(buf)
+
+
+@pytest.mark.parametrize("n", [4 * 32768, 4 * 32768 + 1, 200_001, 9 * 32768 - 1])
+def test_large_host_batches_are_uploaded_piece_by_piece(gpu, n):
+    """A host call that is a device batch on its own is staged by the map's pool threads in 32 768-ray pieces, each
+    piece's host-to-device copy queued as soon as it is staged (stageRaysAndUpload).  Ragged sizes around the piece
+    boundaries, rejected rays in the first, a middle and the last piece, optional arrays, and the caller's buffer
+    reused at once: bit exact against the oracle, counts reported by the call."""
+    layers = ("occupancy", "mean", "touch_time")
+    map_ = OccupancyMap(0.1, layers=layers)
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    scratch = np.empty((2 * n, 3), dtype=np.float64)
+    for k in range(3):
+        rays = synth.rays_c1(n=n, max_range=9.0, seed=700 + k, first=17 * k)
+        ts = 50.0 + k + 1e-6 * np.arange(n, dtype=np.float64)
+        bad = [5, 32768 + 9, n - 1] if k != 1 else []
+        for i in bad:
+            rays[2 * i + 1, k % 3] = np.nan
+        scratch[:] = rays
+        assert gm.integrateRays(scratch, timestamps=ts) == 2 * (n - len(bad))
+        scratch[:] = np.nan  # the library must have taken its copy already
+        om.integrate_occupancy(rays, timestamps=ts)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
