@@ -234,6 +234,16 @@ int ohmhip_map_integrate_rays_filtered(ohmhip_map_t map, const double *rays, siz
  * the arithmetic the device uses.  An error of a deferred batch (pool exhausted ...) surfaces at the call that launches
  * it.  Default min_rays: 65536; 0 launches every call's batch in that call. */
 int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
+/* Large host batches, opt-in: with enable != 0 a host-pointer call that is a device batch on its own returns as soon
+ * as its rays are staged and their upload is queued; the device launch sequence -- which waits for the batch's plan
+ * summary in its middle -- runs on a thread the map owns, so the caller stages its next block, and the link carries it,
+ * beside that wait (1 M-ray calls: 1.4 -> ~1.1 ms).  The reference's GpuMap::integrateRays returns with
+ * its GPU work in flight in the same way (ohmgpu/GpuMap.cpp:874).  What changes for the caller: *integrated is the
+ * host's evaluation of the ray filter (the same verdict), and an error of the batch (OHMHIP_ERR_CAPACITY ...) is
+ * returned by the NEXT call on the map that settles it -- any entry point but the staging part of integrate_rays; the
+ * rays of the call that reports it stay queued.  Everything that observes the map waits for the launch first, so
+ * results do not depend on the setting.  Default: off. */
+int ohmhip_map_set_async_launch(ohmhip_map_t map, int enable);
 /* Same with rays (and optional intensities/timestamps) already resident in device memory.  The arrays must be COMPLETE
  * when the call is made (not merely enqueued on some stream): the map reads them on streams of its own.  Calls below
  * the coalescing threshold are collected like small host batches (round 3): their arrays are copied device to device

@@ -137,6 +137,7 @@ _sigs = {
                                                     C.POINTER(C.c_size_t)]),
     "ohmhip_map_update_config": (C.c_int, [_vp, C.POINTER(MapConfig)]),
     "ohmhip_map_set_batch_coalescing": (C.c_int, [_vp, C.c_size_t]),
+    "ohmhip_map_set_async_launch": (C.c_int, [_vp, C.c_int]),
     "ohmhip_map_set_region_ownership": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_int]),
     "ohmhip_region_owner": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_uint32, _vp]),
     "ohmhip_map_cache_stats": (C.c_int, [_vp, C.POINTER(CacheStats), C.c_int]),

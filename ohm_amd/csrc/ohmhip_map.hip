@@ -253,6 +253,12 @@ struct ohmhip_map_s
     bool rays_uploaded = false;     ///< the rays' H2D copies were queued piece by piece while the block was staged
   } ray_slots[2];
   std::unique_ptr<StagePool> stage_pool;  ///< created by the first large host batch
+  /// ohmhip_map_set_async_launch: a host batch's device launch sequence (with its host round trip for the plan) runs on
+  /// this one thread while the caller returns and stages its next block.
+  bool async_launch = false;
+  std::unique_ptr<StagePool> launch_thread;
+  bool launch_busy = false;
+  int launch_result = OHMHIP_OK;
   int fill_slot = 0;
   size_t pending_rays = 0;
   size_t pending_calls = 0;
@@ -1601,9 +1607,24 @@ int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_cou
                         const unsigned char *d_filter_flags = nullptr);
 int validateBatchRequest(ohmhip_map_t m, unsigned ray_flags);
 
+/// Wait for the launch thread to finish the batch handed to it (ohmhip_map_set_async_launch) and collect its status.
+int settleLaunch(ohmhip_map_t m)
+{
+  if (!m->launch_busy)
+  {
+    return OHMHIP_OK;
+  }
+  m->launch_thread->wait();
+  m->launch_busy = false;
+  const int err = m->launch_result;
+  m->launch_result = OHMHIP_OK;
+  return err;
+}
+
 /// Launch what the filling slot holds: H2D on the copy stream, the batch on the compute stream behind it.
 int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
 {
+  OHMHIP_CHECK(settleLaunch(m));  // (one batch at a time is being launched; its error surfaces here)
   const size_t n = m->pending_rays;
   if (n == 0)
   {
@@ -1653,6 +1674,31 @@ int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
   OHMHIP_CHECK(hipEventRecord(sl.uploaded, m->copy_stream));
   OHMHIP_CHECK(hipStreamWaitEvent(m->stream, sl.uploaded, 0));
   OHMHIP_CHECK(hipStreamWaitEvent(m->front_stream, sl.uploaded, 0));  // (the set-up pass reads the rays first)
+  if (m->async_launch && !on_device && !integrated)
+  {
+    // The launch sequence blocks on the batch's plan summary in its middle: it runs on the launch thread, the caller
+    // goes on (typically to stage its next block into the other slot, whose upload then runs beside this wait).
+    if (!m->launch_thread)
+    {
+      m->launch_thread.reset(new StagePool(1));
+    }
+    ohmhip_map_s::RaySlot *slot = &sl;
+    const double *d_r = static_cast<const double *>(sl.d_rays.ptr);
+    const unsigned flags = m->pending_flags;
+    sl.in_flight = true;
+    m->fill_slot ^= 1;
+    m->launch_busy = true;
+    m->launch_thread->start(1, [m, slot, d_r, n, d_int, d_ts, flags, d_ff](unsigned) {
+      int err = int(hipSetDevice(m->device));
+      if (err == 0)
+      {
+        err = integrateRaysDevice(m, d_r, n * 2, d_int, d_ts, flags, nullptr, d_ff);
+      }
+      const int rec = int(hipEventRecord(slot->done, m->stream));
+      m->launch_result = err ? err : rec;
+    });
+    return OHMHIP_OK;
+  }
   const int err = integrateRaysDevice(m, static_cast<const double *>(sl.d_rays.ptr), n * 2, d_int, d_ts,
                                       m->pending_flags, integrated, d_ff);
   OHMHIP_CHECK(hipEventRecord(sl.done, m->stream));
@@ -1931,6 +1977,7 @@ try
   {
     return OHMHIP_OK;
   }
+  (void)settleLaunch(m);  // (a batch still being launched by the map's thread)
   if (m->stream)
   {
     (void)hipStreamSynchronize(m->stream);
@@ -2427,11 +2474,19 @@ int stageRaysAndUpload(ohmhip_map_t m, ohmhip_map_s::RaySlot &sl, const double *
   };
   StagePool &pool = stagePool(m);
   pool.start(unsigned(std::min<size_t>(kStageThreads, std::max<size_t>(1, n_pieces / 2))), work);
-  // The caller sends what is staged, in order, and stages pieces itself while nothing is ready to go.
+  // The caller sends what is staged, in order, kCopyPieces pieces per copy (a copy call costs ~10 us: 1.5 MiB copies
+  // reach 42 GB/s, 6 MiB and more 55; scripts/probes/h2d_probe.hip), and stages pieces itself while it waits.
+  constexpr size_t kCopyPieces = 4;
   hipError_t copy_err = hipSuccess;
   for (size_t p = 0; p < n_pieces;)
   {
-    if (!done[p].load(std::memory_order_acquire))
+    const size_t want = std::min(n_pieces, p + kCopyPieces);
+    size_t e = p;
+    while (e < want && done[e].load(std::memory_order_acquire))
+    {
+      ++e;
+    }
+    if (e < want)
     {
       const size_t q = next.fetch_add(1);
       if (q < n_pieces)
@@ -2440,15 +2495,14 @@ int stageRaysAndUpload(ohmhip_map_t m, ohmhip_map_s::RaySlot &sl, const double *
       }
       else
       {
-        while (!done[p].load(std::memory_order_acquire))
+        while (!done[e].load(std::memory_order_acquire))
         {
           std::this_thread::yield();
         }
       }
       continue;
     }
-    size_t e = p + 1;
-    while (e < n_pieces && e - p < 8 && done[e].load(std::memory_order_acquire))
+    while (e < n_pieces && e - p < 2 * kCopyPieces && done[e].load(std::memory_order_acquire))
     {
       ++e;
     }
@@ -2516,12 +2570,13 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
   }
   // A call that is a device batch on its own gets the count from the device (k_ray_setup counts what its filter passes
   // and the batch summary reaches the host inside this call anyway); calls that share a batch are counted here.
-  const bool device_counts = m->pending_rays == 0 && (!coalesce || n_rays >= m->coalesce_min_rays);
+  const bool own_batch = m->pending_rays == 0 && (!coalesce || n_rays >= m->coalesce_min_rays);
+  const bool device_counts = own_batch && !m->async_launch;  // (a call that hands its batch to the launch thread counts here)
   size_t passed = 0;
   const auto t_stage = std::chrono::steady_clock::now();
-  if (device_counts && n_rays >= 4 * kUploadPiece)
+  if (own_batch && n_rays >= 4 * kUploadPiece)
   {
-    OHMHIP_CHECK(stageRaysAndUpload(m, sl, rays, n_rays, true, &passed));
+    OHMHIP_CHECK(stageRaysAndUpload(m, sl, rays, n_rays, filter_flags != nullptr || device_counts, &passed));
   }
   else
   {
@@ -2648,6 +2703,19 @@ try
   }
   OHMHIP_SETTLE(m);
   m->coalesce_min_rays = min_rays;
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_set_async_launch(ohmhip_map_t m, int enable)
+try
+{
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);
+  m->async_launch = enable != 0;
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH
@@ -2791,6 +2859,7 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
+  OHMHIP_SETTLE(m);
   m->memory_limit = bytes;
   return OHMHIP_OK;
 }
@@ -3927,6 +3996,7 @@ try
   {
     return OHMHIP_OK;
   }
+  OHMHIP_CHECK(settleLaunch(m));  // (the query shares the map's stream and reads its configuration)
   hipStream_t s = m->stream;
   const size_t key_bytes = sizeof(GpuKeyOut) * line_count * size_t(max_keys_per_line);
   double *d_lines = nullptr;

@@ -429,6 +429,11 @@ class GpuMap(RayMapper):
         (include/ohmhip.h: ohmhip_map_set_batch_coalescing; on by default with 65536).  0 turns it off."""
         L.check(L.lib.ohmhip_map_set_batch_coalescing(self._handle, int(min_rays)), "setBatchCoalescing")
 
+    def setAsyncLaunch(self, enable=True):
+        """Large host-pointer batches return once their rays are staged; the launch sequence runs on a thread of the map
+        (include/ohmhip.h: ohmhip_map_set_async_launch).  Off by default."""
+        L.check(L.lib.ohmhip_map_set_async_launch(self._handle, 1 if enable else 0), "setAsyncLaunch")
+
     def setRegionOwnership(self, world_size, rank, block_shift=0):
         """Owner-computes multi-GPU mode (include/ohmhip.h: ohmhip_map_set_region_ownership): integrate only what falls
         in the regions `rank` owns among `world_size` region-partitioned maps.  Call before the first integrateRays."""

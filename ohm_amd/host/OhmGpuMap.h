@@ -580,6 +580,9 @@ public:
   /// Not in the reference: run consecutive small integrateRays() batches as one device batch of at least @p min_rays
   /// rays (see ohmhip_map_set_batch_coalescing; on by default with 65536); 0 turns it off.
   void setBatchCoalescing(size_t min_rays) { OHMHIP_GPUAPICHECK(ohmhip_map_set_batch_coalescing(handle_, min_rays)); }
+  /// Large host batches return once staged; the launch sequence runs on a thread of the map (see
+  /// ohmhip_map_set_async_launch).  Off by default.
+  void setAsyncLaunch(bool enable) { OHMHIP_GPUAPICHECK(ohmhip_map_set_async_launch(handle_, enable ? 1 : 0)); }
 
   /// Not in the reference (single device): owner-computes multi-GPU mode, see ohmhip_map_set_region_ownership.  The
   /// map integrates only what falls in the regions @p rank owns among @p world_size maps fed the same ray stream.

@@ -77,6 +77,7 @@ def test_null_and_out_of_range_arguments_are_rejected():
     from ohm_amd import _lib as L
     invalid = L.ERR_INVALID_ARG
     assert L.lib.ohmhip_map_set_batch_coalescing(None, 4096) == invalid
+    assert L.lib.ohmhip_map_set_async_launch(None, 1) == invalid
     assert L.lib.ohmhip_map_set_region_ownership(None, 2, 0, 0) == invalid
     assert L.lib.ohmhip_map_integrate_rays(None, None, 0, None, None, 0, None) == invalid
     assert L.lib.ohmhip_map_sync(None) == invalid

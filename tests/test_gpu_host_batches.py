@@ -233,3 +233,63 @@ def test_large_host_batches_are_uploaded_piece_by_piece(gpu, n):
         om.integrate_occupancy(rays, timestamps=ts)
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
+
+
+def test_async_launch_gives_the_same_map_and_counts(gpu):
+    """ohmhip_map_set_async_launch: large host calls return once staged, the launch sequence runs on the map's thread.
+    Mixed with small (collected) calls, device-pointer-free optional arrays, rejected rays and observers in between:
+    bit exact against the oracle, every call reports its own count."""
+    layers = ("occupancy", "mean", "touch_time")
+    map_ = OccupancyMap(0.1, layers=layers)
+    gm = GpuMap(map_)
+    gm.setAsyncLaunch(True)
+    om = make_oracle(map_)
+    sizes = [150_000, 140_000, 3000, 2000, 135_000, 70_000, 200_000]
+    for k, n in enumerate(sizes):
+        rays = synth.rays_c1(n=n, max_range=9.0, seed=900 + k, first=31 * k)
+        ts = 10.0 * k + 1e-6 * np.arange(n, dtype=np.float64)
+        bad = [1, n // 2, n - 2] if k % 2 == 0 else []
+        for i in bad:
+            rays[2 * i + 1, 1] = np.inf
+        assert gm.integrateRays(rays, timestamps=ts) == 2 * (n - len(bad))
+        rays[:] = np.nan  # the library must have taken its copy already
+        if k == 4:
+            assert len(gm.regionKeys()) > 0  # an observer in the middle settles the launch thread first
+    rng_check = [(k, n) for k, n in enumerate(sizes)]
+    for k, n in rng_check:
+        rays = synth.rays_c1(n=n, max_range=9.0, seed=900 + k, first=31 * k)
+        ts = 10.0 * k + 1e-6 * np.arange(n, dtype=np.float64)
+        if k % 2 == 0:
+            for i in (1, n // 2, n - 2):
+                rays[2 * i + 1, 1] = np.inf
+        om.integrate_occupancy(rays, timestamps=ts)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, list(layers), exact_float=True))
+
+
+def test_async_launch_reports_a_failed_batch_at_the_next_call(gpu):
+    """The one change of contract: the batch's error (here: the region pool is full) comes back from the next call that
+    settles the launch, not from the call that presented the rays; the map stays usable and unchanged by the batch."""
+    from ohm_amd import _lib as L
+    map_ = OccupancyMap(0.1, layers=("occupancy",))
+    gm = GpuMap(map_, region_capacity=64)
+    gm.setMemoryLimit(40 * gm.cacheStats()["bytes_per_region"])
+    gm.setAsyncLaunch(True)
+    small = synth.rays_c1(n=140_000, max_range=3.0, seed=5)   # a few regions around the sensor: fits
+    assert gm.integrateRays(small) == small.shape[0]
+    gm.wait()
+    before = len(gm.regionKeys())
+    assert 0 < before <= 40
+    big = synth.rays_c1(n=140_000, max_range=25.0, seed=6)    # hundreds of regions: cannot fit 40
+    assert gm.integrateRays(big) == big.shape[0]              # accepted: staged and handed to the launch thread
+    with pytest.raises(L.OhmHipError) as info:
+        gm.wait()
+    assert info.value.status == L.ERR_CAPACITY
+    assert len(gm.regionKeys()) == before                     # the failed batch left nothing behind
+    assert gm.integrateRays(small) == small.shape[0]          # and the map goes on
+    gm.wait()
+    om = make_oracle(map_)
+    om.integrate_occupancy(small)
+    om.integrate_occupancy(small)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
