@@ -282,8 +282,10 @@ int ohmhip_map_cache_stats(ohmhip_map_t map, ohmhip_cache_stats *stats, int rese
  * ohmgpu/GpuCache.h:90, bounds its cache the same way).  0 removes the limit. */
 int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
 /* SPILL TO HOST (off by default).  With it on, a batch that needs more regions than the memory limit (or the device)
- * allows no longer fails: the least recently used resident regions -- the counterpart of the reference's LRU slot
- * reuse, ohmgpu/GpuLayerCache.cpp:530-584, a quarter of the pool at a time -- are copied to a host store inside the
+ * allows no longer fails: resident regions -- a quarter of the pool at a time; those not expected back soon: least
+ * recently used first, but a region that has been coming back every N batches is kept while its next use is near (a
+ * sweep over a map larger than the pool would otherwise lose every region once per revolution); the counterpart of
+ * the reference's LRU slot reuse, ohmgpu/GpuLayerCache.cpp:530-584 -- are copied to a host store inside the
  * library and dropped from the pool, and the batch is repeated.  A stored region stays part of the map: it is listed by
  * ohmhip_map_regions / _region_count / _dirty_regions, ohmhip_map_read_regions serves it from the store, and it returns
  * to the pool with its content when a later batch reaches it or an upload / ohmhip_map_ensure_regions names it.  Results

@@ -58,7 +58,7 @@ struct BatchScratch
   uint32_t *hit_begin;     ///< [slot_capacity] first sample of the region in the sorted list
   uint32_t *hit_end;       ///< [slot_capacity]
   uint32_t *dirty;         ///< [slot_capacity]
-  uint32_t *last_use;      ///< [slot_capacity] stamp of the last batch that touched the region (spill-to-host: LRU)
+  uint32_t *last_use;      ///< [2 x slot_capacity] use history per slot (touchRegionUse; spill to host)
   uint32_t stamp;          ///< this batch's stamp
   uint32_t *voxel_first_hit;  ///< [slot_capacity * region_voxels] index of a voxel's first sample in the sorted list
   BatchInfo *info;
@@ -758,6 +758,22 @@ __global__ void __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_e
   }
 }
 
+/// A region's use history, two words per pool slot: [0] the stamp of the batch that used it last, [1] the stamp of its
+/// last use BEFORE the current run of consecutive batches (0: none).  last - before = the period a region comes back with
+/// (a sweep that revisits it every N batches), which is what the spill policy predicts its next use from.
+__device__ inline void touchRegionUse(uint32_t *use, uint32_t slot, uint32_t stamp)
+{
+  const uint32_t last = use[2 * size_t(slot)];
+  if (last != stamp)
+  {
+    if (last != 0 && last + 1u != stamp)
+    {
+      use[2 * size_t(slot) + 1] = last;  // back after a gap
+    }
+    use[2 * size_t(slot)] = stamp;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_plan: one block.  Exclusive scan of per-region segment counts over the touched list; build chunk list.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -881,9 +897,9 @@ __global__ void __launch_bounds__(1024)
         // hit_begin + samples.
         bs.hit_begin[slot] = hit_excl;
         bs.hit_end[slot] = hit_excl;
-        // least-recently-used hint (spill to host): also stamped by an attempt the host goes on to reject -- that is
-        // what makes the eviction which follows spare the regions the repeated batch needs
-        bs.last_use[slot] = bs.stamp;
+        // use history (spill to host): also stamped by an attempt the host goes on to reject -- that is what makes
+        // the eviction which follows spare the regions the repeated batch needs
+        touchRegionUse(bs.last_use, slot, bs.stamp);
       }
       if (nchk)
       {
@@ -3008,13 +3024,23 @@ __global__ void __launch_bounds__(256) k_copy_jobs(const CopyJob *__restrict__ j
   }
 }
 
-/// dst[index[i]] = value
-__global__ void k_set_at_u32(uint32_t *dst, const uint32_t *__restrict__ index, size_t count, uint32_t value)
+/// use[2 * index[i]] is touched with `stamp` (touchRegionUse)
+__global__ void k_touch_use_at(uint32_t *use, const uint32_t *__restrict__ index, size_t count, uint32_t stamp)
 {
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
   {
-    dst[index[i]] = value;
+    touchRegionUse(use, index[i], stamp);
+  }
+}
+
+/// pairs = (slot, stamp): the slot's "use before the gap" becomes stamp (a region back from the host store)
+__global__ void k_set_prev_use(uint32_t *use, const uint32_t *__restrict__ pairs, size_t count)
+{
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
+  {
+    use[2 * size_t(pairs[2 * i]) + 1] = pairs[2 * i + 1];
   }
 }
 

@@ -198,7 +198,10 @@ struct ohmhip_map_s
   uint32_t *d_seg_count = nullptr, *d_seg_cursor = nullptr, *d_seg_offset = nullptr, *d_touched_flag = nullptr,
            *d_touched = nullptr;
   uint32_t *d_voxel_first_hit = nullptr, *d_hit_begin = nullptr, *d_hit_end = nullptr, *d_dirty = nullptr;
-  uint32_t *d_last_use = nullptr;  ///< [slot_capacity] batch stamp of a region's last use (k_plan); moves with the slot
+  /// [2 x slot_capacity] per slot: the stamp of the batch that used the region last, and the stamp of the last use before
+  /// the current run of consecutive batches (0: none) -- what the spill policy predicts a region's next use from
+  /// (touchRegionUse, evictColdRegions); moves with the slot
+  uint32_t *d_last_use = nullptr;
   BatchInfo *d_info = nullptr;   ///< three summaries used in turn: k_plan of one batch zeroes the next batch's
   BatchInfo *h_info = nullptr;   ///< pinned, device visible: [0] batch summary (written by k_plan), [1] event count
   BatchInfo *h_info_dev = nullptr;  ///< device address of h_info
@@ -217,6 +220,11 @@ struct ohmhip_map_s
   /// Traversal layer only: per-voxel fixed-point sum of a batch's ray lengths (zero between batches).
   unsigned long long *d_traversal_acc = nullptr;
   DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;
+  DevBuf use_scratch;  ///< (slot, stamp) pairs of re-admitted regions (queueReadmission)
+  /// After how many batches the regions re-admitted lately came back (ring of the last 256): their median stands in as
+  /// the period of regions that have no history of their own yet (evictColdRegions).
+  std::vector<uint32_t> readmit_periods;
+  size_t readmit_period_at = 0;
   DevBuf copy_jobs;  ///< job list of k_copy_jobs (spill to host, compaction)
   DevBuf stop_a, stop_b;  ///< kRfStopOnFirstOccupied: per-ray stop positions (current / candidate)
   uint32_t *d_event_count = nullptr;  ///< per parity: [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count, [3] stop iteration flag
@@ -292,6 +300,7 @@ struct ohmhip_map_s
     /// are single asynchronous copies straight between the pool and the record -- no staging pass on either side.
     char *record = nullptr;
     uint32_t dirty = 0;
+    uint32_t last_use = 0;  ///< stamp of the last batch that used the region before it left the pool
   };
   /// Pinned host store: slabs of fixed-size records, handed out from a free list.
   struct HostStore
@@ -535,10 +544,10 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
     {
       OHMHIP_CHECK(hipMemcpyAsync(new_dirty, m->d_dirty, sizeof(uint32_t) * keep, hipMemcpyDeviceToDevice, s));
     }
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&new_last_use), sizeof(uint32_t) * capacity));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&new_last_use), sizeof(uint32_t) * 2 * capacity));
     if (keep && m->d_last_use)
     {
-      OHMHIP_CHECK(hipMemcpyAsync(new_last_use, m->d_last_use, sizeof(uint32_t) * keep, hipMemcpyDeviceToDevice, s));
+      OHMHIP_CHECK(hipMemcpyAsync(new_last_use, m->d_last_use, sizeof(uint32_t) * 2 * keep, hipMemcpyDeviceToDevice, s));
     }
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_keys), sizeof(unsigned long long) * hash_cap));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_vals), sizeof(uint32_t) * hash_cap));
@@ -684,7 +693,7 @@ int rollbackTable(ohmhip_map_t m)
   {
     // the slots the failed batch handed out go back to the pristine state: no modified flags, no use stamp
     OHMHIP_CHECK(hipMemsetAsync(m->d_dirty + keep, 0, sizeof(uint32_t) * (m->slot_capacity - keep), s));
-    OHMHIP_CHECK(hipMemsetAsync(m->d_last_use + keep, 0, sizeof(uint32_t) * (m->slot_capacity - keep), s));
+    OHMHIP_CHECK(hipMemsetAsync(m->d_last_use + 2 * size_t(keep), 0, sizeof(uint32_t) * 2 * (m->slot_capacity - keep), s));
   }
   OHMHIP_CHECK(hipMemcpyAsync(m->d_n_slots, &keep, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   if (keep)
@@ -3476,8 +3485,8 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
                             reinterpret_cast<char *>(m->d_hit_mask) + mask_row * dst, mask_row });
     jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_dirty + src), reinterpret_cast<char *>(m->d_dirty + dst),
                             sizeof(uint32_t) });
-    jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_last_use + src),
-                            reinterpret_cast<char *>(m->d_last_use + dst), sizeof(uint32_t) });
+    jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_last_use + 2 * size_t(src)),
+                            reinterpret_cast<char *>(m->d_last_use + 2 * size_t(dst)), 2 * sizeof(uint32_t) });
     if (m->d_merge_base)
     {
       jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_merge_base + rv * src),
@@ -3507,7 +3516,7 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
   }
   OHMHIP_CHECK(hipMemsetAsync(reinterpret_cast<char *>(m->d_hit_mask) + mask_row * new_n, 0, mask_row * k, s));
   OHMHIP_CHECK(hipMemsetAsync(m->d_dirty + new_n, 0, sizeof(uint32_t) * k, s));
-  OHMHIP_CHECK(hipMemsetAsync(m->d_last_use + new_n, 0, sizeof(uint32_t) * k, s));
+  OHMHIP_CHECK(hipMemsetAsync(m->d_last_use + 2 * size_t(new_n), 0, sizeof(uint32_t) * 2 * k, s));
   if (m->d_merge_base)
   {
     hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint32_t *>(m->d_merge_base + rv * new_n),
@@ -3559,15 +3568,56 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
     return OHMHIP_ERR_CAPACITY;  // nothing to evict / replica-merge maps keep a base copy per region: not spilled
   }
   const uint32_t k = std::min(std::min(n, std::max(want_free, n / 4u)), std::max(want_free, max_evict));
-  std::vector<uint32_t> stamps(n), dirty(n);
-  OHMHIP_CHECK(hipMemcpy(stamps.data(), m->d_last_use, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> stamps(2 * size_t(n)), dirty(n);
+  OHMHIP_CHECK(hipMemcpy(stamps.data(), m->d_last_use, sizeof(uint32_t) * 2 * n, hipMemcpyDeviceToHost));
   OHMHIP_CHECK(hipMemcpy(dirty.data(), m->d_dirty, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  // Who goes: the regions whose NEXT use is expected to be farthest away.  A region that came back after a gap has a
+  // period (last use - the use before the gap); while it is on schedule (idle for less than two periods) its next use
+  // is predicted at last + period.  Everything else -- never re-used, or overdue -- has no prediction and goes first,
+  // least recently used first: a sensor moving through new space sees plain LRU, a sensor sweeping a map larger than
+  // the pool again and again (the cyclic access LRU is worst at: it evicts exactly what the next calls need) keeps a
+  // fixed part resident and cycles the rest.  The regions of the batch being attempted carry its stamp: always last.
+  const uint32_t now = uint32_t(m->batch_seq + 1u);
+  // A region without a period of its own borrows the one the map's re-admissions show (their median), while it is
+  // younger than that: when regions keep coming back after P batches, one used a moment ago is P batches from its next
+  // use, one used P - 1 batches ago is about to be needed.
+  uint32_t common_period = 0;
+  if (m->readmit_periods.size() >= 16)
+  {
+    std::vector<uint32_t> sorted_periods(m->readmit_periods);
+    std::nth_element(sorted_periods.begin(), sorted_periods.begin() + sorted_periods.size() / 2, sorted_periods.end());
+    common_period = sorted_periods[sorted_periods.size() / 2];
+  }
+  std::vector<uint64_t> rank(n);  // larger = evicted earlier
+  for (uint32_t i = 0; i < n; ++i)
+  {
+    const uint32_t last = stamps[2 * size_t(i)], prev = stamps[2 * size_t(i) + 1];
+    const uint32_t age = now - last;  // (0: in use by the batch being attempted)
+    uint32_t period = (prev != 0 && last > prev) ? last - prev : 0;
+    if (period < 2 && common_period >= 2 && age < common_period)
+    {
+      period = common_period;
+    }
+    if (last == now)
+    {
+      rank[i] = 0;
+    }
+    else if (period >= 2 && age < 2 * period)
+    {
+      const uint32_t next = last + period;               // predicted next use
+      rank[i] = (uint64_t(1) << 32) | uint64_t((next > now) ? next - now : 0u);  // farther away = earlier out
+    }
+    else
+    {
+      rank[i] = (uint64_t(2) << 32) | uint64_t(age);     // no prediction: before all predicted ones, oldest first
+    }
+  }
   std::vector<uint32_t> order(n);
   for (uint32_t i = 0; i < n; ++i)
   {
     order[i] = i;
   }
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return stamps[a] < stamps[b]; });
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rank[a] > rank[b]; });
   const size_t rv = size_t(m->mc.region_voxels);
   const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;  // (transient in occupancy mode: empty between batches)
   // The victims' content goes straight from the pool into pinned store records, all regions and layers by ONE kernel
@@ -3592,6 +3642,7 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
     const uint32_t slot = order[v];
     unpackRegionKey(m->slot_keys_host[slot], &victim_keys[3 * size_t(v)]);
     content[v].dirty = dirty[slot];
+    content[v].last_use = stamps[2 * size_t(slot)];
     content[v].record = takeStoreRecord(m);
     if (!content[v].record)
     {
@@ -3729,7 +3780,7 @@ int makeRoomForNamedRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t coun
     OHMHIP_CHECK(m->merge_slots.ensure(sizeof(uint32_t) * named_resident.size(), false, m->stream));
     OHMHIP_CHECK(hipMemcpy(m->merge_slots.ptr, named_resident.data(), sizeof(uint32_t) * named_resident.size(),
                            hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_set_at_u32, dim3(64), dim3(256), 0, m->stream, m->d_last_use,
+    hipLaunchKernelGGL(k_touch_use_at, dim3(64), dim3(256), 0, m->stream, m->d_last_use,
                        static_cast<const uint32_t *>(m->merge_slots.ptr), named_resident.size(),
                        uint32_t(m->batch_seq + 1u));
     OHMHIP_CHECK(hipStreamSynchronize(m->stream));
@@ -3748,12 +3799,28 @@ int queueReadmission(ohmhip_map_t m, const std::vector<std::pair<uint32_t, ohmhi
   const ohmhip_map_s::HostStore &st = m->store;
   const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;
   std::vector<uint32_t> dirty_slots[4];
+  std::vector<uint32_t> use_pairs;  // (slot, stamp of the region's last use before it left the pool)
+  use_pairs.reserve(back.size() * 2);
   std::vector<CopyJob> jobs;
   jobs.reserve(back.size() * 2);
   for (const auto &entry : back)
   {
     const uint32_t slot = entry.first;
     const char *record = entry.second.record;
+    use_pairs.push_back(slot);
+    use_pairs.push_back(entry.second.last_use);
+    if (entry.second.last_use != 0)
+    {
+      const uint32_t gap = uint32_t(m->batch_seq + 1u) - entry.second.last_use;
+      if (m->readmit_periods.size() < 256)
+      {
+        m->readmit_periods.push_back(gap);
+      }
+      else
+      {
+        m->readmit_periods[m->readmit_period_at++ % 256] = gap;
+      }
+    }
     for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
     {
       if (m->layers[l])
@@ -3770,6 +3837,12 @@ int queueReadmission(ohmhip_map_t m, const std::vector<std::pair<uint32_t, ohmhi
     dirty_slots[entry.second.dirty & (kDirtySync | kDirtyMerge)].push_back(slot);
   }
   OHMHIP_CHECK(launchCopyJobs(m, jobs, m->copy_stream));
+  // The use history comes back with the content: the slot's "use before the gap" is the region's last use before it
+  // left (the slot itself is new: its own last-use stamp is this batch's, or is set by the caller).
+  OHMHIP_CHECK(m->use_scratch.ensure(sizeof(uint32_t) * use_pairs.size(), false, m->copy_stream));
+  OHMHIP_CHECK(hipMemcpy(m->use_scratch.ptr, use_pairs.data(), sizeof(uint32_t) * use_pairs.size(), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_set_prev_use, dim3(64), dim3(256), 0, m->copy_stream, m->d_last_use,
+                     static_cast<const uint32_t *>(m->use_scratch.ptr), back.size());
   // (k_plan may be OR-ing this batch's bits into the same words: atomic ORs, from a persistent index scratch)
   size_t n_index = dirty_slots[1].size() + dirty_slots[2].size() + dirty_slots[3].size();
   if (n_index)
@@ -3907,7 +3980,7 @@ int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count)
   {
     OHMHIP_CHECK(m->merge_slots.ensure(sizeof(uint32_t) * slots.size(), false, m->stream));
     OHMHIP_CHECK(hipMemcpy(m->merge_slots.ptr, slots.data(), sizeof(uint32_t) * slots.size(), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_set_at_u32, dim3(64), dim3(256), 0, m->stream, m->d_last_use,
+    hipLaunchKernelGGL(k_touch_use_at, dim3(64), dim3(256), 0, m->stream, m->d_last_use,
                        static_cast<const uint32_t *>(m->merge_slots.ptr), slots.size(), uint32_t(m->batch_seq + 1u));
     OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   }
