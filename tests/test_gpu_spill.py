@@ -241,3 +241,52 @@ def test_a_rejected_batch_leaves_no_modified_flags(gpu):
     # and a batch that fits afterwards is tracked normally
     assert gm.integrateRays(small) == small.shape[0]
     assert 0 < len(gm.regionKeys(dirty_only=True)) <= n_regions
+
+
+def test_repeated_sweep_keeps_part_of_the_map_resident(gpu):
+    """A sensor sweeping a map larger than the pool again and again is the access pattern plain LRU is worst at: it would
+    evict exactly what the next calls need, every region leaving and returning once per revolution.  The eviction ranks
+    regions by their predicted next use (a region's own return period, or the median of recent re-admissions), so from
+    the second revolution on part of the map stays resident: fewer re-admissions than regions x revolutions -- and the
+    map is the oracle's, bit exact, whatever the policy evicts."""
+    sectors, revolutions, per_sector = 8, 5, 5000
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "mean"))
+    om = make_oracle(map_)
+    rng = np.random.default_rng(2026)
+
+    def sector_rays(j, seed):
+        r = np.random.default_rng(seed)
+        az = (j + r.uniform(0.0, 1.0, per_sector)) * (2.0 * np.pi / sectors)
+        el = r.uniform(-0.2, 0.2, per_sector)
+        length = r.uniform(9.0, 14.0, per_sector)
+        d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=1)
+        rays = np.empty((2 * per_sector, 3), dtype=np.float64)
+        rays[0::2] = np.array([0.013, 0.021, 0.017])
+        rays[1::2] = rays[0::2] + d * length[:, None]
+        return rays
+
+    # how many regions the whole sweep and its largest sector touch (oracle only)
+    probe = make_oracle(OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",)))
+    per_sector_regions = []
+    for j in range(sectors):
+        before = len(probe.chunks())
+        probe.integrate_occupancy(sector_rays(j, 100 + j))
+        per_sector_regions.append(len(probe.chunks()) - before)
+    total = len(probe.chunks())
+    limit = int(0.6 * total)
+    assert limit > 2 * max(per_sector_regions)
+    gm = limited_map(map_, limit)
+    gm.setSpillToHost(True)
+    gm.setBatchCoalescing(0)
+    for rev in range(revolutions):
+        for j in range(sectors):
+            rays = sector_rays(j, 100 + j + 1000 * rev + int(rng.integers(0, 1)))
+            assert gm.integrateRays(rays) == rays.shape[0]
+            om.integrate_occupancy(rays)
+    st = gm.cacheStats()
+    assert st["evictions"] > 0 and st["regions_resident"] <= limit
+    # plain LRU on this cyclic pattern re-admits (nearly) every region once per revolution after the first
+    lru_readmissions = (revolutions - 1) * total
+    assert st["readmissions"] < 0.8 * lru_readmissions, (st["readmissions"], lru_readmissions, total, limit)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
