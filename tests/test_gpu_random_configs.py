@@ -86,3 +86,29 @@ def test_random_geometry_ndt_tsdf(gpu, case):
         assert_parity(compare_maps(om.chunks(), map_.chunks, list(map_.layers), rel=1e-5))
     else:
         assert_parity(compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True))
+
+
+@pytest.mark.parametrize("case", [0, 2, 3, 5])
+def test_random_geometry_traversal(gpu, case):
+    """The traversal pass (k_region_traversal: a 32-bit LDS tile sized by the region volume) on the same geometries:
+    odd voxel counts, tiny and long regions, off-grid origins, ray flags.  Occupancy bit exact, traversal 1e-5."""
+    res, dims, origin, extent, n_rays, batches, flags, _ = CASES[case]
+    rays = synth.random_rays(n_rays, extent=extent, seed=900 + case, origin_spread=0.3 * extent)
+    map_ = OccupancyMap(res, dims, layers=("occupancy", "traversal"))
+    map_.setOrigin(origin)
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    step = 2 * ((n_rays + batches - 1) // batches)
+    for i in range(0, rays.shape[0], step):
+        assert gm.integrateRays(rays[i:i + step], ray_update_flags=flags) == rays[i:i + step].shape[0]
+        om.integrate_occupancy(rays[i:i + step], flags=flags)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+    worst = 0.0
+    for key, cpu in om.chunks().items():
+        g, c = map_.chunks[key]["traversal"], cpu["traversal"]
+        assert np.array_equal(c != 0, g != 0)
+        nz = c != 0
+        if nz.any():
+            worst = max(worst, float(np.max(np.abs(g[nz] - c[nz]) / np.maximum(np.abs(c[nz]), 1e-3))))
+    assert worst < 1e-5, worst
