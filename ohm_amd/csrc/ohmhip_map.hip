@@ -1631,7 +1631,10 @@ int settleLaunch(ohmhip_map_t m)
 }
 
 /// Launch what the filling slot holds: H2D on the copy stream, the batch on the compute stream behind it.
-int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
+/// `may_hand_over`: the caller is the host-pointer integrate call itself and needs nothing from the batch -- with
+/// ohmhip_map_set_async_launch the launch sequence then runs on the map's thread.  Everybody else (the observers,
+/// OHMHIP_SETTLE) gets the batch fully launched before this returns.
+int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr, bool may_hand_over = false)
 {
   OHMHIP_CHECK(settleLaunch(m));  // (one batch at a time is being launched; its error surfaces here)
   const size_t n = m->pending_rays;
@@ -1683,7 +1686,7 @@ int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr)
   OHMHIP_CHECK(hipEventRecord(sl.uploaded, m->copy_stream));
   OHMHIP_CHECK(hipStreamWaitEvent(m->stream, sl.uploaded, 0));
   OHMHIP_CHECK(hipStreamWaitEvent(m->front_stream, sl.uploaded, 0));  // (the set-up pass reads the rays first)
-  if (m->async_launch && !on_device && !integrated)
+  if (may_hand_over && m->async_launch && !on_device && !integrated)
   {
     // The launch sequence blocks on the batch's plan summary in its middle: it runs on the launch thread, the caller
     // goes on (typically to stage its next block into the other slot, whose upload then runs beside this wait).
@@ -2623,7 +2626,7 @@ int integrateRaysHost(ohmhip_map_t m, const double *rays, size_t element_count, 
     return OHMHIP_OK;  // deferred: runs with the following calls' rays, or as soon as anything observes the map
   }
   const auto t_flush = std::chrono::steady_clock::now();
-  err = flushPendingRays(m, device_counts ? integrated : nullptr);
+  err = flushPendingRays(m, device_counts ? integrated : nullptr, true);
   if (m->debug_flags & 2048u)
   {
     const auto t_end = std::chrono::steady_clock::now();

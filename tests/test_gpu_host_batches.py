@@ -244,7 +244,7 @@ def test_async_launch_gives_the_same_map_and_counts(gpu):
     gm = GpuMap(map_)
     gm.setAsyncLaunch(True)
     om = make_oracle(map_)
-    sizes = [150_000, 140_000, 3000, 2000, 135_000, 70_000, 200_000]
+    sizes = [150_000, 140_000, 3000, 2000, 135_000, 70_000, 200_000, 2500, 1500]  # (ends with calls still collected)
     for k, n in enumerate(sizes):
         rays = synth.rays_c1(n=n, max_range=9.0, seed=900 + k, first=31 * k)
         ts = 10.0 * k + 1e-6 * np.arange(n, dtype=np.float64)
