@@ -281,18 +281,24 @@ constexpr int kBinRaysPerBlock = 1024;  ///< rays per binning workgroup for larg
                                         ///< launch still spreads over the CUs (the host picks both per batch)
 constexpr uint32_t kLtabSize = 2048;  ///< entries (power of two)
 
-struct LdsRegionTable
+constexpr uint32_t kLtabSmall = 256;  ///< entries of the small-batch instantiations (128-ray workgroups)
+
+/// kTab entries (kLtabSize, or kLtabSmall for the small-batch instantiations of k_ray_setup / k_ray_bin: with the full
+/// table's 40 KiB of static LDS only three of their two-wave workgroups fit a CU and the kernels are latency bound).
+template <uint32_t kTab>
+struct LdsRegionTableT
 {
-  unsigned long long keys[kLtabSize];
-  uint32_t count[kLtabSize];   ///< k_ray_setup: segments of this workgroup in the region; k_ray_bin: sample cursor
-  uint32_t cursor[kLtabSize];  ///< k_ray_setup: samples of this workgroup in the region; k_ray_bin: segment cursor
-                               ///< (next free global position of the workgroup's reserved range)
+  unsigned long long keys[kTab];
+  uint32_t count[kTab];   ///< k_ray_setup: segments of this workgroup in the region; k_ray_bin: sample cursor
+  uint32_t cursor[kTab];  ///< k_ray_setup: samples of this workgroup in the region; k_ray_bin: segment cursor
+                          ///< (next free global position of the workgroup's reserved range)
 };
 
 /// Find or insert `key`; returns the entry index or kLtabSize when the table is full (caller falls back to global).
 /// `mask` = entries in use - 1 (a power of two <= kLtabSize: small workgroups use a small table so clearing and scanning
 /// it does not dominate their run time).
-__device__ inline uint32_t ltabFindOrInsert(LdsRegionTable &tab, uint64_t key, uint32_t mask)
+template <uint32_t kTab>
+__device__ inline uint32_t ltabFindOrInsert(LdsRegionTableT<kTab> &tab, uint64_t key, uint32_t mask)
 {
   uint32_t idx = hashRegionKey(key, mask);
   for (uint32_t probe = 0; probe < 64; ++probe)
@@ -311,7 +317,8 @@ __device__ inline uint32_t ltabFindOrInsert(LdsRegionTable &tab, uint64_t key, u
   return kLtabSize;
 }
 
-__device__ inline uint32_t ltabFind(const LdsRegionTable &tab, uint64_t key, uint32_t mask)
+template <uint32_t kTab>
+__device__ inline uint32_t ltabFind(const LdsRegionTableT<kTab> &tab, uint64_t key, uint32_t mask)
 {
   uint32_t idx = hashRegionKey(key, mask);
   for (uint32_t probe = 0; probe < 64; ++probe)
@@ -622,11 +629,12 @@ __device__ inline void buildRayOrder(RayOrder &order, uint32_t n_local, BinOf bi
 // ---------------------------------------------------------------------------------------------------------------------
 // (6 waves per SIMD: the kernel sits at 80-odd VGPRs, right at an allocation step -- 80 registers give a wave per SIMD
 // more than 88 do, and the kernel is latency bound)
+template <uint32_t kTab>
 __global__ void __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
   k_ray_setup(MapConst mc, RegionTable rt, BatchScratch bs, const double *__restrict__ rays, uint32_t n_rays,
               unsigned ray_flags, RayWalk *__restrict__ walks, uint32_t rays_per_block, uint32_t tab_mask)
 {
-  __shared__ LdsRegionTable tab;
+  __shared__ LdsRegionTableT<kTab> tab;
   __shared__ unsigned long long s_visits;
   __shared__ uint32_t s_rays_ok;
   __shared__ uint32_t s_list_n;
@@ -1064,14 +1072,15 @@ __global__ void __launch_bounds__(1024)
 // Three steps per workgroup: count its segments per region in LDS, reserve one contiguous range per region with a
 // single returning atomic, then re-enumerate and scatter through LDS cursors.
 // ---------------------------------------------------------------------------------------------------------------------
+template <uint32_t kTab>
 __global__ void __launch_bounds__(kBinThreads)
   k_ray_bin(MapConst mc, RegionTable rt, BatchScratch bs, const RayWalk *__restrict__ walks, uint32_t n_rays,
             Segment *__restrict__ segments, uint32_t segment_capacity, unsigned long long *__restrict__ hit_keys,
             uint32_t *__restrict__ hit_mask, int ray_shift, int bucket_hits, uint32_t rays_per_block,
             uint32_t tab_mask)
 {
-  __shared__ LdsRegionTable tab;
-  __shared__ uint32_t s_slot[kLtabSize];  // region slot per table entry (kSlotUnassigned: not handed over by the set-up)
+  __shared__ LdsRegionTableT<kTab> tab;
+  __shared__ uint32_t s_slot[kTab];  // region slot per table entry (kSlotUnassigned: not handed over by the set-up)
   if (bs.info->error & (kErrHashFull | kErrSlotsFull))
   {
     return;  // the batch's set-up overflowed the pool: the host grows it and repeats the batch

@@ -1058,9 +1058,21 @@ struct BatchRun
 
   void launchBin(bool bucket, uint32_t seg_capacity, unsigned long long *hit_keys)
   {
-    hipLaunchKernelGGL(k_ray_bin, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m), batchScratch(m),
-                       static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays, static_cast<Segment *>(m->segments.ptr),
-                       seg_capacity, hit_keys, m->d_hit_mask, ray_shift, bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
+    // (small batches -- 128-ray workgroups -- run the instantiation with the small LDS table: more workgroups per CU)
+    if (bin_tab_mask < kLtabSmall)
+    {
+      hipLaunchKernelGGL(k_ray_bin<kLtabSmall>, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m),
+                         batchScratch(m), static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays,
+                         static_cast<Segment *>(m->segments.ptr), seg_capacity, hit_keys, m->d_hit_mask, ray_shift,
+                         bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_ray_bin<kLtabSize>, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m),
+                         batchScratch(m), static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays,
+                         static_cast<Segment *>(m->segments.ptr), seg_capacity, hit_keys, m->d_hit_mask, ray_shift,
+                         bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
+    }
     (void)hipEventRecord(m->ev_bin_done, s);
     m->bin_done_recorded = true;
   }
@@ -1095,8 +1107,18 @@ struct BatchRun
       OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), f));
     }
     OHMHIP_CHECK(hipEventRecord(tev[0], f));
-    hipLaunchKernelGGL(k_ray_setup, dim3(bin_blocks), dim3(bin_threads), 0, f, m->mc, regionTable(m), batchScratch(m), d_rays,
-                       n_rays, ray_flags, static_cast<RayWalk *>(batchWalks(m).ptr), bin_rays_per_block, bin_tab_mask);
+    if (bin_tab_mask < kLtabSmall)
+    {
+      hipLaunchKernelGGL(k_ray_setup<kLtabSmall>, dim3(bin_blocks), dim3(bin_threads), 0, f, m->mc, regionTable(m),
+                         batchScratch(m), d_rays, n_rays, ray_flags, static_cast<RayWalk *>(batchWalks(m).ptr),
+                         bin_rays_per_block, bin_tab_mask);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_ray_setup<kLtabSize>, dim3(bin_blocks), dim3(bin_threads), 0, f, m->mc, regionTable(m),
+                         batchScratch(m), d_rays, n_rays, ray_flags, static_cast<RayWalk *>(batchWalks(m).ptr),
+                         bin_rays_per_block, bin_tab_mask);
+    }
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, f, regionTable(m), batchScratch(m), batchChunks(m),
                        m->chunk_capacity, batch_chunk_segments, m->h_info_dev, m->d_info + next_info_index,
                        batchEventCount(m));
