@@ -241,7 +241,8 @@ struct ohmhip_map_s
   /// OHMHIP_DEBUG_FLAGS (development only): 16 = walk kernel refills lanes but does not walk (timing experiments,
   /// breaks results); 64 = per-chunk timing trace of the walk kernel (OHMHIP_DEBUG_TRACE=<file>, scripts/
   /// analyse_trace.py); 128 = iteration / visit / refill counters (hot-address atomics: distorts timing); 256 = phase
-  /// timeline of the last three batches printed by ohmhip_map_sync.
+  /// timeline of the last three batches printed by ohmhip_map_sync; 512 = spill path timers; 2048 = where a host batch's
+  /// call spends its time; 4096 = one line per batch: segments, chunks, regions, densest region.
   unsigned debug_flags = 0;
   int refill_min_idle = kRefillMinIdle;      ///< tunable (OHMHIP_REFILL_MIN_IDLE)  ///< events the previous batch produced (sizes the next batch's list)
   void *h_stage = nullptr;  ///< pinned staging for region copies
@@ -1269,6 +1270,12 @@ struct BatchRun
     // region holds more samples than that kernel's LDS takes (then: ray-order keys + device-wide radix sort).
     bucket_hits = occupancy_mode && info.max_region_hits <= kSortRegionHits;
     m->spec_bucket_ok = bucket_hits;
+    if (m->debug_flags & 4096u)
+    {
+      std::fprintf(stderr, "[ohmhip dbg] batch: %u rays, %u segments, %u chunks, %u regions touched, %u with samples, "
+                   "densest %u samples; binned speculatively: %d\n", n_rays, info.n_segments, info.n_chunks,
+                   info.n_touched, info.n_hit_regions, info.max_region_hits, int(speculated));
+    }
     sorted = keys_b;
     if (!speculated)
     {
