@@ -114,6 +114,13 @@ class OccupancyMap:
     def setOccupancyThresholdProbability(self, p):
         self.occupancy_threshold_value = probability_to_value(p)
 
+    def setHitValue(self, value):
+        """ohm/OccupancyMap.h:623: the log-odds adjustment of a hit, set directly."""
+        self.hit_value = float(np.float32(value))
+
+    def setMissValue(self, value):
+        self.miss_value = float(np.float32(value))
+
     def hitValue(self):
         return self.hit_value
 
@@ -245,6 +252,23 @@ class GpuMap(RayMapper):
 
     def missValue(self):
         return self._map.miss_value
+
+    def setHitValue(self, value):
+        """Pass-through to OccupancyMap::setHitValue for API compatibility (ohmgpu/GpuMap.h:234-236); the device takes
+        the new value with the next batch."""
+        self._map.setHitValue(value)
+
+    def setMissValue(self, value):
+        """ohmgpu/GpuMap.h:242-244."""
+        self._map.setMissValue(value)
+
+    def setGroupedRays(self, group):
+        """ohmgpu/GpuMap.h:271, 323: the reference can sort a batch's rays by region before upload to help its GPU
+        threads.  Here every batch is binned per region on the device: the flag is stored and otherwise ignored."""
+        self._grouped_rays = bool(group)
+
+    def groupedRays(self):
+        return getattr(self, "_grouped_rays", False)
 
     def setRaySegmentLength(self, length):
         """ohmgpu/GpuMap.h:246-262.  Segmentation exists in the reference to balance GPU threads; this backend bins

@@ -270,6 +270,9 @@ public:
   const double *origin() const { return origin_; }
   void setHitProbability(float p) { hit_value_ = probabilityToValue(p); }
   void setMissProbability(float p) { miss_value_ = probabilityToValue(p); }
+  /// ohm/OccupancyMap.h:623: the log-odds adjustments set directly.
+  void setHitValue(float value) { hit_value_ = value; }
+  void setMissValue(float value) { miss_value_ = value; }
   void setOccupancyThresholdProbability(float p) { threshold_value_ = probabilityToValue(p); }
   float hitValue() const { return hit_value_; }
   float missValue() const { return miss_value_; }
@@ -370,6 +373,14 @@ public:
   bool borrowedMap() const { return borrowed_map_; }
   float hitValue() const { return map_->hitValue(); }
   float missValue() const { return map_->missValue(); }
+  /// Pass-throughs to the map for API compatibility (ohmgpu/GpuMap.h:234-244); the device takes the new values with the
+  /// next batch.
+  void setHitValue(float value) { map_->setHitValue(value); }
+  void setMissValue(float value) { map_->setMissValue(value); }
+  /// ohmgpu/GpuMap.h:271, 323: the reference can sort a batch's rays by region before upload.  Here every batch is
+  /// binned per region on the device: stored only.
+  void setGroupedRays(bool group) { grouped_rays_ = group; }
+  bool groupedRays() const { return grouped_rays_; }
   /// ohmgpu/GpuMap.h:246-262.  Stored only: this backend bins rays per region, it does not need segmentation.
   void setRaySegmentLength(double length) { ray_segment_length_ = length; }
   double raySegmentLength() const { return ray_segment_length_; }
@@ -713,6 +724,7 @@ protected:
   bool borrowed_map_ = true;
   ohmhip_map_t handle_ = nullptr;
   double ray_segment_length_ = 0;
+  bool grouped_rays_ = false;
   int last_status_ = OHMHIP_OK;
   RayFilterFunction ray_filter_;
   ohmhip_map_config cfg_;

@@ -86,3 +86,27 @@ def test_ndt_sensor_noise_and_tsdf_options_changed_between_batches(gpu):
     ot.integrate_tsdf(rays[40000:])
     gt.syncVoxels()
     assert_parity(compare_maps(ot.chunks(), map_t.chunks, ["tsdf"], exact_float=True))
+
+
+def test_gpumap_value_pass_throughs_and_grouped_rays(gpu):
+    """GpuMap::setHitValue / setMissValue pass through to the map (ohmgpu/GpuMap.h:234-244) and apply from the next batch;
+    setGroupedRays is accepted and changes nothing (every batch is binned per region on the device)."""
+    from oracle.oracle import lib as _olib
+    map_ = OccupancyMap(0.1, layers=("occupancy",))
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    rays = synth.rays_c1(n=16000, max_range=9.0, seed=8)
+    gm.integrateRays(rays[:16000])
+    om.integrate_occupancy(rays[:16000])
+    gm.setHitValue(1.25)
+    gm.setMissValue(-0.75)
+    assert gm.hitValue() == map_.hitValue() == 1.25 and gm.missValue() == -0.75
+    assert gm.groupedRays() is False
+    gm.setGroupedRays(True)
+    assert gm.groupedRays() is True
+    _olib.oracle_map_set_hit_value(om.handle, 1.25)
+    _olib.oracle_map_set_miss_value(om.handle, -0.75)
+    gm.integrateRays(rays[16000:])
+    om.integrate_occupancy(rays[16000:])
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
