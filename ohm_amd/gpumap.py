@@ -564,6 +564,41 @@ class GpuTsdfMap(GpuMap):
     def _fill_config(self, cfg):
         (cfg.tsdf_max_weight, cfg.tsdf_trunc, cfg.tsdf_dropoff, cfg.tsdf_sparsity) = self.tsdf_options
 
+    # ohmgpu/GpuTsdfMap.h:64-79: the option setters / getters under the reference's names (they apply from the next batch;
+    # `tsdf_options` = (max_weight, default_truncation_distance, dropoff_epsilon, sparsity_compensation_factor)).
+    def setTsdfOptions(self, max_weight, default_truncation_distance, dropoff_epsilon, sparsity_compensation_factor):
+        self.tsdf_options = (float(max_weight), float(default_truncation_distance), float(dropoff_epsilon),
+                             float(sparsity_compensation_factor))
+
+    def _set_option(self, index, value):
+        opts = list(self.tsdf_options)
+        opts[index] = float(value)
+        self.tsdf_options = tuple(opts)
+
+    def setMaxWeight(self, max_weight):
+        self._set_option(0, max_weight)
+
+    def maxWeight(self):
+        return self.tsdf_options[0]
+
+    def setDefaultTruncationDistance(self, default_truncation_distance):
+        self._set_option(1, default_truncation_distance)
+
+    def defaultTruncationDistance(self):
+        return self.tsdf_options[1]
+
+    def setDropoffEpsilon(self, dropoff_epsilon):
+        self._set_option(2, dropoff_epsilon)
+
+    def dropoffEpsilon(self):
+        return self.tsdf_options[2]
+
+    def setSparsityCompensationFactor(self, sparsity_compensation_factor):
+        self._set_option(3, sparsity_compensation_factor)
+
+    def sparsityCompensationFactor(self):
+        return self.tsdf_options[3]
+
 
 class GpuTransformSamples:
     """ohm::GpuTransformSamples (ohmgpu/GpuTransformSamples.h:30-83): local sensor samples + a timestamped trajectory ->

@@ -834,6 +834,9 @@ public:
   void setMaxWeight(float max_weight) { options_.max_weight = max_weight; }
   void setDefaultTruncationDistance(float distance) { options_.default_truncation_distance = distance; }
   void setSparsityCompensationFactor(float factor) { options_.sparsity_compensation_factor = factor; }
+  float sparsityCompensationFactor() const { return options_.sparsity_compensation_factor; }
+  void setDropoffEpsilon(float dropoff_epsilon) { options_.dropoff_epsilon = dropoff_epsilon; }
+  float dropoffEpsilon() const { return options_.dropoff_epsilon; }
 
 protected:
   void fillMapperValues(ohmhip_map_config &cfg) const override { fill(cfg, const_cast<TsdfOptions *>(&options_)); }

@@ -78,7 +78,8 @@ def test_ndt_sensor_noise_and_tsdf_options_changed_between_batches(gpu):
     gt.integrateRays(rays[20000:40000])
     ot.integrate_tsdf(rays[20000:40000])
     # a new truncation distance on a populated map is refused, not approximated; the map keeps working as it was
-    gt.tsdf_options = (3.0, 0.3, 0.0, 1.0)
+    gt.setDefaultTruncationDistance(0.3)  # (the reference's setter names; same effect as assigning tsdf_options)
+    assert gt.tsdf_options == (3.0, 0.3, 0.0, 1.0) and gt.maxWeight() == 3.0 and gt.dropoffEpsilon() == 0.0
     with pytest.raises(Exception):
         gt.integrateRays(rays[40000:])
     gt.tsdf_options = (3.0, 0.2, 0.0, 1.0)
