@@ -4,5 +4,6 @@ The compute path is libohmhip.so (hand-written HIP for gfx950) behind the C ABI 
 is the thin host-side mirror of the reference's interface used by the tests and the benchmark harness.
 """
 from ._lib import OhmHipError, LIB_PATH, EXPORTED_SYMBOLS  # noqa: F401
-from .gpumap import (GpuMap, GpuNdtMap, GpuTransformSamples, GpuTsdfMap, NdtMode, OccupancyMap, RayFlag, RayMapper, LAYERS,  # noqa: F401
+from .gpumap import (GpuMap, GpuNdtMap, GpuTransformSamples, GpuTsdfMap, LineKeysQueryGpu, NdtMode, OccupancyMap, RayFlag,  # noqa: F401
+                     RayMapper, LAYERS,
                      device_count, device_info, probability_to_value, value_to_probability)

@@ -643,6 +643,81 @@ class GpuTransformSamples:
         return out
 
 
+class LineKeysQueryGpu:
+    """ohm::LineKeysQueryGpu (ohmgpu/LineKeysQueryGpu.h; interface of ohm/LineKeysQuery.h:47-101 + ohm/Query.h:51-121): the
+    voxel keys along a set of query lines, walked on the device with the CPU walk's fp64 semantics
+    (ohmhip_map_line_keys).  Given the GpuMap that holds the device handle (the query reads the map's geometry only)."""
+
+    def __init__(self, gpu_map, query_flags=0):
+        self._gpu_map = gpu_map
+        self._query_flags = int(query_flags)
+        self._rays = np.zeros((0, 3), dtype=np.float64)
+        self.reset()
+
+    def queryFlags(self):
+        return self._query_flags
+
+    def setQueryFlags(self, flags):
+        self._query_flags = int(flags)
+
+    def setRays(self, rays):
+        """(2N, 3) start / end point pairs."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 3)
+        self._rays = rays[:rays.shape[0] & ~1].copy()
+
+    def rays(self):
+        return self._rays
+
+    def rayPointCount(self):
+        return self._rays.shape[0]
+
+    def reset(self, hard_reset=True):
+        self._indices = np.zeros(0, dtype=np.uint64)
+        self._counts = np.zeros(0, dtype=np.uint64)
+        self._regions = np.zeros((0, 3), dtype=np.int16)
+        self._locals = np.zeros((0, 3), dtype=np.uint8)
+
+    def execute(self):
+        self.reset(False)
+        n = self._rays.shape[0] // 2
+        if n == 0:
+            return True
+        # worst case keys per line, as the reference sizes its buffer (ohmgpu/LineKeysQueryGpu.cpp:112-119)
+        length = np.linalg.norm(self._rays[1::2] - self._rays[0::2], axis=1)
+        max_keys = int(np.ceil(length.max() / self._gpu_map.map().resolution * math.sqrt(3.0))) + 4
+        regions, voxels, counts = self._gpu_map.lineKeys(self._rays, max_keys_per_line=max_keys)
+        counts = np.minimum(counts.astype(np.uint64), np.uint64(max_keys))
+        self._counts = counts
+        self._indices = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+        keep = np.arange(max_keys)[None, :] < counts[:, None]
+        self._regions = regions[keep]
+        self._locals = voxels[keep]
+        return True
+
+    def executeAsync(self):
+        """The device call is synchronous: the asynchronous forms complete at once (ohm/Query.h:103-121)."""
+        return self.execute()
+
+    def wait(self, timeout_ms=0xffffffff):
+        return True
+
+    def numberOfResults(self):
+        return int(self._counts.shape[0])
+
+    def resultIndices(self):
+        return self._indices
+
+    def resultCounts(self):
+        return self._counts
+
+    def intersectedVoxels(self):
+        """(regions (K, 3) int16, local keys (K, 3) uint8): all rays' keys in walk order, ray after ray."""
+        return self._regions, self._locals
+
+    def ranges(self):
+        return None
+
+
 def device_count():
     n = C.c_int(0)
     status = L.lib.ohmhip_device_count(C.byref(n))

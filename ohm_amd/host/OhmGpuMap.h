@@ -899,6 +899,119 @@ private:
   int last_status_ = OHMHIP_OK;
 };
 
+/// Voxel key as the queries report it: region + local coordinates (ohm/Key.h; the device writes the reference's GpuKey
+/// records, ohmgpu/GpuKey.h:37-46).
+struct Key
+{
+  int16_t region[3];
+  uint8_t local[3];
+  bool operator==(const Key &o) const
+  {
+    return region[0] == o.region[0] && region[1] == o.region[1] && region[2] == o.region[2] && local[0] == o.local[0] &&
+           local[1] == o.local[1] && local[2] == o.local[2];
+  }
+};
+
+/// ohm::LineKeysQueryGpu (ohmgpu/LineKeysQueryGpu.h; the interface of ohm/LineKeysQuery.h:47-101 + ohm/Query.h:51-121):
+/// the voxel keys along a set of query lines, walked on the device with the CPU walk's fp64 semantics
+/// (ohmhip_map_line_keys).  The query needs the map's geometry only; it is given the GpuMap that holds the device
+/// handle.  Results as in the reference: one result per ray, resultIndices() / resultCounts() index
+/// intersectedVoxels().
+class LineKeysQueryGpu
+{
+public:
+  explicit LineKeysQueryGpu(GpuMap &gpu_map, unsigned query_flags = 0)
+    : gpu_map_(&gpu_map)
+    , query_flags_(query_flags)
+  {}
+  void setGpuMap(GpuMap *gpu_map) { gpu_map_ = gpu_map; }
+  unsigned queryFlags() const { return query_flags_; }
+  void setQueryFlags(unsigned flags) { query_flags_ = flags; }
+
+  /// Ray start / end point pairs; @p point_count is twice the number of rays.
+  void setRays(const dvec3 *rays, size_t point_count)
+  {
+    rays_.assign(rays, rays + (point_count & ~size_t(1)));
+  }
+  const dvec3 *rays() const { return rays_.data(); }
+  size_t rayPointCount() const { return rays_.size(); }
+
+  size_t numberOfResults() const { return result_counts_.size(); }
+  const size_t *resultIndices() const { return result_indices_.data(); }
+  const size_t *resultCounts() const { return result_counts_.data(); }
+  const Key *intersectedVoxels() const { return intersected_voxels_.data(); }
+  const double *ranges() const { return nullptr; }  // (not reported by this query, as in the reference)
+
+  /// Synchronous query (ohm/Query.h:93).  @return true on success.
+  bool execute()
+  {
+    reset(false);
+    const size_t ray_count = rays_.size() / 2;
+    if (!gpu_map_ || !gpu_map_->gpuOk())
+    {
+      return false;
+    }
+    if (ray_count == 0)
+    {
+      return true;
+    }
+    // Worst case keys per line, as the reference sizes its buffer (ohmgpu/LineKeysQueryGpu.cpp:112-119).
+    const double res = gpu_map_->map().resolution();
+    uint32_t max_keys = 1;
+    for (size_t i = 0; i < ray_count; ++i)
+    {
+      const dvec3 &a = rays_[2 * i], &b = rays_[2 * i + 1];
+      const double len = std::sqrt((b.x - a.x) * (b.x - a.x) + (b.y - a.y) * (b.y - a.y) + (b.z - a.z) * (b.z - a.z));
+      max_keys = std::max<uint32_t>(max_keys, uint32_t(std::ceil(len / res * std::sqrt(3.0))) + 4u);
+    }
+    std::vector<unsigned char> records(ray_count * size_t(max_keys) * 10u);
+    std::vector<uint32_t> counts(ray_count);
+    if (ohmhip_map_line_keys(gpu_map_->handle(), reinterpret_cast<const double *>(rays_.data()), ray_count, max_keys,
+                             records.data(), counts.data()) != OHMHIP_OK)
+    {
+      return false;
+    }
+    result_indices_.resize(ray_count);
+    result_counts_.resize(ray_count);
+    for (size_t i = 0; i < ray_count; ++i)
+    {
+      result_indices_[i] = intersected_voxels_.size();
+      const size_t n = std::min<size_t>(counts[i], max_keys);
+      result_counts_[i] = n;
+      for (size_t j = 0; j < n; ++j)
+      {
+        const unsigned char *rec = records.data() + (i * size_t(max_keys) + j) * 10u;
+        Key key;
+        std::memcpy(key.region, rec, 6);
+        std::memcpy(key.local, rec + 6, 3);
+        intersected_voxels_.push_back(key);
+      }
+    }
+    return true;
+  }
+  /// The device call is synchronous: the asynchronous forms complete at once (ohm/Query.h:103-121).
+  bool executeAsync() { return execute(); }
+  bool wait(unsigned /*timeout_ms*/ = ~0u) { return true; }
+  void reset(bool hard_reset = true)
+  {
+    result_indices_.clear();
+    result_counts_.clear();
+    intersected_voxels_.clear();
+    if (hard_reset)
+    {
+      // (hard reset releases memory, ohm/Query.h:114)
+      std::vector<Key>().swap(intersected_voxels_);
+    }
+  }
+
+private:
+  GpuMap *gpu_map_ = nullptr;
+  unsigned query_flags_ = 0;
+  std::vector<dvec3> rays_;
+  std::vector<size_t> result_indices_, result_counts_;
+  std::vector<Key> intersected_voxels_;
+};
+
 /// ohm::configureGpu / gpuDevice (ohmgpu/OhmGpu.h:40-66): select the process-wide device.
 inline int configureGpu(int device_index = 0)
 {

@@ -3,7 +3,7 @@
 // (tests/ohmtestgpu/GpuMapTest.cpp:68-205), syncs, and dumps every region layer for the Python parity test to check
 // against the CPU oracle.  Links libohmhip.so only; built with plain g++ (no hipcc, no glm).
 //
-//   gpumap_driver <mode: occ|occmean|occdev|ndt|tsdf> <resolution> <batch_rays> <rays.bin> <out.bin>
+//   gpumap_driver <mode: occ|occmean|occdev|ndt|tsdf|linekeys|...> <resolution> <batch_rays> <rays.bin> <out.bin>
 //   occdev: the sample points (odd entries) go through ohm::GpuTransformSamples with a static identity trajectory and
 //   are integrated straight from the device buffer (all rays then start at the origin).
 //   rays.bin: u64 n_points, then n_points * 3 doubles.  out.bin: u64 regions, per region i16[3] key, then per enabled
@@ -103,6 +103,42 @@ int main(int argc, char **argv)
       return 4;
     }
     std::fclose(in);
+
+    if (mode == "linekeys")
+    {
+      // ohm::LineKeysQueryGpu over the rays: out.bin = u64 rays, then per ray u64 index, u64 count, and after them all
+      // keys (i16[3] region, u8[3] local each) in intersectedVoxels() order.
+      ohm::OccupancyMap query_map(resolution);
+      ohm::GpuMap query_gpu_map(&query_map, true);
+      ohm::LineKeysQueryGpu query(query_gpu_map);
+      query.setRays(rays.data(), rays.size());
+      if (!query.executeAsync() || !query.wait() || query.numberOfResults() != rays.size() / 2)
+      {
+        return 8;
+      }
+      FILE *out = std::fopen(argv[5], "wb");
+      if (!out)
+      {
+        return 6;
+      }
+      const uint64_t n = query.numberOfResults();
+      std::fwrite(&n, sizeof(n), 1, out);
+      uint64_t total_keys = 0;
+      for (uint64_t i = 0; i < n; ++i)
+      {
+        const uint64_t index = query.resultIndices()[i], count = query.resultCounts()[i];
+        std::fwrite(&index, sizeof(index), 1, out);
+        std::fwrite(&count, sizeof(count), 1, out);
+        total_keys = index + count;
+      }
+      for (uint64_t k = 0; k < total_keys; ++k)
+      {
+        std::fwrite(query.intersectedVoxels()[k].region, sizeof(int16_t), 3, out);
+        std::fwrite(query.intersectedVoxels()[k].local, sizeof(uint8_t), 3, out);
+      }
+      std::fclose(out);
+      return 0;
+    }
 
     ohm::OccupancyMap map(resolution);
     std::unique_ptr<ohm::GpuMap> gpu_map;

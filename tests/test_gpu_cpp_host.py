@@ -73,6 +73,37 @@ def test_cpp_host_mirror_matches_oracle(gpu, mode, layers, res):
     assert_parity(stats)
 
 
+def test_cpp_line_keys_query_gpu(gpu):
+    """ohm::LineKeysQueryGpu of the C++ mirror (setRays / executeAsync / wait / resultIndices / resultCounts /
+    intersectedVoxels, ohm/LineKeysQuery.h:47-101): every ray's keys equal the oracle's CPU walk."""
+    lines = synth.random_rays(1500, extent=4.0, seed=77, origin_spread=2.0)
+    assert os.path.exists(DRIVER), "gpumap_driver missing: run __graft_entry__.build()"
+    with tempfile.TemporaryDirectory() as tmp:
+        rp, op = os.path.join(tmp, "rays.bin"), os.path.join(tmp, "out.bin")
+        with open(rp, "wb") as f:
+            f.write(struct.pack("<Q", lines.shape[0]))
+            f.write(np.ascontiguousarray(lines, dtype=np.float64).tobytes())
+        res = subprocess.run([DRIVER, "linekeys", "0.1", "0", rp, op], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+        data = open(op, "rb").read()
+    (n,) = struct.unpack_from("<Q", data, 0)
+    assert n == lines.shape[0] // 2
+    table = np.frombuffer(data, dtype="<u8", count=2 * n, offset=8).reshape(n, 2)
+    keys_off = 8 + 16 * n
+    total = int(table[-1, 0] + table[-1, 1])
+    assert len(data) == keys_off + 9 * total
+    om = OracleMap(0.1)
+    pairs = lines.reshape(-1, 6)
+    for i in range(n):
+        keys, _, _ = om.walk(pairs[i, :3], pairs[i, 3:], 0)
+        index, count = int(table[i, 0]), int(table[i, 1])
+        assert count == len(keys)
+        for j, (region, local) in enumerate(keys):
+            off = keys_off + 9 * (index + j)
+            assert struct.unpack_from("<3h", data, off) == tuple(region)
+            assert struct.unpack_from("<3B", data, off + 6) == tuple(local)
+
+
 def test_cpp_transform_samples_feeds_device_integration(gpu):
     # ohm::GpuTransformSamples -> device buffer -> GpuMap::integrateRays(Buffer): with a static identity trajectory the
     # result must equal integrating rays from the origin to the same sample points.

@@ -41,3 +41,30 @@ def test_line_keys_match_cpu_walk(gpu, origin):
         assert got == keys, (i, ln)
         total += len(keys)
     assert total > 100000
+
+
+def test_line_keys_query_gpu_interface(gpu):
+    """The query object of the reference (ohmgpu/LineKeysQueryGpu.h; tests/ohmtestgpu/GpuLineKeysTests.cpp compares it
+    with the CPU LineKeysQuery ray by ray): setRays / execute / numberOfResults / resultIndices / resultCounts /
+    intersectedVoxels, against the oracle's CPU walk."""
+    from ohm_amd import LineKeysQueryGpu
+    lines = _lines()[:800]
+    map_ = OccupancyMap(0.1)
+    gm = GpuMap(map_)
+    query = LineKeysQueryGpu(gm)
+    query.setRays(lines.reshape(-1, 3))
+    assert query.rayPointCount() == 2 * lines.shape[0]
+    assert query.execute() and query.wait()
+    assert query.numberOfResults() == lines.shape[0]
+    regions, local = query.intersectedVoxels()
+    indices, counts = query.resultIndices(), query.resultCounts()
+    om = OracleMap(0.1)
+    for i, ln in enumerate(lines):
+        keys, _, _ = om.walk(ln[:3], ln[3:], 0)
+        assert counts[i] == len(keys)
+        first = int(indices[i])
+        got = [(tuple(int(v) for v in regions[first + j]), tuple(int(v) for v in local[first + j])) for j in range(len(keys))]
+        assert got == keys, (i, ln)
+    assert int(indices[-1] + counts[-1]) == regions.shape[0]
+    query.reset()
+    assert query.numberOfResults() == 0
