@@ -378,6 +378,18 @@ class GpuMap(RayMapper):
             def remove(self, region_key):
                 owner.removeRegions([region_key])
 
+            def reinitialise(self):
+                """ohmgpu/GpuCache.h:103: the device map keeps its layout for life, so this is clear()."""
+                owner.clear()
+
+            def targetGpuAllocSize(self):
+                """ohmgpu/GpuCache.h:139: byte budget of the device-side voxel storage (0: the device's free memory)."""
+                return int(owner.cacheStats()["memory_limit"])
+
+            def layerCount(self):
+                """ohmgpu/GpuCache.h:143"""
+                return len(owner.map().layers)
+
         return _GpuCacheView()
 
     def removeRegions(self, keys):

@@ -552,6 +552,27 @@ public:
     void clear() { OHMHIP_GPUAPICHECK(ohmhip_map_clear(owner_->handle_)); }
     /// MapRegionCache::remove(region_key)
     void remove(const std::array<int16_t, 3> &region_key) { owner_->removeRegions(region_key.data(), 1); }
+    /// GpuCache::reinitialise (ohmgpu/GpuCache.h:103): the reference rebuilds its layer caches after the map's layout
+    /// changed, dropping what they held; here the device map keeps its layout for life, so this is clear().
+    void reinitialise() { clear(); }
+    /// GpuCache::targetGpuAllocSize (ohmgpu/GpuCache.h:139): the byte budget of the device-side voxel storage
+    /// (0: bounded by the device's free memory only).
+    size_t targetGpuAllocSize() const
+    {
+      ohmhip_cache_stats st{};
+      OHMHIP_GPUAPICHECK(ohmhip_map_cache_stats(owner_->handle_, &st, 0));
+      return size_t(st.memory_limit);
+    }
+    /// GpuCache::layerCount (ohmgpu/GpuCache.h:143): voxel layers held on the device.
+    unsigned layerCount() const
+    {
+      unsigned n = 0;
+      for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
+      {
+        n += owner_->map().hasLayer(l) ? 1u : 0u;
+      }
+      return n;
+    }
 
   private:
     GpuMap *owner_;

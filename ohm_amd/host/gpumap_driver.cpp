@@ -222,6 +222,10 @@ int main(int argc, char **argv)
     if (mode == "occcoalesce")
     {
       gpu_map->gpuCache()->flush();  // GpuCache::flush == syncVoxels
+      if (gpu_map->gpuCache()->layerCount() != 1u || gpu_map->gpuCache()->targetGpuAllocSize() != 0u)
+      {
+        return 9;  // (occupancy only, no memory limit set)
+      }
     }
     gpu_map->syncVoxels();
     std::printf("integrated %zu of %llu points, %zu regions\n", total, (unsigned long long)n_points, map.regionCount());

@@ -130,6 +130,9 @@ def test_stored_regions_answer_the_region_calls(gpu):
     map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
     gm = limited_map(map_, 80)
     gm.setSpillToHost(True)
+    # the GpuCache view reports the budget and the layers (ohmgpu/GpuCache.h:139-143)
+    assert gm.gpuCache().targetGpuAllocSize() == 80 * gm.cacheStats()["bytes_per_region"]
+    assert gm.gpuCache().layerCount() == 1
     om = make_oracle(map_)
     for k, origin in enumerate([(0.0, 0.0, 0.0), (12.0, 0.0, 0.0), (24.0, 0.0, 0.0)]):
         rays = sensor_rays(origin, 5000, seed=900 + k)
