@@ -1502,6 +1502,34 @@ __device__ inline float occHit(const MapConst &mc, unsigned ray_flags, float ini
 /// (the min clamp) the remaining applications are the identity and can be skipped without changing the result.
 __device__ inline float occMissN(const MapConst &mc, unsigned ray_flags, float x, uint32_t n)
 {
+  constexpr unsigned kExcludeFlags = OHMHIP_RF_EXCLUDE_UNOBSERVED | OHMHIP_RF_EXCLUDE_FREE | OHMHIP_RF_EXCLUDE_OCCUPIED;
+  if (n == 0)
+  {
+    return x;
+  }
+  if (!(ray_flags & kExcludeFlags))
+  {
+    // Without the exclusion flags only the FIRST miss can meet an unobserved voxel; every later one is occMiss() of an
+    // observed value, which is these three operations (same operations, same order: bit identical) -- a voxel that is
+    // not yet at the clamp pays them up to ~10 times per batch (a map the sensor is moving through).
+    float nx = occMiss(mc, ray_flags, x);
+    if (nx == x)
+    {
+      return x;
+    }
+    x = nx;
+    for (uint32_t k = 1; k < n; ++k)
+    {
+      const float adj = (mc.sat_min < x && x < mc.sat_max) ? mc.miss_value : 0.0f;
+      nx = fmaxf(mc.min_value, x + adj);
+      if (nx == x)
+      {
+        break;
+      }
+      x = nx;
+    }
+    return x;
+  }
   for (uint32_t k = 0; k < n; ++k)
   {
     const float nx = occMiss(mc, ray_flags, x);
