@@ -654,7 +654,8 @@ def main():
                                                  "static headline mostly because this synthetic scene is inconsistent from "
                                                  "batch to batch (random range per ray): voxels hit by one batch are crossed "
                                                  "by the next, so the log-odds replay iterates instead of meeting the clamp's "
-                                                 "fixed point at once (k_apply_counts 127 vs 37 us, walk epilogue +0.1 ms)"}
+                                                 "fixed point at once (1.20 ms before the repeated miss became three "
+                                                 "operations per application, occMissN)"}
             for hb, _, _ in bufs:
                 L.lib.ohmhip_buffer_destroy(hb)
             gmv.close()
