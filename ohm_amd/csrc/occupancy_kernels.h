@@ -2594,13 +2594,22 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         {
           const uint32_t n0 = w & kTileCountMask;
           const uint32_t n1 = (w >> 16) & kTileCountMask;
+          // (a voxel at its clamp -- most of a settled map's free space -- does not move: nothing to write)
           if (n0)
           {
-            g_occ[2 * i] = occMissN(mc, args.ray_flags, values[j].x, n0);
+            const float v = occMissN(mc, args.ray_flags, values[j].x, n0);
+            if (v != values[j].x)
+            {
+              g_occ[2 * i] = v;
+            }
           }
           if (n1)
           {
-            g_occ[2 * i + 1] = occMissN(mc, args.ray_flags, values[j].y, n1);
+            const float v = occMissN(mc, args.ray_flags, values[j].y, n1);
+            if (v != values[j].y)
+            {
+              g_occ[2 * i + 1] = v;
+            }
           }
         }
       }
@@ -2908,11 +2917,14 @@ __device__ inline void applyCounts(uint32_t region_index, const MapConst &mc, co
           n.z = (bits & 4u) ? 0u : n.z;
           n.w = (bits & 8u) ? 0u : n.w;
         }
-        float4 o = occ4[q];
+        const float4 before = occ4[q];
+        float4 o = before;
         o.x = n.x ? occMissN(mc, ray_flags, o.x, n.x) : o.x;
         o.y = n.y ? occMissN(mc, ray_flags, o.y, n.y) : o.y;
         o.z = n.z ? occMissN(mc, ray_flags, o.z, n.z) : o.z;
         o.w = n.w ? occMissN(mc, ray_flags, o.w, n.w) : o.w;
+        // (voxels at their clamp do not move: a settled map's free space needs no log-odds write)
+        const bool moved = o.x != before.x || o.y != before.y || o.z != before.z || o.w != before.w;
         if (preserve_masked && bits)
         {
           // A masked voxel's log-odds and count belong to applyHits, which may be at work on them right now: only the
@@ -2926,7 +2938,10 @@ __device__ inline void applyCounts(uint32_t region_index, const MapConst &mc, co
         }
         else
         {
-          occ4[q] = o;
+          if (moved)
+          {
+            occ4[q] = o;
+          }
           counts4[q] = make_uint4(0, 0, 0, 0);
         }
         if (hit_miss_counts)
