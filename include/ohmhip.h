@@ -372,6 +372,51 @@ int ohmhip_region_owner(const int16_t *keys_xyz, size_t count, int block_shift, 
                         uint32_t *owners);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Partitioned map (north_star: "ray batches shard by sensor-origin region across GPUs"; no reference
+ * equivalent -- ohm is single device).  The exact multi-GPU mode, and what `bench.py --gpus N` runs: every rank owns a
+ * TERRITORY of region blocks and holds only those regions; rays travel to the owners of the regions they cross (48 B
+ * per routed ray over RCCL -- voxels never cross a link), and every rank integrates the rays addressed to it in
+ * (source rank, ray) order.  The union of the ranks' regions is bit-identical to one map integrating rank 0's batch,
+ * then rank 1's, ... -- for every map type, clamps included (tests/test_gpu_partitioned.py).  One RayFlag is refused on
+ * a partitioned map (OHMHIP_ERR_UNSUPPORTED): OHMHIP_RF_STOP_ON_FIRST_OCCUPIED, whose effect on a voxel depends on voxels
+ * other ranks own.
+ *
+ * ohmhip_map_set_region_partition: like ohmhip_map_set_region_ownership, but the blocks of 2^block_shift regions per
+ * axis are dealt by a TABLE (x fastest) over [grid_origin, grid_origin + grid_dims) in block coordinates (region
+ * coordinate >> block_shift); blocks outside the grid belong to the owner of the nearest cell, so territories that reach
+ * the table's edge extend outwards without limit.  grid_dims = {0,0,0} / owners = NULL: the block hash of
+ * ohmhip_region_owner.  The table is copied.  Only on an empty map.  world_size <= 64.
+ * ohmhip_map_region_owners: owners under the map's current partition (host evaluation).
+ * ohmhip_map_route_rays: for `ray_count` rays in DEVICE memory (6 doubles each) find, per ray, the ranks owning a
+ * region its walk touches or its sample lands in -- exactly, with the functions the integration itself runs (rays the
+ * map's ray filter rejects go nowhere) -- and compact the rays per destination, in ray order, into d_routed
+ * (destination d's block starts at counts[0] + .. + counts[d-1]); d_routed_index (may be NULL) receives each routed
+ * ray's index in the input, for callers that route side arrays (time stamps, intensities) themselves.  counts (host,
+ * world_size entries) = rays per destination; *visits (may be NULL) = voxel visits of the input rays.  Returns
+ * OHMHIP_ERR_CAPACITY -- with counts valid -- when d_routed holds fewer than sum(counts) rays: grow and repeat.
+ * Synchronous.
+ * ohmhip_comm_exchange_counts / _rays: the all-to-all of the routed rays over RCCL (both collective).  First the counts
+ * (recv_counts[s] = rays rank s addressed to this rank), then, with d_recv holding sum(recv_counts) rays, the blocks:
+ * on return (stream order) d_recv holds the rays addressed to this rank in source-rank order, ready for
+ * ohmhip_map_integrate_rays_device.  A torch.distributed all_to_all_single does the same job for Python hosts
+ * (ohm_amd/distributed.py: PartitionedIntegrator). */
+typedef struct ohmhip_partition
+{
+  uint32_t world_size;
+  uint32_t rank;
+  int32_t block_shift;
+  int32_t grid_origin[3];
+  uint32_t grid_dims[3];
+  const uint8_t *owners;
+} ohmhip_partition;
+int ohmhip_map_set_region_partition(ohmhip_map_t map, const ohmhip_partition *partition);
+int ohmhip_map_region_owners(ohmhip_map_t map, const int16_t *keys_xyz, size_t count, uint32_t *owners);
+/* The same rule for a partition description alone (no map, no device): what hosts use to plan and check a table. */
+int ohmhip_partition_owners(const ohmhip_partition *partition, const int16_t *keys_xyz, size_t count, uint32_t *owners);
+int ohmhip_map_route_rays(ohmhip_map_t map, const double *d_rays, size_t ray_count, unsigned ray_flags, double *d_routed,
+                          uint32_t *d_routed_index, size_t capacity, uint32_t *counts, uint64_t *visits);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Replica merge (SURVEY 8e mode 1: every GPU integrates the rays of its own sensor origins into its own resident map;
  * regions touched by more than one GPU are reconciled on demand).  No reference equivalent -- ohm is single device.
  *
@@ -409,6 +454,11 @@ int ohmhip_comm_unique_id(unsigned char id[OHMHIP_COMM_ID_BYTES]);  /* ncclGetUn
 /* ncclCommInitRank on the calling thread's current device (collective: every rank calls it with the same id). */
 int ohmhip_comm_init_rank(ohmhip_comm_t *comm, const unsigned char id[OHMHIP_COMM_ID_BYTES], int world_size, int rank);
 int ohmhip_comm_destroy(ohmhip_comm_t comm);
+/* Partitioned map: the all-to-all of routed rays (see "Partitioned map" above). */
+int ohmhip_comm_exchange_counts(ohmhip_comm_t comm, const uint32_t *send_counts, uint32_t *recv_counts,
+                                ohmhip_stream_t stream);
+int ohmhip_comm_exchange_rays(ohmhip_comm_t comm, const double *d_send, const uint32_t *send_counts, double *d_recv,
+                              const uint32_t *recv_counts, ohmhip_stream_t stream);
 
 typedef struct ohmhip_merge_stats
 {

@@ -68,6 +68,11 @@ class CacheStats(C.Structure):
                 ("spill_enabled", C.c_uint32)]
 
 
+class Partition(C.Structure):
+    _fields_ = [("world_size", C.c_uint32), ("rank", C.c_uint32), ("block_shift", C.c_int32),
+                ("grid_origin", C.c_int32 * 3), ("grid_dims", C.c_uint32 * 3), ("owners", C.c_void_p)]
+
+
 COMM_ID_BYTES = 128
 
 
@@ -140,6 +145,13 @@ _sigs = {
     "ohmhip_map_set_async_launch": (C.c_int, [_vp, C.c_int]),
     "ohmhip_map_set_region_ownership": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_int]),
     "ohmhip_region_owner": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_uint32, _vp]),
+    "ohmhip_map_set_region_partition": (C.c_int, [_vp, C.POINTER(Partition)]),
+    "ohmhip_map_region_owners": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "ohmhip_partition_owners": (C.c_int, [C.POINTER(Partition), _vp, C.c_size_t, _vp]),
+    "ohmhip_map_route_rays": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint, _vp, _vp, C.c_size_t, _vp,
+                                        C.POINTER(C.c_uint64)]),
+    "ohmhip_comm_exchange_counts": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ohmhip_comm_exchange_rays": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ohmhip_map_cache_stats": (C.c_int, [_vp, C.POINTER(CacheStats), C.c_int]),
     "ohmhip_map_set_memory_limit": (C.c_int, [_vp, C.c_uint64]),
     "ohmhip_map_set_spill_to_host": (C.c_int, [_vp, C.c_int]),

@@ -13,6 +13,7 @@ struct ohmhip_comm_s
   ncclComm_t comm = nullptr;
   int world = 1;
   int rank = 0;
+  uint32_t *d_counts = nullptr;  ///< [world + world * world] scratch of ohmhip_comm_exchange_counts (partition_impl.h)
 };
 
 namespace
@@ -152,6 +153,10 @@ try
     if (comm->comm)
     {
       (void)ncclCommDestroy(comm->comm);
+    }
+    if (comm->d_counts)
+    {
+      (void)hipFree(comm->d_counts);
     }
     delete comm;
   }

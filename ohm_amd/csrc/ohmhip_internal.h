@@ -82,6 +82,12 @@ struct MapConst
   unsigned owner_world;
   unsigned owner_rank;
   int owner_shift;
+  /// Region partition table (ohmhip_map_set_region_partition; null: blocks are dealt by regionOwner()'s hash): owner
+  /// rank per block of 2^owner_shift regions per axis over the grid [owner_grid_origin, owner_grid_origin +
+  /// owner_grid_dims) in block coordinates, x fastest; blocks outside the grid belong to the nearest cell's owner.
+  const unsigned char *owner_table;
+  int owner_grid_origin[3];
+  int owner_grid_dims[3];
   /// Per-ray RayFilterFlag bits of a batch the CALLER filtered (ohmhip_map_integrate_rays_filtered; null otherwise):
   /// the device then applies no filter of its own and takes "end point was clipped" from kRffClippedEnd (bit 2).
   const unsigned char *batch_filter_flags;
@@ -217,15 +223,46 @@ __host__ __device__ inline uint32_t regionOwner(int rx, int ry, int rz, int shif
   return h % world;
 }
 
-__host__ __device__ inline bool ownsRegion(const MapConst &mc, uint64_t key)
+/// Cell of a partition table that region coordinate `r` falls in along one axis (clamped: the table's outer cells
+/// extend outwards without limit, so a territory that reaches the table's edge owns everything beyond it).
+__host__ __device__ inline int partitionCell(int r, int shift, int grid_origin, int grid_dim)
+{
+  const int c = (r >> shift) - grid_origin;
+  return (c < 0) ? 0 : ((c >= grid_dim) ? grid_dim - 1 : c);
+}
+
+/// Owner of region (rx, ry, rz) under a partition: the table when there is one (`table` must be addressable by the
+/// caller: the device copy in kernels, the host copy on the host), the block hash otherwise.
+__host__ __device__ inline uint32_t partitionOwner(const unsigned char *table, const int grid_origin[3],
+                                                   const int grid_dims[3], int shift, uint32_t world, int rx, int ry,
+                                                   int rz)
+{
+  if (table)
+  {
+    const int cx = partitionCell(rx, shift, grid_origin[0], grid_dims[0]);
+    const int cy = partitionCell(ry, shift, grid_origin[1], grid_dims[1]);
+    const int cz = partitionCell(rz, shift, grid_origin[2], grid_dims[2]);
+    return table[(size_t(cz) * size_t(grid_dims[1]) + size_t(cy)) * size_t(grid_dims[0]) + size_t(cx)];
+  }
+  return regionOwner(rx, ry, rz, shift, world);
+}
+
+/// Owner of a region under the map's partition (device code: MapConst::owner_table is a device pointer).
+__device__ inline uint32_t regionOwnerOf(const MapConst &mc, uint64_t key)
+{
+  int16_t r[3];
+  unpackRegionKey(key, r);
+  return partitionOwner(mc.owner_table, mc.owner_grid_origin, mc.owner_grid_dims, mc.owner_shift, mc.owner_world, r[0],
+                        r[1], r[2]);
+}
+
+__device__ inline bool ownsRegion(const MapConst &mc, uint64_t key)
 {
   if (mc.owner_world <= 1u)
   {
     return true;
   }
-  int16_t r[3];
-  unpackRegionKey(key, r);
-  return regionOwner(r[0], r[1], r[2], mc.owner_shift, mc.owner_world) == mc.owner_rank;
+  return regionOwnerOf(mc, key) == mc.owner_rank;
 }
 
 __host__ __device__ inline uint32_t hashRegionKey(uint64_t key, uint32_t mask)

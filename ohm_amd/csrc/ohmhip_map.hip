@@ -220,6 +220,15 @@ struct ohmhip_map_s
   /// Traversal layer only: per-voxel fixed-point sum of a batch's ray lengths (zero between batches).
   unsigned long long *d_traversal_acc = nullptr;
   DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;
+  /// Partitioned map (partition_impl.h): the owner table of ohmhip_map_set_region_partition (host copy for
+  /// ohmhip_map_region_owners, device copy behind MapConst::owner_table) and the scratch of ohmhip_map_route_rays.
+  struct PartitionState
+  {
+    std::vector<unsigned char> table_host;
+    DevBuf table_dev, masks, block_counts, totals;
+    uint32_t *h_totals = nullptr;      ///< pinned, device visible: rays per destination of the last routing
+    uint32_t *h_totals_dev = nullptr;
+  } partition;
   DevBuf use_scratch;  ///< (slot, stamp) pairs of re-admitted regions (queueReadmission)
   /// After how many batches the regions re-admitted lately came back (ring of the last 256): their median stands in as
   /// the period of regions that have no history of their own yet (evictColdRegions).
@@ -2052,6 +2061,14 @@ try
   m->merge_keys_dev.release();
   m->merge_delta.release();
   m->merge_observers.release();
+  m->partition.table_dev.release();
+  m->partition.masks.release();
+  m->partition.block_counts.release();
+  m->partition.totals.release();
+  if (m->partition.h_totals)
+  {
+    (void)hipHostFree(m->partition.h_totals);
+  }
   if (m->d_event_count)
   {
     (void)hipFree(m->d_event_count);
@@ -2345,10 +2362,16 @@ namespace
 /// run later with a collected batch.
 int validateBatchRequest(ohmhip_map_t m, unsigned ray_flags)
 {
-  (void)ray_flags;  // (every RayFlag combination of the CPU mappers is supported since round 3)
+  // (every RayFlag combination of the CPU mappers is supported since round 3 -- on ONE map)
   switch (m->config.mode)
   {
   case OHMHIP_MODE_OCCUPANCY:
+    if ((ray_flags & OHMHIP_RF_STOP_ON_FIRST_OCCUPIED) && m->mc.owner_world > 1u)
+    {
+      // Where a ray stops depends on every voxel before that point, also those in regions another rank owns: the one
+      // flag whose effect is not local to a voxel, hence not available on a region-partitioned map.
+      return OHMHIP_ERR_UNSUPPORTED;
+    }
     return m->layers[OHMHIP_LID_OCCUPANCY] ? OHMHIP_OK : OHMHIP_ERR_INVALID_ARG;
   case OHMHIP_MODE_NDT_OM:
   case OHMHIP_MODE_NDT_TM:
@@ -4068,6 +4091,8 @@ try
   m->mc.owner_world = (world_size > 1) ? world_size : 0u;
   m->mc.owner_rank = (world_size > 1) ? rank : 0u;
   m->mc.owner_shift = block_shift;
+  m->mc.owner_table = nullptr;  // the block hash deals the regions (a table: ohmhip_map_set_region_partition)
+  m->partition.table_host.clear();
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH
@@ -4164,3 +4189,4 @@ OHMHIP_ABI_CATCH
 }  // extern "C"
 
 #include "merge_impl.h"
+#include "partition_impl.h"

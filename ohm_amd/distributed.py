@@ -22,6 +22,15 @@ ever crosses a link and the union of the ranks' regions is bit-identical to one 
 because a voxel's update sequence depends only on the rays that reach it, in order.  The line-walk work (the dominant
 kernel) is partitioned, the per-ray front half (set-up and binning) is repeated on every rank.
 
+Partitioned map -- the default of `bench.py --gpus N` (`RegionPartition`, `territories_from_origins`,
+`exchange_routed_rays`, `PartitionedIntegrator`): owner-computes with the rays ROUTED instead of all-gathered.  Every
+rank owns a spatially coherent territory of region blocks (a table: each block belongs to the rank whose sensor origin
+is nearest), the library finds for every local ray the ranks owning a region its walk touches -- exactly, with the
+integration's own enumeration (`GpuMap.routeRays`) -- and the ranks exchange only those rays (one all-to-all of 48 B per
+routed ray; C4: a quarter of the rays cross into a neighbour's territory).  Each rank integrates what is addressed to it
+in (source rank, ray) order, so the union of the ranks' regions is bit-identical to one map integrating rank 0's batch,
+then rank 1's, ... -- clamps included, every map type.
+
 The functions below are backend agnostic (any torch device / process group) so the protocol itself is covered by
 world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py).
 """
@@ -389,3 +398,253 @@ def merge_deviation(merged_chunks, sequential_chunks, keys=None, rel=1e-5):
         if d.size:
             out["max_abs_delta"] = max(out["max_abs_delta"], float(d.max()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Partitioned map: territories, ray routing, all-to-all of the routed rays.
+# ---------------------------------------------------------------------------------------------------------------------
+class RegionPartition:
+    """Who owns which region among `world_size` ranks (include/ohmhip.h: ohmhip_partition): blocks of 2^block_shift
+    regions per axis dealt by a table over the block grid [grid_origin, grid_origin + table.shape) -- `table[x, y, z]`
+    = owner rank, blocks outside the grid go to the nearest cell's owner -- or, with table=None, by the library's block
+    hash.  Identical on every rank apart from `rank`."""
+
+    def __init__(self, world_size, rank, block_shift=0, grid_origin=(0, 0, 0), table=None):
+        self.world_size = int(world_size)
+        self.rank = int(rank)
+        self.block_shift = int(block_shift)
+        self.grid_origin = tuple(int(v) for v in grid_origin)
+        self.table = None if table is None else np.ascontiguousarray(table, dtype=np.uint8)
+        if self.table is not None:
+            assert self.table.ndim == 3 and self.table.size > 0 and int(self.table.max()) < self.world_size
+            # the C ABI wants x fastest
+            self._flat = np.ascontiguousarray(np.transpose(self.table, (2, 1, 0))).reshape(-1)
+        else:
+            self._flat = None
+
+    def c_struct(self, self_rank=True):
+        from . import _lib as L
+        p = L.Partition()
+        p.world_size = self.world_size
+        p.rank = self.rank if self_rank else 0
+        p.block_shift = self.block_shift
+        for a in range(3):
+            p.grid_origin[a] = self.grid_origin[a]
+            p.grid_dims[a] = 0 if self.table is None else self.table.shape[a]
+        p.owners = None if self._flat is None else self._flat.ctypes.data
+        return p
+
+    def owners(self, keys):
+        """Owner rank of each int16 (n, 3) region key (the library's rule, evaluated on the host; no device)."""
+        from . import _lib as L
+        import ctypes as C
+        keys = np.ascontiguousarray(keys, dtype=np.int16).reshape(-1, 3)
+        out = np.zeros(len(keys), dtype=np.uint32)
+        L.check(L.lib.ohmhip_partition_owners(C.byref(self.c_struct()), keys.ctypes.data, len(keys), out.ctypes.data),
+                "partition_owners")
+        return out
+
+    def with_rank(self, rank):
+        return RegionPartition(self.world_size, rank, self.block_shift, self.grid_origin, self.table)
+
+
+def territories_from_origins(origins, world_size, rank, region_size, block_shift=1, margin=40.0, map_origin=(0, 0, 0)):
+    """A RegionPartition that gives every block of 2^block_shift regions to the rank whose sensor origin is nearest to
+    the block's centre (ties: the lower rank) -- spatially coherent territories, so only rays that reach into a
+    neighbour's territory travel.  `origins`: one (x, y, z) per rank, or a list of points per rank; `region_size`: a
+    region's edge in metres per axis (resolution x region voxel dimensions); the table covers the origins' bounding box
+    grown by `margin` metres, everything beyond belongs to the nearest cell's owner.  Deterministic: every rank
+    computes the same table."""
+    pts, owner_of = [], []
+    for r, o in enumerate(origins):
+        o = np.asarray(o, dtype=np.float64).reshape(-1, 3)
+        pts.append(o)
+        owner_of += [r % world_size] * len(o)
+    pts = np.concatenate(pts)
+    owner_of = np.asarray(owner_of, dtype=np.int64)
+    size = np.broadcast_to(np.asarray(region_size, dtype=np.float64), (3,))
+    mo = np.asarray(map_origin, dtype=np.float64)
+    block = size * (1 << block_shift)
+    # region r spans [r - 1/2, r + 1/2) x size + map origin (ohm/OccupancyMap.h:757-778): block b = regions
+    # [b * 2^shift, (b + 1) * 2^shift) spans [(b * 2^shift - 1/2) * size, ...)
+    def block_of(p):
+        return np.floor(((p - mo) / size + 0.5) / (1 << block_shift)).astype(np.int64)
+    lo = block_of(pts.min(axis=0) - margin)
+    hi = block_of(pts.max(axis=0) + margin)
+    dims = (hi - lo + 1).astype(np.int64)
+    ix, iy, iz = np.meshgrid(np.arange(dims[0]), np.arange(dims[1]), np.arange(dims[2]), indexing="ij")
+    cells = np.stack([ix, iy, iz], axis=-1) + lo
+    centres = ((cells + 0.5) * (1 << block_shift) - 0.5) * size + mo
+    d2 = ((centres[..., None, :] - pts[None, None, None, :, :]) ** 2).sum(axis=-1)
+    # nearest origin, ties to the lower rank: order the points by rank first (stable argmin picks the first minimum)
+    order = np.argsort(owner_of, kind="stable")
+    nearest = order[np.argmin(d2[..., order], axis=-1)]
+    table = owner_of[nearest].astype(np.uint8)
+    return RegionPartition(world_size, rank, block_shift, tuple(int(v) for v in lo), table)
+
+
+def exchange_routed_rays(routed, counts, group=None):
+    """All-to-all of routed rays over a torch.distributed group (RCCL for device tensors, gloo on the CPU): `routed` is a
+    (sum(counts), 6) float64 tensor holding this rank's rays per destination, blocks back to back in rank order;
+    returns (received (k, 6) tensor on the same device, rays per source rank) -- the rays addressed to this rank in
+    (source rank, ray) order."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    send = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=routed.device)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_counts = [int(c) for c in recv.tolist()]
+    out = torch.empty((sum(recv_counts), 6), dtype=routed.dtype, device=routed.device)
+    dist.all_to_all_single(out.view(-1), routed.reshape(-1, 6)[:int(sum(int(c) for c in counts))].reshape(-1),
+                           [6 * c for c in recv_counts], [6 * int(c) for c in counts], group=group)
+    assert len(recv_counts) == world
+    return out, recv_counts
+
+
+class PartitionedIntegrator:
+    """Exact multi-rank integration into a region-partitioned map.  Usage on every rank:
+        part = territories_from_origins(all_origins, world, rank, region_size)
+        integ = PartitionedIntegrator(gpu_map, part);  integ.integrateRays(local_rays_device_tensor)
+    `gpu_map` must be empty; it ends up holding this rank's territory of the map ONE device would have built from
+    rank 0's batch, then rank 1's, ... of every call.  `comm` (Communicator): the exchange runs inside the library over
+    RCCL; otherwise over the torch.distributed group (RCCL for device tensors under the nccl backend, host-staged under
+    gloo)."""
+
+    def __init__(self, gpu_map, partition, group=None, comm=None):
+        self.gpu_map = gpu_map
+        self.partition = partition
+        self.group = group
+        self.comm = comm
+        gpu_map.setRegionPartition(partition)
+        self._routed = None
+        self._recv = None
+        self._stream = None
+        self.last = {}
+
+    def _ensure(self, name, rays):
+        import torch
+        t = getattr(self, name)
+        if t is None or t.shape[0] < rays:
+            t = torch.empty((max(int(rays * 1.25) + 1024, 4096), 6), dtype=torch.float64, device="cuda")
+            setattr(self, name, t)
+        return t
+
+    def route(self, d_rays, n_rays, ray_update_flags=0):
+        """Route `n_rays` rays at device pointer `d_rays`; returns (routed tensor, counts, visits)."""
+        routed = self._ensure("_routed", 2 * n_rays)
+        while True:
+            counts, visits, fits = self.gpu_map.routeRays(d_rays, n_rays, routed.data_ptr(), routed.shape[0],
+                                                          ray_update_flags)
+            if fits:
+                return routed, counts, visits
+            routed = self._ensure("_routed", int(counts.sum()))
+
+    def integrateRays(self, local_rays, ray_update_flags=0):
+        """local_rays: (2N, 3) float64 CUDA tensor (origin, sample pairs).  Collective.  Returns the number of rays this
+        rank integrated (its own and received ones that pass the ray filter)."""
+        import ctypes as C
+        import torch
+        from . import _lib as L
+        gm = self.gpu_map
+        local = local_rays.reshape(-1, 6)
+        torch.cuda.current_stream().synchronize()  # the library works on its own HIP streams
+        gm.wait()                                  # the previous batch may still read the receive buffer
+        routed, counts, visits = self.route(local.data_ptr(), local.shape[0], ray_update_flags)
+        sent = int(counts.sum())
+        if self.comm is not None:
+            send_counts = np.ascontiguousarray(counts, dtype=np.uint32)
+            recv_counts = np.zeros_like(send_counts)
+            L.check(L.lib.ohmhip_comm_exchange_counts(self.comm._handle, send_counts.ctypes.data,
+                                                      recv_counts.ctypes.data, None), "exchange_counts")
+            n_recv = int(recv_counts.sum())
+            recv = self._ensure("_recv", n_recv)
+            L.check(L.lib.ohmhip_comm_exchange_rays(self.comm._handle, routed.data_ptr(), send_counts.ctypes.data,
+                                                    recv.data_ptr(), recv_counts.ctypes.data, None), "exchange_rays")
+            L.check(L.lib.ohmhip_device_synchronize(), "device_synchronize")
+            recv_counts = [int(c) for c in recv_counts]
+        else:
+            import torch.distributed as dist
+            backend = dist.get_backend(self.group)
+            block = routed[:sent]
+            if backend == "gloo":
+                got, recv_counts = exchange_routed_rays(block.cpu(), counts, self.group)
+                n_recv = got.shape[0]
+                recv = self._ensure("_recv", n_recv)
+                recv[:n_recv].copy_(got)
+            else:
+                got, recv_counts = exchange_routed_rays(block, counts, self.group)
+                n_recv = got.shape[0]
+                recv = got
+                self._recv = got
+            torch.cuda.current_stream().synchronize()
+        self.last = {"rays_local": int(local.shape[0]), "rays_routed": sent, "rays_kept": int(counts[self.partition.rank]),
+                     "rays_received": n_recv, "recv_counts": recv_counts, "visits_local": visits}
+        if n_recv == 0:
+            return 0
+        return gm.integrateRaysDevice(recv.data_ptr(), 2 * n_recv, ray_update_flags)
+
+
+def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timings=None):
+    """The partitioned integration for several GpuMaps living in ONE process (stand-ins for ranks on a single GPU: tests,
+    and bench.py's one-GPU C4 leg).  gpu_maps[r] carries rank r's partition (setRegionPartition); shards[r]: rank r's
+    (2N_r, 3) float64 host rays.  Every rank's rays are routed by its own map (the library's kernels), the blocks are
+    re-assembled per destination in (source rank, ray) order -- what the all-to-all delivers -- and integrated.  Returns
+    a dict of counts: rays routed per (source, destination), rays received per rank."""
+    import ctypes as C
+    import time
+    from . import _lib as L
+    world = len(gpu_maps)
+    blocks = [[None] * world for _ in range(world)]
+    matrix = np.zeros((world, world), dtype=np.int64)
+    visits = []
+    for r, (gm, rays) in enumerate(zip(gpu_maps, shards)):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = rays.shape[0]
+        src, out = L._vp(), L._vp()
+        L.check(L.lib.ohmhip_buffer_create(C.byref(src), max(rays.nbytes, 48), 3), "buffer_create")
+        L.check(L.lib.ohmhip_buffer_write(src, rays.ctypes.data, rays.nbytes, 0, None, None, None), "buffer_write")
+        cap = max(2 * n, 1024)
+        while True:
+            L.check(L.lib.ohmhip_buffer_create(C.byref(out), 48 * cap, 3), "buffer_create")
+            d_src, d_out = L._vp(), L._vp()
+            L.check(L.lib.ohmhip_buffer_ptr(src, C.byref(d_src)))
+            L.check(L.lib.ohmhip_buffer_ptr(out, C.byref(d_out)))
+            t0 = time.perf_counter()
+            counts, v, fits = gm.routeRays(d_src, n, d_out, cap, ray_update_flags)
+            if timings is not None:
+                timings.setdefault("route_ms", []).append(1e3 * (time.perf_counter() - t0))
+            if fits:
+                break
+            L.lib.ohmhip_buffer_destroy(out)
+            cap = int(counts.sum()) + 1024
+        visits.append(v)
+        total = int(counts.sum())
+        host = np.zeros((total, 6), dtype=np.float64)
+        if total:
+            L.check(L.lib.ohmhip_buffer_read(out, host.ctypes.data, host.nbytes, 0, None, None, None), "buffer_read")
+        at = 0
+        for d in range(world):
+            blocks[r][d] = host[at:at + int(counts[d])]
+            matrix[r, d] = int(counts[d])
+            at += int(counts[d])
+        L.lib.ohmhip_buffer_destroy(src)
+        L.lib.ohmhip_buffer_destroy(out)
+    integrated = []
+    for d, gm in enumerate(gpu_maps):
+        stream = np.concatenate([blocks[r][d] for r in range(world)]) if world else np.zeros((0, 6))
+        if stream.shape[0]:
+            buf, ptr = L._vp(), L._vp()
+            L.check(L.lib.ohmhip_buffer_create(C.byref(buf), stream.nbytes, 3), "buffer_create")
+            L.check(L.lib.ohmhip_buffer_write(buf, stream.ctypes.data, stream.nbytes, 0, None, None, None))
+            L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(ptr)))
+            gm.wait()
+            t0 = time.perf_counter()
+            integrated.append(gm.integrateRaysDevice(ptr, 2 * stream.shape[0], ray_update_flags))
+            gm.wait()
+            if timings is not None:
+                timings.setdefault("integrate_ms", []).append(1e3 * (time.perf_counter() - t0))
+            L.lib.ohmhip_buffer_destroy(buf)
+        else:
+            integrated.append(0)
+    return {"routed": matrix, "received": matrix.sum(axis=0), "integrated": integrated, "visits_local": visits}

@@ -477,6 +477,36 @@ class GpuMap(RayMapper):
                 "setRegionOwnership")
         self._ownership = (int(world_size), int(rank), int(block_shift))
 
+    def setRegionPartition(self, partition):
+        """Partitioned multi-GPU mode (include/ohmhip.h "Partitioned map"): like setRegionOwnership, with the region blocks
+        dealt by `partition` (ohm_amd.distributed.RegionPartition: a block -> rank table, or the block hash).  Call
+        before the first integrateRays."""
+        L.check(L.lib.ohmhip_map_set_region_partition(self._handle, C.byref(partition.c_struct(self_rank=True))),
+                "setRegionPartition")
+        self._partition = partition
+        self._ownership = (partition.world_size, partition.rank, partition.block_shift)
+
+    def regionOwners(self, keys):
+        """Owner rank of each int16 (n, 3) region key under this map's partition."""
+        keys = np.ascontiguousarray(keys, dtype=np.int16).reshape(-1, 3)
+        owners = np.zeros(len(keys), dtype=np.uint32)
+        L.check(L.lib.ohmhip_map_region_owners(self._handle, keys.ctypes.data, len(keys), owners.ctypes.data),
+                "regionOwners")
+        return owners
+
+    def routeRays(self, d_rays, ray_count, d_routed, capacity, ray_update_flags=0, d_index=None):
+        """ohmhip_map_route_rays: destinations of `ray_count` rays in device memory under this map's partition, compacted
+        per destination into `d_routed` (device pointer, `capacity` rays).  Returns (counts per rank, voxel visits of the
+        input rays, fits): fits is False when the routed rays exceed `capacity` (grow and repeat)."""
+        world = max(1, self._ownership[0]) if getattr(self, "_ownership", None) else 1
+        counts = np.zeros(world, dtype=np.uint32)
+        visits = C.c_uint64(0)
+        status = L.lib.ohmhip_map_route_rays(self._handle, d_rays, int(ray_count), int(ray_update_flags), d_routed,
+                                             d_index, int(capacity), counts.ctypes.data, C.byref(visits))
+        if status not in (L.OK, L.ERR_CAPACITY):
+            L.check(status, "routeRays")
+        return counts, int(visits.value), status == L.OK
+
     def lineKeys(self, lines, max_keys_per_line=1024):
         """LineKeysQueryGpu equivalent: voxel keys along each query line (start/end pairs, (2N, 3) float64).
         Returns (keys, counts): keys is (N, max_keys, 10) uint8 viewed as int16 region[3] + uint8 voxel[4]."""

@@ -1,0 +1,232 @@
+"""-m gpu: the partitioned map (include/ohmhip.h "Partitioned map"; ohm_amd/distributed.py: RegionPartition,
+PartitionedIntegrator) -- the exact multi-GPU mode `bench.py --gpus N` runs.  `world` maps on the one test GPU stand in
+for `world` ranks (integrate_partitioned_in_process): every rank's rays are routed by the library's kernels under its
+territory table, the destination blocks are re-assembled in (source rank, ray) order as the all-to-all delivers them,
+and each map integrates what is addressed to it.  Bar: the union of the ranks' regions is the map ONE device -- and the
+CPU oracle -- builds from rank 0's batch, then rank 1's, ...: occupancy / mean / TSDF bit exact, NDT within 1e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ohm_amd import GpuMap, GpuNdtMap, GpuTsdfMap, OccupancyMap, RayFlag, synth
+from ohm_amd import _lib as L
+from ohm_amd import distributed as D
+
+from parity import assert_parity, compare_maps, make_oracle
+from partition_ref import route_reference
+
+pytestmark = pytest.mark.gpu
+
+ORIGINS3 = [(0.05, 0.05, 0.05), (9.65, 0.05, 0.05), (4.85, 8.05, 0.05)]
+
+
+def _union_of_owned(maps, part):
+    union = {}
+    for rank, map_ in enumerate(maps):
+        keys = np.array(sorted(map_.chunks.keys()), dtype=np.int16).reshape(-1, 3)
+        owners = part.owners(keys) if len(keys) else np.zeros(0, np.uint32)
+        for key, owner in zip(map(tuple, keys.tolist()), owners):
+            assert owner == rank, f"rank {rank} holds region {key} owned by {owner}"
+            assert key not in union
+            union[key] = map_.chunks[key]
+    return union
+
+
+def _device_route(gm, rays, flags=0, capacity=None, want_index=False):
+    """ohmhip_map_route_rays on host rays -> (routed (k, 6), counts, visits, fits[, index])."""
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+    n = rays.shape[0]
+    cap = 2 * n + 16 if capacity is None else capacity
+    src, out, idx = L._vp(), L._vp(), L._vp()
+    L.check(L.lib.ohmhip_buffer_create(C.byref(src), max(rays.nbytes, 48), 3))
+    L.check(L.lib.ohmhip_buffer_write(src, rays.ctypes.data, rays.nbytes, 0, None, None, None))
+    L.check(L.lib.ohmhip_buffer_create(C.byref(out), 48 * max(cap, 1), 3))
+    L.check(L.lib.ohmhip_buffer_create(C.byref(idx), 4 * max(cap, 1), 3))
+    d_src, d_out, d_idx = L._vp(), L._vp(), L._vp()
+    L.check(L.lib.ohmhip_buffer_ptr(src, C.byref(d_src)))
+    L.check(L.lib.ohmhip_buffer_ptr(out, C.byref(d_out)))
+    L.check(L.lib.ohmhip_buffer_ptr(idx, C.byref(d_idx)))
+    counts, visits, fits = gm.routeRays(d_src, n, d_out, cap, flags, d_index=d_idx if want_index else None)
+    total = min(int(counts.sum()), cap)
+    routed = np.zeros((total, 6), dtype=np.float64)
+    index = np.zeros(total, dtype=np.uint32)
+    if total:
+        L.check(L.lib.ohmhip_buffer_read(out, routed.ctypes.data, routed.nbytes, 0, None, None, None))
+        if want_index:
+            L.check(L.lib.ohmhip_buffer_read(idx, index.ctypes.data, index.nbytes, 0, None, None, None))
+    for b in (src, out, idx):
+        L.lib.ohmhip_buffer_destroy(b)
+    return (routed, counts, visits, fits, index) if want_index else (routed, counts, visits, fits)
+
+
+def test_device_routing_equals_the_oracle_walk(gpu):
+    """Destinations from the library's kernel == destinations derived from the CPU oracle's line walk, ray by ray and in
+    ray order; the visit count equals what integrating the rays reports; a short output buffer is reported, not
+    overrun."""
+    world = 3
+    rays = np.concatenate([synth.rays_c1(n=1500, origin=ORIGINS3[1], max_range=14.0, seed=21),
+                           synth.random_rays(700, extent=9.0, seed=5, origin_spread=6.0)])
+    # degenerate members: zero length, start == end voxel, a ray the default filter rejects (non-finite)
+    extra = np.array([[1.0, 1.0, 1.0], [1.0, 1.0, 1.0], [2.0, 2.0, 2.0], [2.03, 2.0, 2.0],
+                      [0.0, 0.0, 0.0], [np.inf, 0.0, 0.0]])
+    rays = np.concatenate([rays, extra])
+    for shift in (0, 1):
+        part = D.territories_from_origins(ORIGINS3, world, 1, 3.2, block_shift=shift, margin=12.0)
+        map_ = OccupancyMap(0.1)
+        gm = GpuMap(map_)
+        gm.setRegionPartition(part)
+        routed, counts, visits, fits, index = _device_route(gm, rays, want_index=True)
+        assert fits
+        om = make_oracle(map_)
+        ref, ref_counts = route_reference(om, part, rays[:-2], world)  # (the rejected ray goes nowhere)
+        assert counts.tolist() == ref_counts
+        assert np.array_equal(routed, ref)
+        assert np.array_equal(rays.reshape(-1, 6)[index], routed)
+        assert (counts > 0).all() and counts.sum() > rays.shape[0] // 2  # some rays reach two territories
+        # visits: the same figure an unpartitioned map reports for these rays
+        plain = GpuMap(OccupancyMap(0.1))
+        plain.setBatchCoalescing(0)
+        plain.integrateRays(rays)
+        plain.wait()
+        assert visits == plain.stats()["voxel_visits"]
+        # capacity: counts stay valid, nothing is written past the end
+        short = int(counts.sum()) - 5
+        r2, c2, _, fits2 = _device_route(gm, rays, capacity=short)
+        assert not fits2 and c2.tolist() == counts.tolist() and np.array_equal(r2, routed[:short])
+        gm.close()
+        plain.close()
+
+
+def test_hash_partition_routes_like_region_ownership(gpu):
+    """No table: the block hash.  Routing + integrating what arrives == giving every rank the whole stream."""
+    world = 3
+    rays = synth.rays_c1(n=6000, max_range=12.0, seed=9)
+    part = D.RegionPartition(world, 0, block_shift=1)
+    maps = [OccupancyMap(0.1, layers=("occupancy", "mean")) for _ in range(world)]
+    gms = [GpuMap(m) for m in maps]
+    for r, gm in enumerate(gms):
+        gm.setRegionPartition(part.with_rank(r))
+    D.integrate_partitioned_in_process(gms, [rays] + [np.zeros((0, 3))] * (world - 1))
+    om = make_oracle(maps[0])
+    om.integrate_occupancy(rays)
+    for gm in gms:
+        gm.syncVoxels()
+        gm.close()
+    union = _union_of_owned(maps, part)
+    assert_parity(compare_maps(om.chunks(), union, ["occupancy", "mean"], exact_float=True))
+
+
+@pytest.mark.parametrize("flags", [0, int(RayFlag.kRfEndPointAsFree), int(RayFlag.kRfExcludeOrigin),
+                                   int(RayFlag.kRfExcludeSample),
+                                   int(RayFlag.kRfExcludeUnobserved | RayFlag.kRfExcludeFree)])
+def test_occupancy_partitioned_is_exact(gpu, flags):
+    world = 3
+    layers = ("occupancy", "mean")
+    maps, gms = [], []
+    part0 = D.territories_from_origins(ORIGINS3, world, 0, 3.2, block_shift=0, margin=16.0)
+    for rank in range(world):
+        map_ = OccupancyMap(0.1, (32, 32, 32), layers=layers)
+        gm = GpuMap(map_)
+        gm.setRegionPartition(part0.with_rank(rank))
+        maps.append(map_)
+        gms.append(gm)
+    om = make_oracle(maps[0])
+    travelled = 0
+    for rnd in range(3):  # ragged shards, several rounds: clamps engage between the ranks' updates
+        shards = [synth.rays_c1(n=7000 + 900 * r, origin=ORIGINS3[r], max_range=13.0, seed=60 + 10 * rnd + r)
+                  for r in range(world)]
+        info = D.integrate_partitioned_in_process(gms, shards, flags)
+        for s in shards:
+            om.integrate_occupancy(s, flags=flags)
+        m = info["routed"]
+        assert all(m[r, r] > 0 for r in range(world))
+        travelled += int(m.sum() - np.trace(m))
+        for r in range(world):  # a rank keeps most of its rays and sends only what reaches a neighbour
+            assert m[r].sum() < 2 * (shards[r].shape[0] // 2)
+    assert travelled > 0
+    for gm in gms:
+        gm.syncVoxels()
+        gm.close()
+    union = _union_of_owned(maps, part0)
+    assert_parity(compare_maps(om.chunks(), union, list(layers), exact_float=True))
+    assert min(len(m.chunks) for m in maps) > 0
+
+
+def test_stop_on_first_occupied_is_refused_on_a_partitioned_map(gpu):
+    """Where a ray stops depends on voxels other ranks own: the one RayFlag that is not local to a voxel."""
+    gm = GpuMap(OccupancyMap(0.1))
+    gm.setRegionPartition(D.RegionPartition(2, 0))
+    with pytest.raises(L.OhmHipError) as err:
+        gm.integrateRays(synth.rays_c0(n=100, length=2.0), ray_update_flags=int(RayFlag.kRfStopOnFirstOccupied))
+    assert err.value.status == L.ERR_UNSUPPORTED
+    gm.close()
+
+
+def test_partition_rejected_once_regions_exist(gpu):
+    gm = GpuMap(OccupancyMap(0.1))
+    gm.integrateRays(synth.rays_c0(n=100, length=2.0))
+    with pytest.raises(Exception):
+        gm.setRegionPartition(D.RegionPartition(2, 0))
+    gm.close()
+    # a table naming a rank outside the world, or more than 64 ranks, is refused
+    gm = GpuMap(OccupancyMap(0.1))
+    bad = D.RegionPartition(2, 0, 0, (0, 0, 0), np.zeros((2, 2, 2), dtype=np.uint8))
+    bad._flat[3] = 5
+    with pytest.raises(Exception):
+        gm.setRegionPartition(bad)
+    with pytest.raises(Exception):
+        gm.setRegionPartition(D.RegionPartition(65, 0))
+    gm.close()
+
+
+def test_ndt_partitioned(gpu):
+    world = 2
+    origins = [(0.05, 0.05, 0.05), (10.05, 0.05, 0.05)]
+    part0 = D.territories_from_origins(origins, world, 0, 6.4, block_shift=0, margin=30.0)
+    maps, gms = [], []
+    for rank in range(world):
+        map_ = OccupancyMap(0.2, (32, 32, 32), layers=("occupancy",))
+        gm = GpuNdtMap(map_)
+        gm.setRegionPartition(part0.with_rank(rank))
+        maps.append(map_)
+        gms.append(gm)
+    om = make_oracle(maps[0])
+    g = gms[0]
+    om.set_ndt(sensor_noise=g.sensor_noise, sample_threshold=g.sample_threshold, adaptation_rate=g.adaptation_rate,
+               reinit_threshold=g.reinitialise_covariance_threshold,
+               reinit_count=g.reinitialise_covariance_point_count, ndt_tm=False)
+    for rnd in range(2):
+        shards = [synth.rays_c2(n=15000, origin=origins[r], seed=70 + rnd + 5 * r) for r in range(world)]
+        D.integrate_partitioned_in_process(gms, shards)
+        for s in shards:
+            om.integrate_ndt(s)
+    for gm in gms:
+        gm.syncVoxels()
+        gm.close()
+    union = _union_of_owned(maps, part0)
+    assert_parity(compare_maps(om.chunks(), union, list(maps[0].layers), rel=1e-5))
+
+
+def test_tsdf_partitioned(gpu):
+    world = 3
+    part0 = D.territories_from_origins(ORIGINS3, world, 0, 3.2, block_shift=1, margin=30.0)
+    maps, gms = [], []
+    for rank in range(world):
+        map_ = OccupancyMap(0.1, (32, 32, 32), layers=("tsdf",))
+        gm = GpuTsdfMap(map_, default_truncation_distance=0.1)
+        gm.setRegionPartition(part0.with_rank(rank))
+        maps.append(map_)
+        gms.append(gm)
+    om = make_oracle(maps[0])
+    opts = gms[0].tsdf_options
+    om.set_tsdf(max_weight=opts[0], trunc=opts[1], dropoff=opts[2], sparsity=opts[3])
+    shards = [synth.rays_c2(n=9000, origin=ORIGINS3[r], seed=90 + r) for r in range(world)]
+    D.integrate_partitioned_in_process(gms, shards)
+    for s in shards:
+        om.integrate_tsdf(s)
+    for gm in gms:
+        gm.syncVoxels()
+        gm.close()
+    union = _union_of_owned(maps, part0)
+    assert_parity(compare_maps(om.chunks(), union, ["tsdf"], exact_float=True))
