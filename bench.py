@@ -134,7 +134,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the P-process leg of cpu_baseline")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--no-deviation", action="store_true", help="N > 1: skip the untimed merge-vs-sequential check")
+    ap.add_argument("--no-deviation", action="store_true", help="N > 1: skip the untimed check against sequential integration")
+    ap.add_argument("--multi-gpu-mode", choices=("partitioned", "replica-merge"), default="partitioned",
+                    help="N > 1: partitioned map with routed rays (exact; default) or replicated maps reconciled by the "
+                         "additive delta all-reduce (approximate where clamps engage)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -187,9 +190,16 @@ def main():
         workload = "C1: GpuMap occupancy-only, 0.1 m voxels, 32^3 regions, 1M-ray 64-beam lidar batch, 7.5-30 m"
     else:
         rays = synth.rays_c4_shard(rank, n=n_rays)
-        workload = ("C4: GpuMap occupancy, 0.1 m voxels, 1M-ray lidar batch per sensor origin, one origin per GPU, "
-                    "replicated maps, regions touched by more than one GPU merged by an RCCL delta all-reduce after "
-                    "every batch (inside the timed region)")
+        if args.multi_gpu_mode == "partitioned":
+            workload = ("C4: GpuMap occupancy, 0.1 m voxels, 1M-ray lidar batch per sensor origin, one origin per GPU, map "
+                        "partitioned into territories (each region block belongs to the nearest origin's GPU); every "
+                        "step routes the rays to the owners of the regions they cross (exact enumeration on the "
+                        "device), exchanges the routed rays (all-to-all, 48 B per ray) and integrates what arrives -- "
+                        "all inside the timed region; bit-identical to one map integrating the shards in rank order")
+        else:
+            workload = ("C4: GpuMap occupancy, 0.1 m voxels, 1M-ray lidar batch per sensor origin, one origin per GPU, "
+                        "replicated maps, regions touched by more than one GPU merged by an RCCL delta all-reduce after "
+                        "every batch (inside the timed region)")
 
     map_ = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
     gm = ohm_amd.GpuMap(map_, gpu_mem_size=8 << 30)
@@ -204,6 +214,9 @@ def main():
     merger = None
     comm = None
     merge_log = []
+    integ = None
+    route_log = []
+    partitioned = world > 1 and args.multi_gpu_mode == "partitioned"
     if world > 1:
         from ohm_amd import distributed as D
         # RCCL communicator owned by the library when every rank has its own GPU; otherwise (single-GPU smoke runs with
@@ -223,7 +236,12 @@ def main():
                 comm.close()
                 comm = None
                 merge_note = "library RCCL communicator missing on another rank: merge staged over the torch group"
-        merger = D.ReplicaMerger(gm, comm=comm)
+        if partitioned:
+            origins = [synth.C4_ORIGINS[r % len(synth.C4_ORIGINS)] for r in range(world)]
+            part = D.territories_from_origins(origins, world, rank, 32 * resolution, block_shift=1, margin=40.0)
+            integ = D.PartitionedIntegrator(gm, part, comm=comm)
+        else:
+            merger = D.ReplicaMerger(gm, comm=comm)
 
     def barrier():
         gm.wait()
@@ -236,6 +254,10 @@ def main():
     merge_state = {"merger": merger, "error": None}
 
     def step():
+        if integ is not None:
+            integ.integrateRaysDevice(dptr, rays.shape[0])
+            route_log.append(dict(integ.last))
+            return
         gm.integrateRaysDevice(dptr, rays.shape[0])
         if merge_state["merger"] is not None:
             try:
@@ -251,6 +273,7 @@ def main():
         step()
     barrier()
     del merge_log[:]
+    del route_log[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -270,6 +293,11 @@ def main():
     st = gm.stats()
     visits = int(st["voxel_visits"])
     rays_ok = int(st["rays_integrated"])
+    if partitioned and route_log:
+        # A partitioned rank walks the segments inside its territory of every ray addressed to it; the batch statistics
+        # count whole rays.  The job's voxel visits are those of the ranks' own shards: this rank's share is its shard's.
+        visits = int(route_log[-1]["visits_local"])
+        rays_ok = n_rays
     # Algorithmic bytes: 44 B per ray + 8 B per voxel visit (4 B read + 4 B write of the log-odds).
     b_alg = 44.0 * rays_ok + 8.0 * visits
     # Measured HBM traffic: from the committed PMC profile of this same command (separate rocprofv3 --pmc passes,
@@ -339,9 +367,22 @@ def main():
     out["ranks"] = world
     out["devices_visible"] = n_dev if n_dev is not None else int(ohm_amd.device_count())
     if world > 1:
-        out["backend"] = "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: staged merge, NOT a scaling figure)"
+        out["backend"] = "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: host-staged exchange, NOT a scaling figure)"
         out["rccl_ranks"] = comm.world if comm is not None else None
-    if world > 1 and (merge_state["error"] or not merge_log):
+    if partitioned:
+        sent = float(np.mean([r["rays_routed"] - r["rays_kept"] for r in route_log])) if route_log else 0.0
+        out["multi_gpu"] = {
+            "mode": "partitioned map, routed rays (exact)",
+            "transport": "RCCL (library: ncclSend / ncclRecv group)" if comm is not None else
+                         ("RCCL (torch.distributed all_to_all_single)" if backend == "nccl" else
+                          "gloo all_to_all_single, host staged (ranks share a GPU: NOT a scaling figure)"),
+            "territories": "blocks of 2 x 2 x 2 regions, each owned by the rank whose sensor origin is nearest",
+            "per_step_this_rank": {"rays_local": n_rays,
+                                   "rays_sent_to_other_ranks": sent,
+                                   "rays_received": float(np.mean([r["rays_received"] for r in route_log])) if route_log else 0.0,
+                                   "bytes_sent": 48.0 * sent},
+            "note": merge_note}
+    if world > 1 and not partitioned and (merge_state["error"] or not merge_log):
         out["merge"] = {"error": merge_state["error"] or "no merge ran", "note": "replicas not reconciled in this run"}
     elif merge_log:
         out["merge"] = {"per_step": {"regions_local": int(np.mean([m["regions_local"] for m in merge_log])),
@@ -353,6 +394,49 @@ def main():
                         "note": merge_note,
                         "rule": "merged = clamp(base + sum_r (x_r - base)); exact where no clamp engaged between ranks; "
                                 "regions pending on one rank only stay on that rank (shared base untouched)"}
+    if partitioned and not args.no_deviation:
+        # Untimed: the partitioned map against SEQUENTIAL integration.  Fresh maps: one partitioned step (collective), and
+        # every rank integrates the shards of all ranks, in rank order, into one map of its own -- the HIP path, bit exact
+        # against the CPU mapper (tests/test_gpu_full_configs.py) -- and compares the regions of its territory bit for
+        # bit; the counts are summed over the ranks.
+        try:
+            import torch
+            from ohm_amd import distributed as D
+            dm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+            dg = ohm_amd.GpuMap(dm, gpu_mem_size=8 << 30)
+            dinteg = D.PartitionedIntegrator(dg, integ.partition, comm=comm)
+            dinteg.integrateRaysDevice(dptr, rays.shape[0])
+            dg.syncVoxels()
+            sm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+            sg = ohm_amd.GpuMap(sm, gpu_mem_size=16 << 30)
+            for r in range(world):
+                sg.integrateRays(synth.rays_c4_shard(r, n=n_rays))
+            sg.syncVoxels()
+            seq_keys = np.array(sorted(sm.chunks), dtype=np.int16).reshape(-1, 3)
+            mine = seq_keys[integ.partition.owners(seq_keys) == rank]
+            mine_set = set(tuple(int(v) for v in k) for k in mine)
+            dev = D.merge_deviation(dm.chunks, sm.chunks, keys=sorted(mine_set & set(dm.chunks)))
+            counts = [dev["regions_compared"], dev["voxels_compared"], dev["voxels_observed"],
+                      dev["voxels_state_differs"], dev["voxels_value_differs"], dev["voxels_beyond_rel"],
+                      len(mine_set - set(dm.chunks)),                                    # regions this rank should hold
+                      sum(1 for k, c in dm.chunks.items() if k not in mine_set and np.isfinite(c["occupancy"]).any()),
+                      len(sm.chunks) if rank == 0 else 0]
+            t = torch.tensor(counts, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            mx = torch.tensor([dev["max_abs_delta"]], dtype=torch.float64, device=t.device)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            c = [int(v) for v in t.tolist()]
+            out["multi_gpu"]["deviation"] = {
+                "regions_compared": c[0], "voxels_compared": c[1], "voxels_observed": c[2],
+                "voxels_state_differs": c[3], "voxels_value_differs": c[4], "voxels_beyond_rel": c[5],
+                "regions_missing": c[6], "regions_outside_their_territory": c[7], "regions_sequential": c[8],
+                "max_abs_delta": float(mx.item()), "rel": dev["rel"],
+                "note": "union of the ranks' territories after ONE batch per rank vs one map integrating the shards of "
+                        "all ranks in rank order: every count but the first three must be 0 (bit-identical)"}
+            sg.close()
+            dg.close()
+        except Exception as exc:
+            out["multi_gpu"]["deviation"] = {"error": repr(exc)}
     if world > 1 and merge_state["merger"] is not None and not args.no_deviation:
         # Untimed: how far the replica merge is from SEQUENTIAL integration ("must be stated with results").
         # Fresh maps: every rank integrates its shard ONCE and the replicas merge (collective); rank 0 also integrates
@@ -498,8 +582,69 @@ def main():
             g0.close()
         except Exception as exc:
             extra["C0_100k_rays_10m"] = {"error": repr(exc)}
-        # C4 on ONE GPU (8 replica maps in this process standing in for the 8 ranks): what the replica merge moves and how
-        # far its result is from the sequential integration of the 8 shards.  Not a scaling figure.
+        # C4 on ONE GPU, the mode `--gpus N` runs: 8 partitioned maps in this process standing in for the 8 ranks.  Every
+        # rank's shard is routed by the library's kernels, the destination blocks are re-assembled in (source rank, ray)
+        # order -- what the all-to-all delivers -- and each map integrates what is addressed to it; compared bit for bit
+        # with ONE map integrating the 8 shards in rank order.  Per-rank times are this GPU's; not a scaling figure.
+        if not args.no_deviation:
+            try:
+                from ohm_amd import distributed as D
+                part0 = D.territories_from_origins(synth.C4_ORIGINS, 8, 0, 32 * resolution, block_shift=1, margin=40.0)
+                pmaps, pgs = [], []
+                for r in range(8):
+                    pm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+                    pg = ohm_amd.GpuMap(pm, gpu_mem_size=2 << 30)
+                    pg.setRegionPartition(part0.with_rank(r))
+                    pmaps.append(pm)
+                    pgs.append(pg)
+                shards = [synth.rays_c4_shard(r, n=n_rays) for r in range(8)]
+                D.integrate_partitioned_in_process(pgs, shards)  # first pass: pools, buffers
+                tms = {}
+                info = D.integrate_partitioned_in_process(pgs, shards, timings=tms)
+                sm = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+                sg = ohm_amd.GpuMap(sm, gpu_mem_size=16 << 30)
+                for _ in range(2):
+                    for r in range(8):
+                        sg.integrateRays(shards[r])
+                sg.syncVoxels()
+                union = {}
+                outside = 0
+                for r, (pm, pg) in enumerate(zip(pmaps, pgs)):
+                    pg.syncVoxels()
+                    keys = np.array(sorted(pm.chunks), dtype=np.int16).reshape(-1, 3)
+                    owners = part0.owners(keys) if len(keys) else []
+                    for k, o in zip(map(tuple, keys.tolist()), owners):
+                        if int(o) != r:
+                            outside += 1
+                        union[k] = pm.chunks[k]
+                dev = D.merge_deviation(union, sm.chunks)
+                dev["regions_missing"] = len(set(sm.chunks) - set(union))
+                dev["regions_outside_their_territory"] = outside
+                routed = info["routed"]
+                step_ms = [a + b for a, b in zip(tms["route_ms"], tms["integrate_ms"])]
+                extra["C4_8_shards_one_gpu_partitioned"] = {
+                    "rays_per_shard": n_rays,
+                    "rays_sent_to_other_ranks_per_rank": [int(routed[r].sum() - routed[r, r]) for r in range(8)],
+                    "rays_received_per_rank": [int(v) for v in info["received"]],
+                    "exchange_bytes_per_rank_max": int(48 * max(int(routed[r].sum() - routed[r, r]) for r in range(8))),
+                    "route_ms_per_rank": [round(v, 4) for v in tms["route_ms"]],
+                    "integrate_ms_per_rank": [round(v, 4) for v in tms["integrate_ms"]],
+                    "max_rank_step_ms": max(step_ms),
+                    "projected_8gpu_rays_per_s": 8 * n_rays / (max(step_ms) * 1e-3),
+                    "deviation_vs_sequential": dev,
+                    "note": "two batches per rank; union of the 8 territories vs ONE map integrating the 8 shards in rank "
+                            "order twice (the HIP path, bit exact vs the CPU mapper): voxels_value_differs must be 0.  "
+                            "Per-rank times: routing kernels + integration of the received stream on THIS GPU (host "
+                            "synchronised per phase), the exchange itself (48 B per routed ray) excluded"}
+                for pg in pgs:
+                    pg.close()
+                sg.close()
+                del pmaps, sm, union, shards
+            except Exception as exc:
+                extra["C4_8_shards_one_gpu_partitioned"] = {"error": repr(exc)}
+        # C4 on ONE GPU in the OPTIONAL replica-merge mode (--multi-gpu-mode replica-merge; 8 replica maps in this process
+        # standing in for the 8 ranks): what the additive merge moves and how far its result is from the sequential
+        # integration of the 8 shards.  Not a scaling figure, and not what --gpus N runs by default.
         if not args.no_deviation:
             try:
                 from ohm_amd import distributed as D

@@ -541,16 +541,22 @@ class PartitionedIntegrator:
             routed = self._ensure("_routed", int(counts.sum()))
 
     def integrateRays(self, local_rays, ray_update_flags=0):
-        """local_rays: (2N, 3) float64 CUDA tensor (origin, sample pairs).  Collective.  Returns the number of rays this
-        rank integrated (its own and received ones that pass the ray filter)."""
-        import ctypes as C
+        """local_rays: (2N, 3) float64 CUDA tensor (origin, sample pairs).  Collective.  Returns the number of points
+        (2 x rays, like GpuMap.integrateRays) this rank integrated: its own rays and received ones that pass the ray
+        filter."""
+        import torch
+        local = local_rays.reshape(-1, 6)
+        torch.cuda.current_stream().synchronize()  # the library works on its own HIP streams
+        return self.integrateRaysDevice(local.data_ptr(), 2 * local.shape[0], ray_update_flags)
+
+    def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=0):
+        """The same for a raw device pointer to element_count dvec3 (complete when the call is made)."""
         import torch
         from . import _lib as L
         gm = self.gpu_map
-        local = local_rays.reshape(-1, 6)
-        torch.cuda.current_stream().synchronize()  # the library works on its own HIP streams
-        gm.wait()                                  # the previous batch may still read the receive buffer
-        routed, counts, visits = self.route(local.data_ptr(), local.shape[0], ray_update_flags)
+        n_local = int(element_count) // 2
+        gm.wait()  # the previous batch may still read the receive buffer
+        routed, counts, visits = self.route(d_rays_ptr, n_local, ray_update_flags)
         sent = int(counts.sum())
         if self.comm is not None:
             send_counts = np.ascontiguousarray(counts, dtype=np.uint32)
@@ -565,9 +571,8 @@ class PartitionedIntegrator:
             recv_counts = [int(c) for c in recv_counts]
         else:
             import torch.distributed as dist
-            backend = dist.get_backend(self.group)
             block = routed[:sent]
-            if backend == "gloo":
+            if dist.get_backend(self.group) == "gloo":
                 got, recv_counts = exchange_routed_rays(block.cpu(), counts, self.group)
                 n_recv = got.shape[0]
                 recv = self._ensure("_recv", n_recv)
@@ -576,9 +581,9 @@ class PartitionedIntegrator:
                 got, recv_counts = exchange_routed_rays(block, counts, self.group)
                 n_recv = got.shape[0]
                 recv = got
-                self._recv = got
+                self._recv = got  # stays alive while the batch reads it
             torch.cuda.current_stream().synchronize()
-        self.last = {"rays_local": int(local.shape[0]), "rays_routed": sent, "rays_kept": int(counts[self.partition.rank]),
+        self.last = {"rays_local": n_local, "rays_routed": sent, "rays_kept": int(counts[self.partition.rank]),
                      "rays_received": n_recv, "recv_counts": recv_counts, "visits_local": visits}
         if n_recv == 0:
             return 0

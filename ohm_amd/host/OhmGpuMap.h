@@ -623,6 +623,79 @@ public:
     OHMHIP_GPUAPICHECK(ohmhip_map_set_region_ownership(handle_, world_size, rank, block_shift));
   }
 
+  /// Not in the reference (single device): the partitioned map (include/ohmhip.h "Partitioned map") -- like
+  /// setRegionOwnership(), with the blocks of 2^block_shift regions dealt by a table (x fastest) over
+  /// [grid_origin, grid_origin + grid_dims) in block coordinates; an empty table selects the block hash.
+  struct RegionPartition
+  {
+    unsigned world_size = 1;
+    unsigned rank = 0;
+    int block_shift = 0;
+    int grid_origin[3] = { 0, 0, 0 };
+    unsigned grid_dims[3] = { 0, 0, 0 };
+    std::vector<uint8_t> owners;
+  };
+  void setRegionPartition(const RegionPartition &partition)
+  {
+    ohmhip_partition p;
+    p.world_size = partition.world_size;
+    p.rank = partition.rank;
+    p.block_shift = partition.block_shift;
+    for (int a = 0; a < 3; ++a)
+    {
+      p.grid_origin[a] = partition.grid_origin[a];
+      p.grid_dims[a] = partition.grid_dims[a];
+    }
+    p.owners = partition.owners.empty() ? nullptr : partition.owners.data();
+    OHMHIP_GPUAPICHECK(ohmhip_map_set_region_partition(handle_, &p));
+    partition_world_ = (partition.world_size > 1) ? partition.world_size : 1u;
+  }
+  /// Route @p element_count / 2 rays resident in @p device_rays to the ranks owning a region they touch
+  /// (ohmhip_map_route_rays): @p routed is resized to hold them per destination, blocks back to back in rank order,
+  /// rays in order inside a block; @p counts[d] = rays addressed to rank d.  Returns the total number of routed rays.
+  size_t routeRays(const gputil::Buffer &device_rays, size_t element_count, unsigned ray_update_flags,
+                   gputil::Buffer &routed, std::vector<uint32_t> &counts)
+  {
+    counts.assign(partition_world_, 0u);
+    void *src = nullptr;
+    OHMHIP_GPUAPICHECK(ohmhip_buffer_ptr(device_rays.handle(), &src));
+    size_t capacity = routed.isValid() ? routed.size() / (6 * sizeof(double)) : 0;
+    for (;;)
+    {
+      void *dst = nullptr;
+      if (routed.isValid())
+      {
+        OHMHIP_GPUAPICHECK(ohmhip_buffer_ptr(routed.handle(), &dst));
+      }
+      const int status = ohmhip_map_route_rays(handle_, static_cast<const double *>(src), element_count / 2,
+                                               ray_update_flags, static_cast<double *>(dst), nullptr, capacity,
+                                               counts.data(), nullptr);
+      size_t total = 0;
+      for (uint32_t c : counts)
+      {
+        total += c;
+      }
+      if (status == OHMHIP_OK)
+      {
+        return total;
+      }
+      if (status != OHMHIP_ERR_CAPACITY)
+      {
+        OHMHIP_GPUAPICHECK(status);
+      }
+      capacity = total + total / 4 + 64;
+      if (routed.isValid())
+      {
+        routed.resize(capacity * 6 * sizeof(double));
+      }
+      else
+      {
+        routed.create(capacity * 6 * sizeof(double));
+      }
+      capacity = routed.size() / (6 * sizeof(double));
+    }
+  }
+
   ohmhip_map_t handle() const { return handle_; }
 
 protected:
@@ -747,6 +820,7 @@ protected:
   double ray_segment_length_ = 0;
   bool grouped_rays_ = false;
   int last_status_ = OHMHIP_OK;
+  unsigned partition_world_ = 1;
   RayFilterFunction ray_filter_;
   ohmhip_map_config cfg_;
   GpuCache cache_view_{ this };

@@ -143,7 +143,7 @@ int main(int argc, char **argv)
     ohm::OccupancyMap map(resolution);
     std::unique_ptr<ohm::GpuMap> gpu_map;
     if (mode == "occ" || mode == "occmean" || mode == "occdev" || mode == "occcoalesce" || mode == "occowner" ||
-        mode == "occclipbox")
+        mode == "occclipbox" || mode == "occpart")
     {
       if (mode == "occmean")
       {
@@ -161,6 +161,19 @@ int main(int argc, char **argv)
         gpu_map->setRayFilter([clip_box](ohm::dvec3 *start, ohm::dvec3 *end, unsigned *filter_flags) {
           return ohm::clipBounded(start, end, filter_flags, clip_box);
         });
+      }
+      if (mode == "occpart")
+      {
+        // rank 1 of a two-way partition by a table: region blocks (2 x 2 x 2 regions) with block x >= 1 belong to rank 1
+        ohm::GpuMap::RegionPartition part;
+        part.world_size = 2;
+        part.rank = 1;
+        part.block_shift = 1;
+        part.grid_origin[0] = 0;
+        part.grid_dims[0] = 2;
+        part.grid_dims[1] = part.grid_dims[2] = 1;
+        part.owners = { 0, 1 };
+        gpu_map->setRegionPartition(part);
       }
       if (mode == "occowner")
       {
@@ -209,6 +222,40 @@ int main(int argc, char **argv)
         const unsigned elements = transform.transform(times, translations, rotations, 2, sample_times.data(),
                                                       samples.data(), unsigned(samples.size()), queue, device_rays);
         total += gpu_map->integrateRays(device_rays, elements, ohm::kRfDefault);
+      }
+    }
+    else if (mode == "occpart")
+    {
+      // route every batch on the device and integrate the block addressed to this rank (what the all-to-all would
+      // deliver from a single source rank); the points of rays that never reach rank 1's territory count as done
+      gputil::Device device;
+      gputil::Buffer device_rays, routed;
+      std::vector<uint32_t> counts;
+      for (size_t i = 0; i < n_points; i += batch_points)
+      {
+        const size_t count = std::min<size_t>(batch_points, n_points - i);
+        if (!device_rays.isValid())
+        {
+          device_rays.create(count * sizeof(ohm::dvec3));
+        }
+        device_rays.resize(count * sizeof(ohm::dvec3));
+        device_rays.write(rays.data() + i, count * sizeof(ohm::dvec3));
+        gpu_map->routeRays(device_rays, count, ohm::kRfDefault, routed, counts);
+        gputil::Buffer mine;
+        if (counts[1])
+        {
+          std::vector<ohm::dvec3> block(size_t(counts[1]) * 2);
+          routed.read(block.data(), block.size() * sizeof(ohm::dvec3), size_t(counts[0]) * 2 * sizeof(ohm::dvec3));
+          mine.create(block.size() * sizeof(ohm::dvec3));
+          mine.write(block.data(), block.size() * sizeof(ohm::dvec3));
+          const size_t done = gpu_map->integrateRays(mine, block.size(), ohm::kRfDefault);
+          if (done != block.size())
+          {
+            return 11;
+          }
+          gpu_map->syncVoxels();  // (the block buffer goes out of scope: the batch must have read it)
+        }
+        total += count;
       }
     }
     else

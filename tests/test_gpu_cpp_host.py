@@ -135,6 +135,25 @@ def test_cpp_batch_coalescing_and_region_ownership(gpu):
     assert_parity(compare_maps({k: expect[k] for k in mine}, owned, ["occupancy"], exact_float=True))
 
 
+def test_cpp_region_partition_and_ray_routing(gpu):
+    """GpuMap::setRegionPartition + GpuMap::routeRays through the C++ mirror: rank 1 of a two-way table partition routes
+    every batch on the device and integrates the block addressed to it -> exactly the regions the table gives rank 1,
+    with the values the whole map has there."""
+    from ohm_amd import distributed as D
+    rays = synth.rays_c1(n=20000, max_range=12.0)
+    om = OracleMap(0.1, layers=("occupancy",))
+    for i in range(0, rays.shape[0], 2 * 4096):
+        om.integrate_occupancy(rays[i:i + 2 * 4096])
+    expect = om.chunks()
+    owned = run_driver("occpart", 0.1, 4096, rays, 1)
+    part = D.RegionPartition(2, 1, 1, (0, 0, 0), np.array([0, 1], dtype=np.uint8).reshape(2, 1, 1))
+    keys = np.array(sorted(expect.keys()), dtype=np.int16).reshape(-1, 3)
+    mine = {tuple(int(v) for v in k) for k, o in zip(keys, part.owners(keys)) if o == 1}
+    assert all(k[0] >= 2 for k in mine) and 0 < len(mine) < len(expect)
+    assert set(owned.keys()) == mine
+    assert_parity(compare_maps({k: expect[k] for k in mine}, owned, ["occupancy"], exact_float=True))
+
+
 def test_cpp_set_ray_filter_clip_box(gpu):
     """GpuMap::setRayFilter with a RayFilterFunction wrapping clipBounded, as GpuMap.ClipBox does
     (tests/ohmtestgpu/GpuMapTest.cpp:633-647): the C++ mirror's Aabb / clipBounded against the numpy restatement."""
