@@ -73,6 +73,23 @@ def main():
         om2.integrate_occupancy(rays[:4000])
         for key, layers in om2.chunks().items():
             assert np.array_equal(map2.chunks[key]["occupancy"].view(np.uint32), layers["occupancy"].view(np.uint32))
+        # Partitioned integrator, both transports, world 1: the routing kernels, the library's RCCL exchange (count
+        # all-gather + the self block) and torch's all_to_all_single on device tensors all run; every ray comes back.
+        for use_comm in (True, False):
+            map3 = OccupancyMap(0.1)
+            gm3 = GpuMap(map3)
+            comm3 = D.Communicator() if use_comm else None
+            part = D.territories_from_origins([(0.05, 0.05, 0.05)], 1, 0, 3.2)
+            pinteg = D.PartitionedIntegrator(gm3, part, comm=comm3)
+            assert pinteg.integrateRays(d_rays) == rays.shape[0]
+            assert pinteg.last["rays_received"] == rays.shape[0] // 2 == pinteg.last["rays_kept"]
+            assert pinteg.integrateRays(d_rays[:4000]) == 4000
+            gm3.syncVoxels()
+            for key, layers in om2.chunks().items():
+                assert np.array_equal(map3.chunks[key]["occupancy"].view(np.uint32), layers["occupancy"].view(np.uint32))
+            if comm3 is not None:
+                comm3.close()
+            gm3.close()
         print("MERGE_OK", n, checked)
     finally:
         dist.destroy_process_group()
