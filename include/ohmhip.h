@@ -275,7 +275,9 @@ typedef struct ohmhip_cache_stats
 int ohmhip_map_cache_stats(ohmhip_map_t map, ohmhip_cache_stats *stats, int reset);
 /* RESIDENCY LIMIT.  Without spilling (below) a map that outgrows what it may allocate fails the batch that needs the
  * extra regions with OHMHIP_ERR_CAPACITY and stays exactly as it was before that batch (the batch's region inserts are
- * rolled back), so the caller can cull regions (ohmhip_map_remove_regions after reading them back) and present the
+ * rolled back; this holds for pool / chunk-list EXHAUSTION, the failure a caller can act on -- a batch that dies later
+ * of a device error or a failed buffer allocation may leave regions it touched flagged as modified, which costs a
+ * redundant copy at the next syncVoxels(), never a wrong value), so the caller can cull regions (ohmhip_map_remove_regions after reading them back) and present the
  * batch again -- or turn on ohmhip_map_set_spill_to_host and let the library move cold regions to host memory.  The
  * limit is free device memory -- 288 GB of HBM3E hold about 1 million 32^3 occupancy-only regions (8.1 B per voxel
  * with scratch) -- or, when set, `bytes` for this map's region pool (the reference's gpu_mem_size,

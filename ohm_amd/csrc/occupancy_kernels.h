@@ -26,6 +26,12 @@
 #ifndef OHMHIP_COLD_HINTS
 #define OHMHIP_COLD_HINTS 3  // k_region_walk: branch hints on the rare blocks of the loop (1: exact step, 2: lane refill)
 #endif
+#ifndef OHMHIP_WALK_VGPR_CONSTS
+#define OHMHIP_WALK_VGPR_CONSTS 0  // k_region_walk: wave-uniform constants of the step held in VGPRs
+#endif
+#ifndef OHMHIP_WALK_FLAG_SUPERSET
+#define OHMHIP_WALK_FLAG_SUPERSET 0  // k_region_walk: one cheap test per trip for "some lane met a flagged voxel"
+#endif
 #ifndef OHMHIP_BIN_FUSE_STEPS
 #define OHMHIP_BIN_FUSE_STEPS 1  // k_ray_bin: sample key emitted in the segment loop (one RayWalk load per ray)
 #endif
@@ -1611,6 +1617,16 @@ __device__ inline uint32_t tileWord(uint32_t w)
 #endif
 }
 
+/// The same with the swizzle's bank mask (31 << 2) handed in -- the walk loop keeps it in a VGPR.
+__device__ inline uint32_t tileAddressMasked(uint32_t va, uint32_t bank_mask)
+{
+#ifdef OHMHIP_ABL_NOSWZ
+  return va & ~3u;
+#else
+  return (va & ~3u) ^ (((va >> 5) ^ (va >> 10)) & bank_mask);
+#endif
+}
+
 /// Byte address of the tile word holding the u16 entry at byte offset `va` (= 2 x voxel index).
 __device__ inline uint32_t tileAddress(uint32_t va)
 {
@@ -2234,7 +2250,16 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     const int ray_shift = args.ray_shift;
     const int refill_min_idle = args.refill_min_idle;
     const bool refill_only = kTrace && (args.dbg & 16u) != 0;
+#if OHMHIP_WALK_VGPR_CONSTS
+    // (a VALU instruction with an SGPR source issues at half rate on gfx950 -- profiles/r04_valu_probe.txt -- so the
+    // step's wave-uniform constants sit in VGPRs)
+    uint32_t fix_margin = mc.fix_margin;
+    asm volatile("" : "+v"(fix_margin));
+    uint32_t bank_mask = 31u << 2;
+    asm volatile("" : "+v"(bank_mask));
+#else
     const uint32_t fix_margin = mc.fix_margin;
+#endif
     const uint32_t idle_address = uint32_t(reinterpret_cast<char *>(l_idle + lane) - reinterpret_cast<char *>(lds));
 
     // Per-lane walk state (all named scalars: no run-time indexed arrays).
@@ -2351,7 +2376,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #elif defined(OHMHIP_ABL_RANDOM)
         olds[u] = tileAdd((((va * 2654435761u) ^ (ray * 0x9E3779B1u)) >> 16) & 0xfffcu, shiftOne(va << 3));
 #else
+#if OHMHIP_WALK_VGPR_CONSTS
+        olds[u] = tileAdd(visit ? tileAddressMasked(va, bank_mask) : idle_address, shiftOne(va << 3));
+#else
         olds[u] = tileAdd(visit ? tileAddress(va) : idle_address, shiftOne(va << 3));
+#endif
 #endif
         if (kSpecial)
         {
@@ -2372,7 +2401,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           const uint32_t fmin = umin3(f0, f1, f2);
           const uint32_t fmed = umed3(f0, f1, f2);
           const uint32_t limit = min(fmed, kFixMaxDelta);
+#if OHMHIP_WALK_VGPR_CONSTS
+          const uint32_t lead = addSat(fmin, fix_margin);
+#else
           const uint32_t lead = addSatUniform(fmin, fix_margin);
+#endif
           const unsigned long long certain = __builtin_amdgcn_uicmp(lead, limit, kIcmpUlt);
           unsigned long long a0 = __builtin_amdgcn_uicmp(f0, fmin, kIcmpEq);
           unsigned long long a2 = __builtin_amdgcn_uicmp(f2, fmin, kIcmpEq);
@@ -2432,6 +2465,18 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         ++qcount;
       }
       if (false)
+#endif
+#if OHMHIP_WALK_FLAG_SUPERSET
+      // One test for the whole trip: did ANY returned word carry a flag bit (its voxel's or the voxel's sharing the
+      // word)?  A superset of the lanes that met a flagged voxel, two full-rate instructions and one compare for the
+      // trip instead of a bit-field extract and a compare per step.
+      uint32_t any_flag_bits = olds[0];
+#pragma unroll
+      for (int u = 1; u < kWalkUnroll; ++u)
+      {
+        any_flag_bits |= olds[u];
+      }
+      if (__ballot((any_flag_bits & ((kTileFlag << 16) | kTileFlag)) != 0u))
 #endif
 #pragma unroll
       for (int u = 0; u < kWalkUnroll; ++u)

@@ -1674,7 +1674,18 @@ int settleLaunch(ohmhip_map_t m)
 /// OHMHIP_SETTLE) gets the batch fully launched before this returns.
 int flushPendingRays(ohmhip_map_t m, size_t *integrated = nullptr, bool may_hand_over = false)
 {
-  OHMHIP_CHECK(settleLaunch(m));  // (one batch at a time is being launched; its error surfaces here)
+  // One batch at a time is being launched; its error surfaces here.  The rays waiting in the filling slot are NOT that
+  // batch's: they stay queued and run with the next flush -- which must then send the whole block again, because calls
+  // appended from now on only reach the pinned block (a stale "uploaded" flag made that flush skip both the
+  // resize of the device copy and the transfer).
+  {
+    const int settle_err = settleLaunch(m);
+    if (settle_err != OHMHIP_OK)
+    {
+      m->ray_slots[m->fill_slot].rays_uploaded = false;
+      return settle_err;
+    }
+  }
   const size_t n = m->pending_rays;
   if (n == 0)
   {
@@ -2328,7 +2339,11 @@ try
   }
   if (integrated)
   {
-    hipLaunchKernelGGL(k_count_passed, dim3(1), dim3(1024), 0, cs, m->mc, static_cast<const double *>(staged),
+    // (its own copy of the constants: a batch being launched on the map's thread -- ohmhip_map_set_async_launch -- points
+    // m->mc.batch_filter_flags at ITS filter flags while it runs; this call's rays carry none.  ADVICE r3)
+    MapConst count_mc = m->mc;
+    count_mc.batch_filter_flags = nullptr;
+    hipLaunchKernelGGL(k_count_passed, dim3(1), dim3(1024), 0, cs, count_mc, static_cast<const double *>(staged),
                        uint32_t(n_rays), ray_flags, m->h_passed_dev);
     OHMHIP_CHECK(hipEventRecord(m->ev_passed, cs));
     OHMHIP_CHECK(hipEventSynchronize(m->ev_passed));  // (also: the caller's arrays have been copied)
@@ -2941,20 +2956,25 @@ try
   {
     return OHMHIP_ERR_UNSUPPORTED;  // replica-merge maps keep a base copy per region: they do not spill
   }
-  m->spill_enabled = enable != 0;
-  if (m->spill_enabled)
+  if (enable)
   {
     // The host store is pinned memory: reserve what the pool can hold now (pinning is slow -- of the order of a second
     // per few GB -- and belongs here, not into the first batch that overflows the pool).  It grows by slabs on demand.
+    // The eager part is capped in bytes (8 GiB): a multi-layer NDT map with a large pool and no memory limit would
+    // otherwise pin tens of GB before anything spills.  Reserved BEFORE the mode is switched: a failed reservation
+    // leaves spilling off and the coalescing threshold as it was.
     const uint64_t per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
     const uint64_t pool_regions =
       m->memory_limit ? std::min<uint64_t>(m->memory_limit / per_region, kMaxRegionSlots) : m->slot_capacity;
     // (what the pool holds + the quarter an eviction moves out while as much again may still be waiting in the store)
-    OHMHIP_CHECK(reserveStoreRecords(m, size_t(std::min<uint64_t>(pool_regions + pool_regions / 2 + 64, 16384))));
+    const uint64_t by_count = std::min<uint64_t>(pool_regions + pool_regions / 2 + 64, 16384);
+    const uint64_t by_bytes = std::max<uint64_t>((uint64_t(8) << 30) / std::max<uint64_t>(per_region, 1), 64);
+    OHMHIP_CHECK(reserveStoreRecords(m, size_t(std::min(by_count, by_bytes))));
     // A collected batch touches the regions of all its calls at once -- more than any one of them, possibly more than
     // the limit holds: with spilling on every call runs as its own device batch (the caller may still set a threshold).
     m->coalesce_min_rays = 0;
   }
+  m->spill_enabled = enable != 0;
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH

@@ -216,6 +216,72 @@ __global__ void __launch_bounds__(1024) valu_branch(int iters, double *sink)
   }
 }
 
+// the pair the compiler emits for `cond ? a : b`: VOPC compare into VCC, VOP2 select reading VCC
+__global__ void __launch_bounds__(1024) pair_cmp_cnd_vcc(int iters, double *sink)
+{
+  unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 3, c = threadIdx.x * 7u;
+  for (int i = 0; i < iters; ++i)
+  {
+    asm volatile(REP4("v_cmp_lt_u32_e32 vcc, %0, %4\n v_cndmask_b32_e32 %0, %4, %5, vcc\n"
+                      "v_cmp_lt_u32_e32 vcc, %1, %4\n v_cndmask_b32_e32 %1, %4, %5, vcc\n"
+                      "v_cmp_lt_u32_e32 vcc, %2, %4\n v_cndmask_b32_e32 %2, %4, %5, vcc\n"
+                      "v_cmp_lt_u32_e32 vcc, %3, %4\n v_cndmask_b32_e32 %3, %4, %5, vcc\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+  }
+  if (threadIdx.x == 1023 && a0 + a1 + a2 + a3 == 77777u)
+  {
+    sink[0] = double(a0);
+  }
+}
+// the same with two plain VALU instructions between the compare and the select
+__global__ void __launch_bounds__(1024) pair_cmp_gap_cnd_vcc(int iters, double *sink)
+{
+  unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 3, c = threadIdx.x * 7u;
+  for (int i = 0; i < iters; ++i)
+  {
+    asm volatile(REP8("v_cmp_lt_u32_e32 vcc, %0, %4\n v_xor_b32 %1, %4, %1\n v_xor_b32 %2, %4, %2\n"
+                      "v_cndmask_b32_e32 %0, %4, %5, vcc\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");
+  }
+  if (threadIdx.x == 1023 && a0 + a1 + a2 + a3 == 77777u)
+  {
+    sink[0] = double(a0);
+  }
+}
+// select through explicit SGPR pairs (what selectI does), compare and select independent of each other
+__global__ void __launch_bounds__(1024) pair_cmp_cnd_sgpr(int iters, double *sink)
+{
+  unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 3, c = threadIdx.x * 7u;
+  unsigned long long m0 = 0, m1 = 0;
+  for (int i = 0; i < iters; ++i)
+  {
+    asm volatile(REP4("v_cmp_lt_u32_e64 %6, %0, %4\n v_cndmask_b32_e64 %0, %4, %5, %6\n"
+                      "v_cmp_lt_u32_e64 %7, %1, %4\n v_cndmask_b32_e64 %1, %4, %5, %7\n"
+                      "v_cmp_lt_u32_e64 %6, %2, %4\n v_cndmask_b32_e64 %2, %4, %5, %6\n"
+                      "v_cmp_lt_u32_e64 %7, %3, %4\n v_cndmask_b32_e64 %3, %4, %5, %7\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c), "s"(m0), "s"(m1));
+  }
+  if (threadIdx.x == 1023 && a0 + a1 + a2 + a3 == 77777u)
+  {
+    sink[0] = double(a0) + double(m0 + m1);
+  }
+}
+// full-rate select from a VGPR mask: sign mask by arithmetic shift, v_bitop3 as (mask & x) | (~mask & y)
+__global__ void __launch_bounds__(1024) select_bitop3(int iters, double *sink)
+{
+  unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 3, c = threadIdx.x * 7u, t = 0;
+  for (int i = 0; i < iters; ++i)
+  {
+    asm volatile(REP4("v_sub_u32 %6, %0, %4\n v_ashrrev_i32 %6, 31, %6\n v_bitop3_b32 %0, %6, %4, %5 bitop3:0xca\n"
+                      "v_sub_u32 %6, %1, %4\n v_ashrrev_i32 %6, 31, %6\n v_bitop3_b32 %1, %6, %4, %5 bitop3:0xca\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c), "v"(t));
+  }
+  if (threadIdx.x == 1023 && a0 + a1 + a2 + a3 == 77777u)
+  {
+    sink[0] = double(a0);
+  }
+}
+
 template <typename K>
 void run(const char *name, K kernel, double *sink, double instr_per_trip = 32.0)
 {
@@ -281,6 +347,10 @@ int main()
   run("v_mov_b32", thr_mov, sink);
   run("v_addc_co_u32", thr_addc, sink);
   run("v_sub_u32", thr_sub, sink);
+  run("cmp_e32+cnd_e32 vcc", pair_cmp_cnd_vcc, sink);
+  run("cmp,2 valu,cnd vcc", pair_cmp_gap_cnd_vcc, sink);
+  run("cmp_e64+cnd_e64 sgpr", pair_cmp_cnd_sgpr, sink);
+  run("sub,ashr,bitop3 sel", select_bitop3, sink, 24.0);
   run("dep s_xor_b64", dep_salu, sink);
   run("3 valu + cmp + br", valu_branch, sink, 40.0);
   return 0;

@@ -293,3 +293,30 @@ def test_async_launch_reports_a_failed_batch_at_the_next_call(gpu):
     om.integrate_occupancy(small)
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+
+
+def test_async_launch_failure_keeps_the_following_calls_intact(gpu):
+    """batch A fails on the launch thread; call B (a device batch of its own, staged AND uploaded piece by
+    piece) is the one that learns of it and returns A's error with B's rays still queued; call C is appended to the
+    same slot.  The flush that runs B + C must send the whole block again -- a stale 'uploaded' flag made it read
+    n_B + n_C rays from a device copy holding only B's."""
+    from ohm_amd import _lib as L
+    map_ = OccupancyMap(0.1, layers=("occupancy",))
+    gm = GpuMap(map_, region_capacity=64)
+    gm.setMemoryLimit(40 * gm.cacheStats()["bytes_per_region"])
+    gm.setAsyncLaunch(True)
+    small = synth.rays_c1(n=140_000, max_range=3.0, seed=5)
+    assert gm.integrateRays(small) == small.shape[0]
+    gm.wait()
+    big = synth.rays_c1(n=140_000, max_range=25.0, seed=6)     # A: cannot fit 40 regions
+    assert gm.integrateRays(big) == big.shape[0]
+    rays_b = synth.rays_c1(n=140_000, max_range=3.0, seed=7)   # B: learns of A's failure
+    assert gm.integrateRays(rays_b) == 0 and gm._last_error == L.ERR_CAPACITY  # (0 on failure, like the reference)
+    rays_c = synth.rays_c1(n=9_000, max_range=3.0, seed=8)     # C: small, appended behind B in the same slot
+    assert gm.integrateRays(rays_c) == rays_c.shape[0]
+    gm.wait()
+    gm.syncVoxels()
+    om = make_oracle(map_)
+    for r in (small, rays_b, rays_c):                           # A left nothing; B ran with C
+        om.integrate_occupancy(r)
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
