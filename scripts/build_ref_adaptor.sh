@@ -1,0 +1,71 @@
+#!/bin/bash
+# Build what can be built of ohm_amd/host/ref_adaptor (INTEGRATION.md Level 2) against the reference checkout the moment
+# glm exists on the box.  Never writes a stand-in for glm: without it the script says so and exits 77
+# (the "skipped" code); tests/test_ref_adaptor_build.py turns that into a pytest skip.
+#
+#   scripts/build_ref_adaptor.sh [reference checkout = /root/reference] [output dir = build/ref_adaptor]
+#   GLM_INCLUDE_DIR=<dir containing glm/glm.hpp>   overrides the search
+#   OHM_LIB_DIR=<dir with libohm / libohmutil / liblogutil built with real glm>   also LINKS libohmgpuhip.so
+#
+# Step 1 compiles every adaptor source -- the gputil backend AND the ohm:: half (GpuMap / GpuNdtMap / GpuTsdfMap /
+# GpuCache / OhmGpu / HipMapBinding) -- to object files against the reference's headers where they lie; the four headers
+# the reference's build generates (OhmConfig.h, OhmGpuConfig.h, gpuConfig.h and the export-macro headers) are produced
+# from its own templates in the output directory, as ref_adaptor/CMakeLists.txt does.  Step 2 (only with OHM_LIB_DIR)
+# links them into libohmgpuhip.so against the reference's core libraries and libohmhip.so.  The full recipe with the
+# reference's own GPU tests is the CMakeLists.txt next to the sources.
+set -u
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+REF="${1:-/root/reference}"
+OUT="${2:-$ROOT/build/ref_adaptor}"
+SRC="$ROOT/ohm_amd/host/ref_adaptor"
+if [ ! -f "$REF/ohmgpu/GpuMap.h" ]; then
+  echo "SKIPPED: no reference checkout at $REF (ohmgpu/GpuMap.h not found)"
+  exit 77
+fi
+GLM=""
+for d in "${GLM_INCLUDE_DIR:-}" /usr/include /usr/local/include /opt/rocm/include /usr/include/x86_64-linux-gnu; do
+  if [ -n "$d" ] && [ -f "$d/glm/glm.hpp" ]; then GLM="$d"; break; fi
+done
+if [ -z "$GLM" ]; then
+  echo "SKIPPED: glm absent (looked for glm/glm.hpp in \$GLM_INCLUDE_DIR, /usr/include, /usr/local/include, /opt/rocm/include); no stand-in is ever written"
+  exit 77
+fi
+echo "glm: $GLM/glm/glm.hpp"
+set -e
+GEN="$OUT/generated"
+mkdir -p "$GEN/ohm" "$GEN/ohmgpu" "$GEN/gputil" "$GEN/ohmutil" "$GEN/logutil" "$OUT/obj"
+# configure_file(): #cmakedefine X -> /* #undef X */ (no optional feature is switched on), @VAR@ -> empty
+configure() { sed -E 's|^#cmakedefine01 ([A-Za-z0-9_]+).*|#define \1 0|; s|^#cmakedefine ([A-Za-z0-9_]+).*|/* #undef \1 */|; s|@[A-Za-z0-9_]+@||g' "$1" > "$2"; }
+configure "$REF/ohm/OhmConfig.in.h" "$GEN/ohm/OhmConfig.h"
+configure "$REF/ohmgpu/OhmGpuConfig.in.h" "$GEN/ohmgpu/OhmGpuConfig.h"
+configure "$REF/gputil/gpuConfig.in.h" "$GEN/gputil/gpuConfig.h"
+configure "$REF/ohmutil/OhmUtilConfig.in.h" "$GEN/ohmutil/OhmUtilConfig.h"
+configure "$REF/logutil/LogUtilConfig.in.h" "$GEN/logutil/LogUtilConfig.h"
+# generate_export_header() for a shared build
+export_header() { # file, macro, guard
+  printf '#ifndef %s\n#define %s\n#define %s __attribute__((visibility("default")))\n#define %s_NO_EXPORT __attribute__((visibility("hidden")))\n#endif\n' "$3" "$3" "$2" "$2" > "$1"
+}
+export_header "$GEN/ohm/OhmExport.h" ohm_API OHM_EXPORT_H
+export_header "$GEN/ohmgpu/OhmGpuExport.h" ohmgpu_API OHMGPU_EXPORT_H
+export_header "$GEN/gputil/gputilExport.h" gputilAPI GPUTIL_EXPORT_H
+export_header "$GEN/ohmutil/OhmUtilExport.h" ohmutil_API OHMUTIL_EXPORT_H
+export_header "$GEN/logutil/LogUtilExport.h" logutil_API LOGUTIL_EXPORT_H
+INC="-I$GEN -I$GEN/ohm -I$GEN/ohmgpu -I$GEN/gputil -I$GEN/ohmutil -I$GEN/logutil -I$REF -I$REF/ohmutil/3rdparty -I$GLM -I$ROOT/include -I$SRC -I$SRC/gputil_hip"
+OBJS=""
+for f in GpuCache.cpp GpuMap.cpp GpuNdtMap.cpp GpuTsdfMap.cpp OhmGpu.cpp private/HipMapBinding.cpp gputil_hip/gputilHip.cpp gputil_hip/gputilHipBuffer.cpp; do
+  o="$OUT/obj/$(echo "$f" | tr '/' '_' | sed 's/\.cpp$/.o/')"
+  echo "compile $f"
+  g++ -std=c++14 -O1 -fPIC -Wall -Dgputil_EXPORTS -Dohmgpuhip_EXPORTS $INC -c "$SRC/$f" -o "$o"
+  OBJS="$OBJS $o"
+done
+echo "compile gputil/gpuEventList.cpp (the reference's own, backend independent)"
+g++ -std=c++14 -O1 -fPIC -Dgputil_EXPORTS $INC -c "$REF/gputil/gpuEventList.cpp" -o "$OUT/obj/gpuEventList.o"
+OBJS="$OBJS $OUT/obj/gpuEventList.o"
+echo "COMPILED: $(echo $OBJS | wc -w) objects under $OUT/obj"
+if [ -n "${OHM_LIB_DIR:-}" ]; then
+  g++ -shared -o "$OUT/libohmgpuhip.so" $OBJS -L"$OHM_LIB_DIR" -lohm -lohmutil -llogutil -L"$ROOT/ohm_amd/lib" -lohmhip \
+      -Wl,-rpath,"$ROOT/ohm_amd/lib" -Wl,-rpath,"$OHM_LIB_DIR"
+  echo "LINKED: $OUT/libohmgpuhip.so"
+else
+  echo "NOT LINKED: set OHM_LIB_DIR to the reference's core libraries (built with real glm) to link libohmgpuhip.so; ref_adaptor/CMakeLists.txt is the full recipe incl. the reference's GPU tests"
+fi

@@ -247,6 +247,47 @@ def test_ndt_hit_matches_independent_reference():
     assert np.all(np.abs(Cm @ Cm.T - pop) < 2e-3)
 
 
+def test_ndt_hit_step_by_step_against_the_independent_reference():
+    """the reference's own Ndt.Hit holds only the END of 10 000 updates to 1e-2 / 1e-1.  Here every
+    single step of the oracle's calculateHitWithCovariance (ohm/CovarianceVoxelCompute.h:301-375) is compared with
+    ohmtestutil::updateHit (tests/ohmtestcommon/CovarianceTestUtil.cpp:43-117, restated above) on the SAME input state
+    -- packed factor, mean, count, sample -- over 10 000 samples: the factor's six terms to 1e-6 relative.  Two
+    trajectories: the state carried by the oracle (what the mapper does) and by the reference (so a drift of one cannot
+    hide in the other's state)."""
+    res = 2.0
+    samples = _ndt_samples_gaussian(10000, 1153297050)
+    worst = 0.0
+    for carrier in ("oracle", "reference"):
+        cov = np.zeros(6, dtype=np.float32)
+        mean = np.zeros(3)
+        count = 0
+        for s in samples:
+            # the reference's harness initialises the factor before the first update (initialiseTestVoxel / first-sample
+            # rule of the mapper: covariance reset, sample_to_mean = 0)
+            if count == 0:
+                ref_in = np.array([0.1 * res, 0, 0.1 * res, 0, 0, 0.1 * res])
+                ref_mean_in = s.copy()
+            else:
+                ref_in = cov.astype(np.float64)
+                ref_mean_in = mean
+            ref_cov, ref_mean, _ = _independent_update_hit(ref_in, ref_mean_in, count, s)
+            ocov = (C.c_float * 6)(*cov)
+            value = C.c_float(0.5)
+            reset = O.lib.oracle_calculate_hit_with_covariance(ocov, C.byref(value), (C.c_double * 3)(*s),
+                                                               (C.c_double * 3)(*mean), count, 0.1, float("inf"),
+                                                               res, -1e30, 1 << 30)
+            assert bool(reset) == (count == 0)
+            got = np.array(list(ocov), dtype=np.float64)
+            ref32 = ref_cov.astype(np.float32).astype(np.float64)
+            err = np.abs(got - ref32) / np.maximum(np.abs(ref32), 1e-3)
+            worst = max(worst, float(err.max()))
+            assert np.all(err <= 1e-6), (carrier, count, got, ref32)
+            cov = np.array(list(ocov), dtype=np.float32) if carrier == "oracle" else ref_cov.astype(np.float32)
+            mean = ref_mean if count else s.copy()
+            count += 1
+    assert worst <= 1e-6
+
+
 def _build_ndt_voxel(samples, res, origin, sensor_noise):
     m = OracleMap(res, layers=("occupancy", "mean", "covariance"))
     m.set_origin(origin)
