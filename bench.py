@@ -124,6 +124,27 @@ def _relaunch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def load_traffic_profile(kind, build_id):
+    """profiles/rNN_<kind>.json of the newest round; {'doc': parsed or None, 'note': where it came from / why not}."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s.json" % kind)),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    if not files:
+        return {"doc": None, "note": "no profiles/rNN_%s.json" % kind}
+    name = os.path.basename(files[-1])
+    try:
+        with open(files[-1]) as fh:
+            doc = json.load(fh)
+    except Exception as exc:
+        return {"doc": None, "note": "%s unreadable: %r" % (name, exc)}
+    recorded = doc.get("library_build_id")
+    if recorded != build_id:
+        return {"doc": None, "note": "STALE: profiles/%s was recorded with library build %s, this is build %s -- re-run "
+                                     "scripts/profile_bench.sh <tag> pmc + scripts/traffic_json.py" % (name, recorded, build_id)}
+    return {"doc": doc, "note": "profiles/%s (library build %s)" % (name, build_id)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,20 +322,21 @@ def main():
     # Algorithmic bytes: 44 B per ray + 8 B per voxel visit (4 B read + 4 B write of the log-odds).
     b_alg = 44.0 * rays_ok + 8.0 * visits
     # Measured HBM traffic: from the committed PMC profile of this same command (separate rocprofv3 --pmc passes,
-    # profiles/r03_traffic.json <- scripts/traffic_json.py; bench.py itself cannot run the profiler).  FETCH_SIZE counts
-    # 64-byte requests: x2 for coalesced streams (the guide's correction), x1 for the kernel's 32-byte record gathers
-    # (profiles/r02_fetch_calibration.txt) -- the two figures bracket the bytes moved.
+    # profiles/rNN_traffic.json <- scripts/traffic_json.py; bench.py itself cannot run the profiler).  The NEWEST round's
+    # file is taken, and only if it was recorded with THIS build of the library (library_build_id): a profile of another
+    # build is reported as stale, never quoted.  FETCH_SIZE counts 64-byte requests: x2 for coalesced streams (the
+    # guide's correction), x1 for the kernel's 32-byte record gathers (profiles/r02_fetch_calibration.txt) -- the two
+    # figures bracket the bytes moved.
     traffic = traffic_lower = batch_traffic = batch_traffic_lower = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
-            tj = json.load(fh)
-        if world == 1 and n_rays == 1_000_000:
-            traffic = tj["kernels"]["k_region_walk"]["bytes_upper"]
-            traffic_lower = tj["kernels"]["k_region_walk"]["bytes_lower"]
-            batch_traffic = tj["batch_bytes_upper"]
-            batch_traffic_lower = tj["batch_bytes_lower"]
-    except Exception:
-        traffic = traffic_lower = batch_traffic = batch_traffic_lower = None
+    traffic_source = None
+    build_id = L.lib.ohmhip_build_id().decode()
+    tj = load_traffic_profile("traffic", build_id)
+    traffic_source = tj["note"]
+    if tj["doc"] is not None and world == 1 and n_rays == 1_000_000:
+        traffic = tj["doc"]["kernels"]["k_region_walk"]["bytes_upper"]
+        traffic_lower = tj["doc"]["kernels"]["k_region_walk"]["bytes_lower"]
+        batch_traffic = tj["doc"]["batch_bytes_upper"]
+        batch_traffic_lower = tj["doc"]["batch_bytes_lower"]
     # Measured ceiling next to the nominal peak: a device-to-device copy of 1 GiB (read + write).
     copy_gbps = None
     try:
@@ -355,7 +377,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_region_walk", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_lower": traffic_lower, "pipeline_traffic": batch_traffic,
-                     "pipeline_traffic_lower": batch_traffic_lower, "peak_measured_copy": copy_gbps,
+                     "pipeline_traffic_lower": batch_traffic_lower, "traffic_source": traffic_source,
+                     "peak_measured_copy": copy_gbps,
                      "algorithmic_bytes_per_launch": b_alg, "kernel_ms": t_walk * 1e3,
                      "pipeline_ms": t_dev * 1e3, "pipeline_frac": b_alg / t_dev / 1e9 / HBM_PEAK_GBPS},
         "device_ms": {"setup_bin": float(np.mean([t["ms_setup"] for t in timings])), "walk": float(np.mean(walk_ms)),
@@ -499,14 +522,11 @@ def main():
                 b_alg2 = 16.0 * v2 + 68.0 * n2
             dev2 = float(np.mean([t["ms_total"] for t in tm2])) * 1e-3
             walk2 = float(np.mean([t["ms_walk"] for t in tm2])) * 1e-3
-            tr2 = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r03_traffic_c2_ndt.json" if cls is ohm_amd.GpuNdtMap
-                                       else "r03_traffic_c3_tsdf.json")) as fh:
-                    tj2 = json.load(fh)
-                tr2 = {"pipeline_traffic": tj2["batch_bytes_upper"], "pipeline_traffic_lower": tj2["batch_bytes_lower"]}
-            except Exception:
-                tr2 = None
+            tj2 = load_traffic_profile("traffic_c2_ndt" if cls is ohm_amd.GpuNdtMap else "traffic_c3_tsdf", build_id)
+            tr2 = {"source": tj2["note"]}
+            if tj2["doc"] is not None:
+                tr2.update({"pipeline_traffic": tj2["doc"]["batch_bytes_upper"],
+                            "pipeline_traffic_lower": tj2["doc"]["batch_bytes_lower"]})
             extra[name] = {"rays_per_s": (r2.shape[0] // 2) / dt, "ms_per_step": dt * 1e3, "rays": r2.shape[0] // 2,
                            "voxel_visits": v2, "regions": int(st2["regions_resident"]),
                            "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": b_alg2, "peak": HBM_PEAK_GBPS,
@@ -558,6 +578,36 @@ def main():
             del r4
         except Exception as exc:  # never lose the bench line over a secondary figure
             extra["C3_tsdf_cache_stress_1GiB"] = {"error": repr(exc)}
+        # The headline integrates the SAME batch into one map again and again: after the first passes every free voxel
+        # sits at the min clamp (its update is a compare, its store is skipped) and no region is created.  Next to it: the
+        # first pass of the same batch over a FRESH map (regions created on the device, every voxel written) and the
+        # second (values still moving towards the clamps).  Pool allocation happens at map creation, outside the timing.
+        try:
+            fresh = []
+            for _ in range(3):
+                mf = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
+                gf = ohm_amd.GpuMap(mf, gpu_mem_size=8 << 30)
+                gf.wait()
+                t1 = time.perf_counter()
+                gf.integrateRaysDevice(dptr, rays.shape[0])
+                gf.wait()
+                t2 = time.perf_counter()
+                gf.integrateRaysDevice(dptr, rays.shape[0])
+                gf.wait()
+                t3 = time.perf_counter()
+                fresh.append((t2 - t1, t3 - t2, float(gf.batchTimings(1)["ms_walk"]), float(gf.batchTimings(0)["ms_walk"])))
+                gf.close()
+            first = min(f[0] for f in fresh)
+            second = min(f[1] for f in fresh)
+            extra["C1_fresh_map_first_pass"] = {
+                "first_pass_ms": first * 1e3, "second_pass_ms": second * 1e3,
+                "first_pass_walk_kernel_ms": min(f[2] for f in fresh), "second_pass_walk_kernel_ms": min(f[3] for f in fresh),
+                "first_pass_rays_per_s": n_rays / first,
+                "first_pass_pipeline_frac": b_alg / first / 1e9 / HBM_PEAK_GBPS,
+                "note": "one isolated call each (host-synchronised, so the next batch's set-up pass does not overlap as in "
+                        "the steady-state headline); best of 3 fresh maps"}
+        except Exception as exc:
+            extra["C1_fresh_map_first_pass"] = {"error": repr(exc)}
         # C0 (BASELINE configs[0]: 100 k uniform 10 m rays from one origin) on the HIP path, device-resident rays.
         try:
             r0 = synth.rays_c0()
@@ -793,7 +843,15 @@ def main():
             gmv.wait()
             dt = (time.perf_counter() - t1) / n_mov
             stm = gmv.stats()
+            mov_visits = int(stm["voxel_visits"])
+            mov_b_alg = 44.0 * n_rays + 8.0 * mov_visits
+            mov_tm = [gmv.batchTimings(back) for back in range(n_mov)]
+            mov_walk = float(np.mean([t["ms_walk"] for t in mov_tm])) * 1e-3
             extra["C1_moving_sensor"] = {"rays_per_s": n_rays / dt, "ms_per_step": dt * 1e3, "batches": n_mov,
+                                         "voxel_visits_last_batch": mov_visits, "walk_kernel_ms": mov_walk * 1e3,
+                                         "roofline": {"algorithmic_bytes_per_step": mov_b_alg,
+                                                      "frac": mov_b_alg / mov_walk / 1e9 / HBM_PEAK_GBPS,
+                                                      "pipeline_frac": mov_b_alg / dt / 1e9 / HBM_PEAK_GBPS},
                                          "sensor_step_m": 0.41, "regions_at_end": int(stm["regions_resident"]),
                                          "note": "the C1 sweep from an origin that advances 0.41 m per batch.  Slower than the "
                                                  "static headline mostly because this synthetic scene is inconsistent from "

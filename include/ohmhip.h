@@ -33,6 +33,9 @@ extern "C" {
 #define OHMHIP_ERR_PEER (-7)        /* a collective call was abandoned because ANOTHER rank failed in it */
 
 const char *ohmhip_error_string(int status);
+/* Identifies the build: 16 hex digits over the library's sources (set by __graft_entry__.build()), "unversioned" for
+ * other builds.  Recorded with profiles so a counter profile of another build is not quoted for this one. */
+const char *ohmhip_build_id(void);
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* 1. Device plumbing (replaces gputil)                                                                               */

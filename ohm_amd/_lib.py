@@ -86,6 +86,7 @@ class BatchStats(C.Structure):
 _vp = C.c_void_p
 _sigs = {
     "ohmhip_error_string": (C.c_char_p, [C.c_int]),
+    "ohmhip_build_id": (C.c_char_p, []),
     "ohmhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ohmhip_device_select": (C.c_int, [C.c_int]),
     "ohmhip_device_get_info": (C.c_int, [C.c_int, C.POINTER(DeviceInfo)]),

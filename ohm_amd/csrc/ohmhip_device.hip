@@ -9,6 +9,14 @@
 
 extern "C" {
 
+#ifndef OHMHIP_BUILD_ID
+#define OHMHIP_BUILD_ID "unversioned"
+#endif
+const char *ohmhip_build_id(void)
+{
+  return OHMHIP_BUILD_ID;
+}
+
 const char *ohmhip_error_string(int status)
 {
   switch (status)
