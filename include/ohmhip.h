@@ -200,6 +200,19 @@ typedef struct ohmhip_batch_stats
   float ms_apply;            /* hit sort + ordered apply                                                 */
 } ohmhip_batch_stats;
 
+/* LARGE REGIONS.  region_dim takes what the reference takes: any 1..255 voxels per axis (ohm/OccupancyMap.h:287,
+ * glm::u8vec3; default 32^3, :24-26).  A region of up to 32768 voxels is one LDS tile of the walk kernel.  A larger one
+ * is cut, inside the library, into equal tiles that each are one contiguous piece of the region's MapChunk block -- z
+ * slabs of whole x-y layers (64^3 -> 8 tiles of 64 x 64 x 8), or, when one layer alone exceeds a tile, y strips of single
+ * layers (255 x 255 x n -> 255 x 85 x 1) -- and everything internal works per tile.  The ABI keeps speaking REGIONS:
+ * keys, listings, dirty sets and the blocks of read_regions / write_regions are the caller's regions (a tile no ray has
+ * reached reads as cleared), results are those of the CPU mappers run with the same region size.  What counts tiles
+ * instead: ohmhip_batch_stats::regions_touched / regions_resident, ohmhip_cache_stats, the memory limit's granule.
+ * Not available for such maps (OHMHIP_ERR_UNSUPPORTED): the slot-level plumbing ohmhip_map_region_slot /
+ * _ensure_regions / the replica merge -- the partitioned map works.  One limit: tile coordinates (region coordinate x
+ * tiles per region on that axis) share the packed key's 16-bit fields, so with t tiles per region along an axis only
+ * region coordinates within +-32767 / t are addressable there (64^3 at 0.1 m: +-26 km in z); rays beyond are rejected by
+ * the key test like rays beyond the reference's own int16 region range. */
 void ohmhip_map_config_default(ohmhip_map_config *config); /* reference defaults, ohm/OccupancyMap.cpp:192-223 */
 int ohmhip_map_create(ohmhip_map_t *map, const ohmhip_map_config *config); /* GpuMap ctor + gpumap::enableGpu,
                                                                               ohmgpu/GpuMap.cpp:272, 106-122 */

@@ -172,6 +172,10 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
+  if (m->mc.tile_split[1] > 1 || m->mc.tile_split[2] > 1)
+  {
+    return OHMHIP_ERR_UNSUPPORTED;  // the replica merge exchanges whole regions by slot: one-tile regions only
+  }
   if (m->config.mode != OHMHIP_MODE_OCCUPANCY || !m->layers[OHMHIP_LID_OCCUPANCY])
   {
     return OHMHIP_ERR_UNSUPPORTED;  // NDT / TSDF state is not additive: replicas or region ownership

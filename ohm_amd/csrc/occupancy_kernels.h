@@ -2844,9 +2844,9 @@ __device__ inline void applyHits(uint32_t i, const MapConst &mc, const RegionTab
     const int lx = int(vi % uint32_t(mc.dim[0]));
     const int ly = int((vi / uint32_t(mc.dim[0])) % uint32_t(mc.dim[1]));
     const int lz = int(vi / uint32_t(mc.dim[0] * mc.dim[1]));
-    centre[0] = voxelCentreAxis(mc, 0, rk[0], lx);
-    centre[1] = voxelCentreAxis(mc, 1, rk[1], ly);
-    centre[2] = voxelCentreAxis(mc, 2, rk[2], lz);
+    centre[0] = globalVoxelCentreAxis(mc, 0, int(rk[0]) * mc.dim[0] + lx);
+    centre[1] = globalVoxelCentreAxis(mc, 1, int(rk[1]) * mc.dim[1] + ly);
+    centre[2] = globalVoxelCentreAxis(mc, 2, int(rk[2]) * mc.dim[2] + lz);
   }
 
   uint32_t packed_normal = sec.incident ? sec.incident[gi] : 0u;

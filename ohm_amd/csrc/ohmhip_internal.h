@@ -57,8 +57,15 @@ struct MapConst
   double resolution;
   double region_dim[3];  ///< Spatial size of a region per axis (ohm/OccupancyMap.cpp:200-202).
   double origin[3];
-  int dim[3];            ///< Voxels per region per axis.
-  int region_voxels;     ///< dim[0] * dim[1] * dim[2]
+  /// Voxels per TILE per axis: the unit the whole pipeline works in (hash table, pool slots, LDS count tile, segment and
+  /// sample keys).  A region of up to 32768 voxels is one tile; a larger one (ohm/OccupancyMap.h:287 allows 255 per axis)
+  /// is cut into equal tiles of full x rows -- z slabs, and y strips of single z layers when one layer alone is too
+  /// large -- so that a tile's voxels are contiguous in the region's MapChunk block.  Tile coordinates are global voxel
+  /// coordinates divided by dim[]; they play the part of region coordinates everywhere but in the key maths.
+  int dim[3];
+  int region_voxels;     ///< dim[0] * dim[1] * dim[2] (voxels per tile)
+  int kdim[3];           ///< Voxels per REGION per axis as the caller configured them: key maths only (voxelKey, voxel centres).
+  int tile_split[3];     ///< kdim / dim: tiles per region per axis ({1, 1, 1}: a region is a tile)
   float hit_value;
   float miss_value;
   float threshold_value;
@@ -247,13 +254,22 @@ __host__ __device__ inline uint32_t partitionOwner(const unsigned char *table, c
   return regionOwner(rx, ry, rz, shift, world);
 }
 
-/// Owner of a region under the map's partition (device code: MapConst::owner_table is a device pointer).
+/// floor(a / b) for b > 0
+__host__ __device__ inline int floorDiv(int a, int b)
+{
+  const int q = a / b;
+  return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+
+/// Owner of the region a TILE belongs to under the map's partition (device code: MapConst::owner_table is a device
+/// pointer).  Ownership is a property of the caller's regions: all tiles of a region share their owner.
 __device__ inline uint32_t regionOwnerOf(const MapConst &mc, uint64_t key)
 {
   int16_t r[3];
   unpackRegionKey(key, r);
-  return partitionOwner(mc.owner_table, mc.owner_grid_origin, mc.owner_grid_dims, mc.owner_shift, mc.owner_world, r[0],
-                        r[1], r[2]);
+  return partitionOwner(mc.owner_table, mc.owner_grid_origin, mc.owner_grid_dims, mc.owner_shift, mc.owner_world,
+                        floorDiv(r[0], mc.tile_split[0]), floorDiv(r[1], mc.tile_split[1]),
+                        floorDiv(r[2], mc.tile_split[2]));
 }
 
 __device__ inline bool ownsRegion(const MapConst &mc, uint64_t key)

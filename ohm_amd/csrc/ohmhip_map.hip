@@ -220,6 +220,9 @@ struct ohmhip_map_s
   /// Traversal layer only: per-voxel fixed-point sum of a batch's ray lengths (zero between batches).
   unsigned long long *d_traversal_acc = nullptr;
   DevBuf merge_slots, merge_keys_dev, merge_delta, merge_observers;
+  /// Regions cut into tiles (tiling_impl.h): > 0 while the translation layer calls back into the entry points with tile
+  /// keys.
+  int tile_passthrough = 0;
   /// Partitioned map (partition_impl.h): the owner table of ohmhip_map_set_region_partition (host copy for
   /// ohmhip_map_region_owners, device copy behind MapConst::owner_table) and the scratch of ohmhip_map_route_rays.
   struct PartitionState
@@ -328,6 +331,20 @@ struct ohmhip_map_s
   uint64_t evictions = 0, readmissions = 0;
   double spill_ms[6] = { 0, 0, 0, 0, 0, 0 };  ///< OHMHIP_DEBUG_FLAGS & 512: evict select / copy / compact, readmit copy, failed attempts, store growth
 };
+
+// Regions larger than one tile (tiling_impl.h): the entry points that name or list regions translate.
+inline bool tiledBoundary(ohmhip_map_t m)
+{
+  return m && (m->mc.tile_split[1] > 1 || m->mc.tile_split[2] > 1) && m->tile_passthrough == 0;
+}
+namespace
+{
+void chooseTileDims(const int dims[3], int limit, int tile[3]);
+int tiledListRegions(ohmhip_map_t m, bool dirty_only, int16_t *keys_xyz, size_t capacity, size_t *count);
+int tiledReadRegions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, size_t count, void *const *dsts);
+int tiledWriteRegions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, size_t count, const void *const *srcs);
+int tiledRemoveRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed);
+}  // namespace
 
 // Defined further down (they use the region read / remove machinery of the C ABI section).
 int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed);
@@ -1859,25 +1876,29 @@ try
   MapConst &mc = m->mc;
   std::memset(&mc, 0, sizeof(mc));
   mc.resolution = m->config.resolution;
-  for (int a = 0; a < 3; ++a)
   {
-    mc.dim[a] = m->config.region_dim[a];
-    mc.region_dim[a] = mc.dim[a] * mc.resolution;  // ohm/OccupancyMap.cpp:200-202
-    mc.origin[a] = m->config.origin[a];
+    // A region of more than 2^15 voxels is cut into equal tiles that fit the LDS count tile and the 15-bit voxel index
+    // of the segment / sample / event keys (tiling_impl.h); a region of up to 32^3 voxels is one tile.
+    const int region_dims[3] = { m->config.region_dim[0], m->config.region_dim[1], m->config.region_dim[2] };
+    int tile[3];
+    chooseTileDims(region_dims, 1 << kHitVoxelBits, tile);
+    for (int a = 0; a < 3; ++a)
+    {
+      mc.kdim[a] = region_dims[a];
+      mc.dim[a] = tile[a];
+      mc.tile_split[a] = region_dims[a] / tile[a];
+      mc.region_dim[a] = mc.kdim[a] * mc.resolution;  // ohm/OccupancyMap.cpp:200-202
+      mc.origin[a] = m->config.origin[a];
+    }
   }
   mc.region_voxels = mc.dim[0] * mc.dim[1] * mc.dim[2];
   {
-    // Fixed-point walk predictor (ohmhip_internal.h, Segment): a region's diagonal maps to 2^30 / 1.01 units; the
-    // trusted lead covers one truncation per candidate plus one per step a candidate can take inside a region.
-    const double diagonal = std::sqrt(mc.region_dim[0] * mc.region_dim[0] + mc.region_dim[1] * mc.region_dim[1] +
-                                      mc.region_dim[2] * mc.region_dim[2]);
+    // Fixed-point walk predictor (ohmhip_internal.h, Segment): a TILE's diagonal maps to 2^30 / 1.01 units; the
+    // trusted lead covers one truncation per candidate plus one per step a candidate can take inside a tile.
+    const double tx = mc.dim[0] * mc.resolution, ty = mc.dim[1] * mc.resolution, tz = mc.dim[2] * mc.resolution;
+    const double diagonal = std::sqrt(tx * tx + ty * ty + tz * tz);
     mc.fix_scale = double(kFixMaxDelta) / (1.01 * diagonal);
     mc.fix_margin = 2u * uint32_t(std::max(mc.dim[0], std::max(mc.dim[1], mc.dim[2]))) + 8u;
-  }
-  if (mc.region_voxels > (1 << kHitVoxelBits))
-  {
-    delete m;
-    return OHMHIP_ERR_UNSUPPORTED;  // region tile must fit the LDS count tile / 15-bit voxel index
   }
   applyValueConfig(m);
 
@@ -3012,6 +3033,10 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
+  if (tiledBoundary(m))
+  {
+    return tiledListRegions(m, false, nullptr, 0, count);
+  }
   *count = size_t(m->slots_committed) + m->spilled.size();  // (regions in the host store are part of the map)
   return OHMHIP_OK;
 }
@@ -3024,6 +3049,10 @@ try
   if (!m || !count)
   {
     return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (tiledBoundary(m))
+  {
+    return tiledListRegions(m, false, keys_xyz, capacity, count);
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   const int err = refreshHostRegionTable(m);
@@ -3052,6 +3081,10 @@ try
   if (!m || !count)
   {
     return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (tiledBoundary(m))
+  {
+    return tiledListRegions(m, true, keys_xyz, capacity, count);
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   int err = refreshHostRegionTable(m);
@@ -3117,6 +3150,10 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
+  if (tiledBoundary(m))
+  {
+    return OHMHIP_ERR_UNSUPPORTED;  // a region cut into tiles has no single slot (zero-copy views: 32^3 regions)
+  }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   const int err = refreshHostRegionTable(m);
   if (err)
@@ -3165,6 +3202,10 @@ try
   if (!m->layers[layer_id])
   {
     return OHMHIP_ERR_NOT_FOUND;
+  }
+  if (tiledBoundary(m))
+  {
+    return tiledReadRegions(m, layer_id, keys_xyz, count, dsts);
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));  // fence: all queued integration done
   int err = refreshHostRegionTable(m);
@@ -3322,6 +3363,10 @@ try
   {
     return OHMHIP_ERR_NOT_FOUND;
   }
+  if (tiledBoundary(m))
+  {
+    return tiledWriteRegions(m, layer_id, keys_xyz, count, srcs);
+  }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   OHMHIP_CHECK(readmitSpilledKeys(m, keys_xyz, count));  // (an upload edits the region where it lives: in the pool)
   OHMHIP_CHECK(makeRoomForNamedRegions(m, keys_xyz, count));
@@ -3412,6 +3457,10 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
+  if (tiledBoundary(m))
+  {
+    return OHMHIP_ERR_UNSUPPORTED;  // slots are per tile: the zero-copy / merge plumbing is for one-tile regions
+  }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
   OHMHIP_CHECK(readmitSpilledKeys(m, keys_xyz, count));
   OHMHIP_CHECK(makeRoomForNamedRegions(m, keys_xyz, count));
@@ -3471,6 +3520,10 @@ try
     return OHMHIP_ERR_INVALID_ARG;
   }
   OHMHIP_SETTLE(m);
+  if (tiledBoundary(m))
+  {
+    return tiledRemoveRegions(m, keys_xyz, count, removed);
+  }
   // Regions held in the host store (spill to host) are simply forgotten.
   size_t forgotten = 0;
   for (size_t i = 0; i < count && !m->spilled.empty(); ++i)
@@ -4210,3 +4263,4 @@ OHMHIP_ABI_CATCH
 
 #include "merge_impl.h"
 #include "partition_impl.h"
+#include "tiling_impl.h"

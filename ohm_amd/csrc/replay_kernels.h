@@ -25,9 +25,9 @@ __device__ inline void voxelCentreOf(const MapConst &mc, const RegionTable &rt, 
   const int lx = int(vi % uint32_t(mc.dim[0]));
   const int ly = int((vi / uint32_t(mc.dim[0])) % uint32_t(mc.dim[1]));
   const int lz = int(vi / uint32_t(mc.dim[0] * mc.dim[1]));
-  centre[0] = voxelCentreAxis(mc, 0, rk[0], lx);
-  centre[1] = voxelCentreAxis(mc, 1, rk[1], ly);
-  centre[2] = voxelCentreAxis(mc, 2, rk[2], lz);
+  centre[0] = globalVoxelCentreAxis(mc, 0, int(rk[0]) * mc.dim[0] + lx);
+  centre[1] = globalVoxelCentreAxis(mc, 1, int(rk[1]) * mc.dim[1] + ly);
+  centre[2] = globalVoxelCentreAxis(mc, 2, int(rk[2]) * mc.dim[2] + lz);
 }
 
 /// Compact the indices of the first event of every voxel group: the replay kernels then run one lane per VOXEL with full
@@ -381,9 +381,9 @@ __global__ void __launch_bounds__(128)
       {
         mcoord = mean[2 * gi];
         mcount = mean[2 * gi + 1];
-        centre[0] = voxelCentreAxis(mc, 0, rk[0], lx);
-        centre[1] = voxelCentreAxis(mc, 1, rk[1], ly);
-        centre[2] = voxelCentreAxis(mc, 2, rk[2], lz);
+        centre[0] = globalVoxelCentreAxis(mc, 0, gx);
+        centre[1] = globalVoxelCentreAxis(mc, 1, gy);
+        centre[2] = globalVoxelCentreAxis(mc, 2, gz);
       }
       packed_normal = sec.incident ? sec.incident[gi] : 0u;
     }
@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(256)
     splitGlobal(g0, mc.dim[0], r0, l0);
     splitGlobal(g1, mc.dim[1], r1, l1);
     splitGlobal(g2, mc.dim[2], r2, l2);
-    const D3 centre = d3(voxelCentreAxis(mc, 0, r0, l0), voxelCentreAxis(mc, 1, r1, l1), voxelCentreAxis(mc, 2, r2, l2));
+    const D3 centre = d3(globalVoxelCentreAxis(mc, 0, g0), globalVoxelCentreAxis(mc, 1, g1), globalVoxelCentreAxis(mc, 2, g2));
     const float sdf = tsdfComputeDistance(sensor, sample, centre);
     if (sdf < kTsdfFreeMargin * mc.tsdf_trunc)
     {
@@ -677,10 +677,10 @@ __global__ void __launch_bounds__(256)
   {
     if (n < max_keys_per_line)
     {
-      int r0, r1, r2, l0, l1, l2;
-      splitGlobal(g0, mc.dim[0], r0, l0);
-      splitGlobal(g1, mc.dim[1], r1, l1);
-      splitGlobal(g2, mc.dim[2], r2, l2);
+      int r0, r1, r2, l0, l1, l2;  // the caller's region key: region edge, not tile edge
+      splitGlobal(g0, mc.kdim[0], r0, l0);
+      splitGlobal(g1, mc.kdim[1], r1, l1);
+      splitGlobal(g2, mc.kdim[2], r2, l2);
       GpuKeyOut k;
       k.region[0] = int16_t(r0);
       k.region[1] = int16_t(r1);

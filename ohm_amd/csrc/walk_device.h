@@ -63,7 +63,10 @@ __device__ inline bool voxelKey(const MapConst &mc, const double p[3], int regio
     const double region_min = centre - 0.5 * mc.region_dim[a];
     const double pl = p[a] - mc.origin[a] - region_min;
     const int q = pointToRegionVoxel(pl, mc.resolution, mc.region_dim[a]);
-    ok = ok && 0 <= q && q < mc.dim[a];
+    ok = ok && 0 <= q && q < mc.kdim[a];
+    // (regions cut into tiles: the tile coordinate coord * tile_split + j has to fit the 16-bit field of the packed
+    // key too -- include/ohmhip.h, "LARGE REGIONS")
+    ok = ok && coord * mc.tile_split[a] >= -32768 && coord * mc.tile_split[a] + (mc.tile_split[a] - 1) <= 32767;
     region[a] = coord;
     local[a] = q;
   }
@@ -89,7 +92,7 @@ __device__ inline double voxelCentreAxis(const MapConst &mc, int a, int region, 
   return v;
 }
 
-/// floor division / modulo for global voxel coordinate -> (region, local).
+/// floor division / modulo for global voxel coordinate -> (region, local), or -> (tile, local) with the tile edge.
 __device__ inline void splitGlobal(int g, int dim, int &region, int &local)
 {
   if ((dim & (dim - 1)) == 0)
@@ -119,6 +122,16 @@ __device__ inline int localCoord(int g, int dim)
   }
   int r = g % dim;
   return (r < 0) ? r + dim : r;
+}
+
+/// Voxel centre along one axis from the GLOBAL voxel coordinate, evaluated as the reference evaluates it: from the
+/// caller's region coordinate and the voxel's coordinate inside that region (voxelCentreAxis) -- which is what a tile
+/// coordinate has to be turned back into first.
+__device__ inline double globalVoxelCentreAxis(const MapConst &mc, int a, int g)
+{
+  int region, local;
+  splitGlobal(g, mc.kdim[a], region, local);
+  return voxelCentreAxis(mc, a, region, local);
 }
 
 /// Time at which the j-th step (j >= 1) along an axis is taken: the value `time_next[axis]` holds after j-1 steps on
@@ -264,12 +277,15 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
     // unaddressable end point lands on Key::kNull -- region (-32768)^3, voxel 0 (an end point in that corner region IS
     // addressable and keeps its voxel; only the walk treats its key as null).  Mirrored here so the maps stay identical: a ray with no walk whose "start voxel" is the voxel the sample goes to.
     const bool include_end = clipped_end || (ray_flags & OHMHIP_RF_END_POINT_AS_FREE);
-    if (!include_end && !(ray_flags & OHMHIP_RF_EXCLUDE_SAMPLE))
+    // (a map whose regions are cut into tiles cannot address Key::kNull's region -- its tile coordinates leave the
+    // packed key's range: there the sample of an unaddressable end point is dropped)
+    const bool tiled = (mc.tile_split[1] | mc.tile_split[2]) > 1;
+    if (!include_end && !(ray_flags & OHMHIP_RF_EXCLUDE_SAMPLE) && (addressable1 || !tiled))
     {
 #pragma unroll
       for (int a = 0; a < 3; ++a)
       {
-        rw.g0[a] = addressable1 ? (r1[a] * mc.dim[a] + l1[a]) : (-32768 * mc.dim[a]);
+        rw.g0[a] = addressable1 ? (r1[a] * mc.kdim[a] + l1[a]) : (-32768 * mc.kdim[a]);
       }
       rw.flags = kRwPassed | kRwValid | kRwApplySample;
     }
@@ -307,8 +323,8 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
     }
     rw.init[a] = exit0;
     rw.delta[a] = exit1;
-    rw.g0[a] = r0[a] * mc.dim[a] + l0[a];
-    const int g1 = r1[a] * mc.dim[a] + l1[a];
+    rw.g0[a] = r0[a] * mc.kdim[a] + l0[a];
+    const int g1 = r1[a] * mc.kdim[a] + l1[a];
     const int diff = g1 - rw.g0[a];
     rw.total[a] = diff < 0 ? -diff : diff;
     // The step direction the reference uses comes from the sign of the ray direction, while the step COUNT comes
