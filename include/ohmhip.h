@@ -287,6 +287,9 @@ typedef struct ohmhip_cache_stats
   uint64_t readmissions;      /* regions brought back from it                                               */
   uint32_t regions_spilled;   /* regions in the host store right now                                        */
   uint32_t spill_enabled;
+  uint64_t writebacks;        /* regions copied to the store in the background, ahead of their eviction     */
+  uint64_t writeback_hits;    /* evictions that found their region clean (no copy-out on the batch's path)   */
+  uint64_t writeback_stale;   /* background copies discarded because a batch touched the region afterwards  */
 } ohmhip_cache_stats;
 int ohmhip_map_cache_stats(ohmhip_map_t map, ohmhip_cache_stats *stats, int reset);
 /* RESIDENCY LIMIT.  Without spilling (below) a map that outgrows what it may allocate fails the batch that needs the
@@ -307,11 +310,17 @@ int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
  * library and dropped from the pool, and the batch is repeated.  A stored region stays part of the map: it is listed by
  * ohmhip_map_regions / _region_count / _dirty_regions, ohmhip_map_read_regions serves it from the store, and it returns
  * to the pool with its content when a later batch reaches it or an upload / ohmhip_map_ensure_regions names it.  Results
- * are those of an unbounded pool.  What does not combine with it: replica merge (OHMHIP_ERR_UNSUPPORTED either way
+ * are those of an unbounded pool.  WRITE-BACK: once the pool is under pressure the regions the policy would evict next
+ * are copied to the store in the background, on the copy stream while batches run, so that an eviction finds them
+ * clean and only drops them (the reference overlaps the download of the cache slot it reuses with queued work the same
+ * way, ohmgpu/GpuLayerCache.cpp:550-584); a copy is discarded if a batch touches its region afterwards
+ * (ohmhip_cache_stats::writebacks / writeback_hits / writeback_stale).  What does not combine with it: replica merge (OHMHIP_ERR_UNSUPPORTED either way
  * round) and the zero-copy views (ohmhip_map_region_slot reports OHMHIP_ERR_NOT_FOUND for a stored region).  A batch
  * that alone touches more regions than the limit allows still fails with OHMHIP_ERR_CAPACITY; turning spilling on
  * therefore sets the batch coalescing threshold to 0 (a collected batch touches the regions of all its calls at once). */
 int ohmhip_map_set_spill_to_host(ohmhip_map_t map, int enable);
+/* The background write-back of the spill path (see WRITE-BACK above), opt-in: off by default. */
+int ohmhip_map_set_spill_writeback(ohmhip_map_t map, int enable);
 /* Wait for all queued work (GpuMap::syncVoxels fence half, ohmgpu/GpuMap.cpp:308-324). */
 int ohmhip_map_sync(ohmhip_map_t map);
 int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);

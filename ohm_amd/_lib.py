@@ -65,7 +65,8 @@ class CacheStats(C.Structure):
     _fields_ = [("hits", C.c_uint64), ("misses", C.c_uint64), ("full", C.c_uint64), ("regions_resident", C.c_uint32),
                 ("region_capacity", C.c_uint32), ("bytes_per_region", C.c_uint64), ("memory_limit", C.c_uint64),
                 ("evictions", C.c_uint64), ("readmissions", C.c_uint64), ("regions_spilled", C.c_uint32),
-                ("spill_enabled", C.c_uint32)]
+                ("spill_enabled", C.c_uint32), ("writebacks", C.c_uint64), ("writeback_hits", C.c_uint64),
+                ("writeback_stale", C.c_uint64)]
 
 
 class Partition(C.Structure):
@@ -156,6 +157,7 @@ _sigs = {
     "ohmhip_map_cache_stats": (C.c_int, [_vp, C.POINTER(CacheStats), C.c_int]),
     "ohmhip_map_set_memory_limit": (C.c_int, [_vp, C.c_uint64]),
     "ohmhip_map_set_spill_to_host": (C.c_int, [_vp, C.c_int]),
+    "ohmhip_map_set_spill_writeback": (C.c_int, [_vp, C.c_int]),
     "ohmhip_comm_unique_id": (C.c_int, [_vp]),
     "ohmhip_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
     "ohmhip_comm_destroy": (C.c_int, [_vp]),

@@ -327,10 +327,42 @@ struct ohmhip_map_s
     size_t records_total = 0;
   } store;
   std::unordered_map<uint64_t, SpilledRegion> spilled;
+  /// Background write-back (writeback_impl.h): resident regions whose content already sits in a store record, valid
+  /// while the region's use stamp is the one the copy was taken at.
+  struct Precleaned
+  {
+    char *record = nullptr;
+    uint32_t last_use = 0;
+  };
+  std::unordered_map<uint64_t, Precleaned> precleaned;
+  std::vector<char *> stale_records;  ///< records of discarded copies, recycled once the copy stream has passed them
+  static constexpr uint32_t kWritebackRing = 4;
+  struct WritebackRing
+  {
+    DevBuf jobs;
+    hipEvent_t done = nullptr;
+    bool used = false;
+  } wb_ring[kWritebackRing];
+  uint32_t wb_next = 0;
+  uint32_t *h_use = nullptr;     ///< pinned: the resident regions' use stamps as of the latest plan (queueUseStamps)
+  size_t h_use_capacity = 0;
+  uint32_t h_use_slots = 0;      ///< slots the copy covers
+  uint32_t evicted_per_call = 0; ///< regions the latest eviction moved out (sizes the write-back's lead)
+  bool writeback_off = true;     ///< ohmhip_map_set_spill_writeback (off by default; OHMHIP_WRITEBACK=0 / 1 overrides)
+  uint64_t writebacks = 0, writeback_hits = 0, writeback_stale = 0;
   bool spill_enabled = false;
   uint64_t evictions = 0, readmissions = 0;
   double spill_ms[6] = { 0, 0, 0, 0, 0, 0 };  ///< OHMHIP_DEBUG_FLAGS & 512: evict select / copy / compact, readmit copy, failed attempts, store growth
 };
+
+// Background write-back of the spill path (writeback_impl.h).
+namespace
+{
+int queueUseStamps(ohmhip_map_t m, hipStream_t stream);
+void scheduleWriteBack(ohmhip_map_t m, uint32_t now);
+void dropPrecleaned(ohmhip_map_t m);
+void dropPrecleanedKey(ohmhip_map_t m, uint64_t key);
+}  // namespace
 
 // Regions larger than one tile (tiling_impl.h): the entry points that name or list regions translate.
 inline bool tiledBoundary(ohmhip_map_t m)
@@ -496,6 +528,10 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   const size_t rv = size_t(m->mc.region_voxels);
   const uint32_t hash_cap = nextPow2(std::max<uint32_t>(1024u, capacity * 2u));
   hipStream_t s = m->stream;
+  if (m->copy_stream && (!m->precleaned.empty() || !m->stale_records.empty()))
+  {
+    OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));  // background write-back copies read the pool being replaced
+  }
 
   std::vector<void *> fresh;  // released again if any step fails
   auto alloc = [&](void **p, size_t bytes) -> int {
@@ -1150,6 +1186,7 @@ struct BatchRun
                        m->chunk_capacity, batch_chunk_segments, m->h_info_dev, m->d_info + next_info_index,
                        batchEventCount(m));
     m->info_clean = true;
+    OHMHIP_CHECK(queueUseStamps(m, f));  // (spill to host: the regions' use stamps reach the host with the summary)
     OHMHIP_CHECK(hipEventRecord(tev[5], f));
     OHMHIP_CHECK(hipEventRecord(m->ev[7], f));
     OHMHIP_CHECK(hipStreamWaitEvent(s, m->ev[7], 0));
@@ -1624,6 +1661,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
       }
     }
     OHMHIP_CHECK(run.commitRegions());
+    scheduleWriteBack(m, uint32_t(m->batch_seq + 1u));  // (spill to host: keep the next eviction's victims clean)
     OHMHIP_CHECK(run.sizeBuffers());
     OHMHIP_CHECK(run.binAndOrder());
     OHMHIP_CHECK(run.walk());
@@ -2009,6 +2047,10 @@ try
   {
     m->event_limit = uint32_t(std::max(0, std::atoi(env)));
   }
+  if (const char *env = std::getenv("OHMHIP_WRITEBACK"))
+  {
+    m->writeback_off = std::atoi(env) == 0;
+  }
   if (const char *env = std::getenv("OHMHIP_BIN_RAYS"))
   {
     m->bin_rays_per_block = uint32_t(std::max(128, std::min(int(kBinRaysPerBlock), std::atoi(env))));
@@ -2093,6 +2135,18 @@ try
   m->merge_keys_dev.release();
   m->merge_delta.release();
   m->merge_observers.release();
+  if (m->h_use)
+  {
+    (void)hipHostFree(m->h_use);
+  }
+  for (auto &ring : m->wb_ring)
+  {
+    ring.jobs.release();
+    if (ring.done)
+    {
+      (void)hipEventDestroy(ring.done);
+    }
+  }
   m->partition.table_dev.release();
   m->partition.masks.release();
   m->partition.block_counts.release();
@@ -2943,10 +2997,14 @@ try
   stats->readmissions = m->readmissions;
   stats->regions_spilled = uint32_t(m->spilled.size());
   stats->spill_enabled = m->spill_enabled ? 1u : 0u;
+  stats->writebacks = m->writebacks;
+  stats->writeback_hits = m->writeback_hits;
+  stats->writeback_stale = m->writeback_stale;
   if (reset)
   {
     m->cache_hits = m->cache_misses = m->cache_full = 0;
     m->evictions = m->readmissions = 0;
+    m->writebacks = m->writeback_hits = m->writeback_stale = 0;
   }
   return OHMHIP_OK;
 }
@@ -2996,6 +3054,23 @@ try
     m->coalesce_min_rays = 0;
   }
   m->spill_enabled = enable != 0;
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_set_spill_writeback(ohmhip_map_t m, int enable)
+try
+{
+  OHMHIP_SETTLE(m);
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  m->writeback_off = enable == 0;
+  if (m->writeback_off)
+  {
+    dropPrecleaned(m);
+  }
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH
@@ -3368,6 +3443,11 @@ try
     return tiledWriteRegions(m, layer_id, keys_xyz, count, srcs);
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  for (size_t i = 0; i < count && !m->precleaned.empty(); ++i)
+  {
+    // (the write-back's copy of a region that is being rewritten is void)
+    dropPrecleanedKey(m, packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]));
+  }
   OHMHIP_CHECK(readmitSpilledKeys(m, keys_xyz, count));  // (an upload edits the region where it lives: in the pool)
   OHMHIP_CHECK(makeRoomForNamedRegions(m, keys_xyz, count));
   int err = refreshHostRegionTable(m);
@@ -3557,6 +3637,11 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
   }
   hipStream_t s = m->stream;
   OHMHIP_CHECK(hipStreamSynchronize(s));
+  if (!m->precleaned.empty() || !m->stale_records.empty())
+  {
+    // background write-back copies read the slots that are about to move
+    OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
+  }
   int err = refreshHostRegionTable(m);
   if (err)
   {
@@ -3567,11 +3652,18 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
   uint32_t k = 0;
   for (size_t i = 0; i < count; ++i)
   {
-    const auto it = m->region_slots.find(packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]));
+    const uint64_t packed = packRegionKey(keys_xyz[3 * i], keys_xyz[3 * i + 1], keys_xyz[3 * i + 2]);
+    const auto it = m->region_slots.find(packed);
     if (it != m->region_slots.end() && !drop[it->second])
     {
       drop[it->second] = 1;
       ++k;
+      const auto pre = m->precleaned.find(packed);
+      if (pre != m->precleaned.end())
+      {
+        releaseStoreRecord(m, pre->second.record);  // (the copy stream is drained: nothing writes the record any more)
+        m->precleaned.erase(pre);
+      }
     }
   }
   if (removed)
@@ -3678,6 +3770,8 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
 /// Spill to host, first half: copy the least recently used resident regions into the host store and drop them from the
 /// pool, so that at least `want_free` slots become free (a quarter of the pool at a time, so evictions are rare).
 /// Regions the current batch attempt touched carry the newest stamp (k_plan) and go last.
+#include "writeback_impl.h"
+
 int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
 {
   const auto t_begin = std::chrono::steady_clock::now();
@@ -3699,55 +3793,16 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
   std::vector<uint32_t> stamps(2 * size_t(n)), dirty(n);
   OHMHIP_CHECK(hipMemcpy(stamps.data(), m->d_last_use, sizeof(uint32_t) * 2 * n, hipMemcpyDeviceToHost));
   OHMHIP_CHECK(hipMemcpy(dirty.data(), m->d_dirty, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-  // Who goes: the regions whose NEXT use is expected to be farthest away.  A region that came back after a gap has a
-  // period (last use - the use before the gap); while it is on schedule (idle for less than two periods) its next use
-  // is predicted at last + period.  Everything else -- never re-used, or overdue -- has no prediction and goes first,
-  // least recently used first: a sensor moving through new space sees plain LRU, a sensor sweeping a map larger than
-  // the pool again and again (the cyclic access LRU is worst at: it evicts exactly what the next calls need) keeps a
-  // fixed part resident and cycles the rest.  The regions of the batch being attempted carry its stamp: always last.
+  // Who goes: the regions whose NEXT use is expected to be farthest away (rankForEviction, writeback_impl.h).
   const uint32_t now = uint32_t(m->batch_seq + 1u);
-  // A region without a period of its own borrows the one the map's re-admissions show (their median), while it is
-  // younger than that: when regions keep coming back after P batches, one used a moment ago is P batches from its next
-  // use, one used P - 1 batches ago is about to be needed.
-  uint32_t common_period = 0;
-  if (m->readmit_periods.size() >= 16)
-  {
-    std::vector<uint32_t> sorted_periods(m->readmit_periods);
-    std::nth_element(sorted_periods.begin(), sorted_periods.begin() + sorted_periods.size() / 2, sorted_periods.end());
-    common_period = sorted_periods[sorted_periods.size() / 2];
-  }
-  std::vector<uint64_t> rank(n);  // larger = evicted earlier
-  for (uint32_t i = 0; i < n; ++i)
-  {
-    const uint32_t last = stamps[2 * size_t(i)], prev = stamps[2 * size_t(i) + 1];
-    const uint32_t age = now - last;  // (0: in use by the batch being attempted)
-    uint32_t period = (prev != 0 && last > prev) ? last - prev : 0;
-    if (period < 2 && common_period >= 2 && age < common_period)
-    {
-      period = common_period;
-    }
-    if (last == now)
-    {
-      rank[i] = 0;
-    }
-    else if (period >= 2 && age < 2 * period)
-    {
-      const uint32_t next = last + period;               // predicted next use
-      rank[i] = (uint64_t(1) << 32) | uint64_t((next > now) ? next - now : 0u);  // farther away = earlier out
-    }
-    else
-    {
-      rank[i] = (uint64_t(2) << 32) | uint64_t(age);     // no prediction: before all predicted ones, oldest first
-    }
-  }
+  std::vector<uint64_t> rank;
+  rankForEviction(m, stamps.data(), n, now, rank, true);
   std::vector<uint32_t> order(n);
   for (uint32_t i = 0; i < n; ++i)
   {
     order[i] = i;
   }
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rank[a] > rank[b]; });
-  const size_t rv = size_t(m->mc.region_voxels);
-  const bool keep_mask = m->config.mode != OHMHIP_MODE_OCCUPANCY;  // (transient in occupancy mode: empty between batches)
   // The victims' content goes straight from the pool into pinned store records, all regions and layers by ONE kernel
   // that writes the mapped host memory itself (k_copy_jobs); the compute stream is idle here -- it was drained above.
   lap(0, t_mark);
@@ -3755,12 +3810,22 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
   lap(5, t_mark);
   std::vector<int16_t> victim_keys(3 * size_t(k));
   std::vector<ohmhip_map_s::SpilledRegion> content(k);
-  const ohmhip_map_s::HostStore &st = m->store;
+  std::vector<uint64_t> precleaned_used;  // victims whose content the background write-back had copied already
   auto giveBack = [&]() {
-    for (auto &c : content)
+    // (records of pre-cleaned victims stay with the write-back's bookkeeping: the regions are still resident)
+    std::unordered_map<uint64_t, char> kept;
+    for (uint64_t key : precleaned_used)
     {
-      releaseStoreRecord(m, c.record);
-      c.record = nullptr;
+      kept.emplace(key, 1);
+    }
+    for (uint32_t v = 0; v < k; ++v)
+    {
+      const bool pre = content[v].record && v < uint32_t(order.size()) && kept.count(m->slot_keys_host[order[v]]) != 0;
+      if (!pre)
+      {
+        releaseStoreRecord(m, content[v].record);
+      }
+      content[v].record = nullptr;
     }
   };
   std::vector<CopyJob> jobs;
@@ -3771,30 +3836,28 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
     unpackRegionKey(m->slot_keys_host[slot], &victim_keys[3 * size_t(v)]);
     content[v].dirty = dirty[slot];
     content[v].last_use = stamps[2 * size_t(slot)];
+    // Pre-cleaned by the background write-back and not touched since: its record is in the store already.
+    const auto pre = m->precleaned.find(m->slot_keys_host[slot]);
+    if (pre != m->precleaned.end())
+    {
+      if (pre->second.last_use == stamps[2 * size_t(slot)])
+      {
+        content[v].record = pre->second.record;
+        precleaned_used.push_back(pre->first);
+        ++m->writeback_hits;
+        continue;
+      }
+      m->stale_records.push_back(pre->second.record);  // (recycled once the copy stream has passed its copy)
+      m->precleaned.erase(pre);
+      ++m->writeback_stale;
+    }
     content[v].record = takeStoreRecord(m);
     if (!content[v].record)
     {
       giveBack();
       return OHMHIP_ERR_CAPACITY;
     }
-    for (int l = 0; l < OHMHIP_LID_COUNT; ++l)
-    {
-      if (m->layers[l])
-      {
-        const size_t stride = rv * kLayerBytes[l];
-        jobs.push_back(CopyJob{ static_cast<const char *>(m->layers[l]) + stride * slot,
-                                content[v].record + st.layer_offset[l], stride });
-      }
-    }
-    if (keep_mask)
-    {
-      jobs.push_back(CopyJob{ reinterpret_cast<const char *>(m->d_hit_mask) + st.mask_bytes * slot,
-                              content[v].record + st.mask_offset, st.mask_bytes });
-    }
-    else
-    {
-      std::memset(content[v].record + st.mask_offset, 0, st.mask_bytes);
-    }
+    appendSlotToRecordJobs(m, slot, content[v].record, jobs);
   }
   {
     const int err = launchCopyJobs(m, jobs, m->copy_stream);
@@ -3816,9 +3879,22 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
   lap(1, t_mark);
   size_t removed = 0;
   {
+    // (the records of pre-cleaned victims are the spilled regions' from here on: out of the write-back's bookkeeping
+    // before the removal, which would otherwise release them with the regions)
+    std::vector<std::pair<uint64_t, ohmhip_map_s::Precleaned>> moved;
+    for (uint64_t key : precleaned_used)
+    {
+      const auto it = m->precleaned.find(key);
+      moved.push_back({ key, it->second });
+      m->precleaned.erase(it);
+    }
     const int err = removeResidentRegions(m, victim_keys.data(), k, &removed);
     if (err)
     {
+      for (auto &e : moved)
+      {
+        m->precleaned[e.first] = e.second;
+      }
       giveBack();  // the regions are still resident: nothing is lost
       return err;
     }
@@ -3830,6 +3906,7 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
       content[v];
   }
   m->evictions += removed;
+  m->evicted_per_call = k;
   return OHMHIP_OK;
 }
 
@@ -4247,6 +4324,7 @@ try
     return OHMHIP_ERR_INVALID_ARG;
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->stream));
+  dropPrecleaned(m);
   m->slots_committed = 0;
   m->region_slots.clear();
   m->slot_keys_host.clear();

@@ -460,6 +460,11 @@ class GpuMap(RayMapper):
         of cache slots (ohmgpu/GpuLayerCache.cpp:530-584) serves the same purpose."""
         L.check(L.lib.ohmhip_map_set_spill_to_host(self._handle, 1 if enable else 0), "set_spill_to_host")
 
+    def setSpillWriteback(self, enable=True):
+        """Opt-in background write-back of the spill path (include/ohmhip.h "WRITE-BACK"): the regions the eviction
+        policy would take next are copied to the host store while batches run, so an eviction finds them clean."""
+        L.check(L.lib.ohmhip_map_set_spill_writeback(self._handle, 1 if enable else 0), "set_spill_writeback")
+
     def setBatchCoalescing(self, min_rays):
         """Collect consecutive small host batches and run them as one device batch of >= min_rays rays
         (include/ohmhip.h: ohmhip_map_set_batch_coalescing; on by default with 65536).  0 turns it off."""

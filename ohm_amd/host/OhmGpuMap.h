@@ -609,6 +609,13 @@ public:
     OHMHIP_GPUAPICHECK(ohmhip_map_set_spill_to_host(handle_, enable ? 1 : 0));
   }
 
+  /// Opt-in background write-back of the spill path (include/ohmhip.h "WRITE-BACK"; the reference overlaps the download
+  /// of a reused cache slot with queued work, ohmgpu/GpuLayerCache.cpp:550-584).
+  void setSpillWriteback(bool enable = true)
+  {
+    OHMHIP_GPUAPICHECK(ohmhip_map_set_spill_writeback(handle_, enable ? 1 : 0));
+  }
+
   /// Not in the reference: run consecutive small integrateRays() batches as one device batch of at least @p min_rays
   /// rays (see ohmhip_map_set_batch_coalescing; on by default with 65536); 0 turns it off.
   void setBatchCoalescing(size_t min_rays) { OHMHIP_GPUAPICHECK(ohmhip_map_set_batch_coalescing(handle_, min_rays)); }

@@ -36,11 +36,13 @@ def limited_map(map_, regions, cls=GpuMap, **kwargs):
     return gm
 
 
-@pytest.mark.parametrize("layers", [("occupancy",), ("occupancy", "mean")])
-def test_track_under_a_memory_limit_equals_the_unbounded_result(gpu, layers):
+@pytest.mark.parametrize("layers,writeback", [(("occupancy",), False), (("occupancy", "mean"), False),
+                                              (("occupancy", "mean"), True)])
+def test_track_under_a_memory_limit_equals_the_unbounded_result(gpu, layers, writeback):
     map_ = OccupancyMap(0.1, (32, 32, 32), layers=layers)
     gm = limited_map(map_, 100)
     gm.setSpillToHost(True)
+    gm.setSpillWriteback(writeback)  # (background copies of the next victims: same results, fewer copy-outs on the path)
     om = make_oracle(map_)
     for k, origin in enumerate(track(6)):
         rays = sensor_rays(origin, 6000, seed=700 + k)
@@ -49,6 +51,7 @@ def test_track_under_a_memory_limit_equals_the_unbounded_result(gpu, layers):
     st = gm.cacheStats()
     assert st["evictions"] > 0 and st["readmissions"] > 0 and st["regions_spilled"] > 0 and st["spill_enabled"] == 1
     assert st["regions_resident"] <= 100
+    assert (st["writebacks"] > 0 and st["writeback_hits"] > 0) if writeback else st["writebacks"] == 0
     n_regions = len(om.chunks())
     assert len(gm.regionKeys()) == n_regions == st["regions_resident"] + st["regions_spilled"]
     assert len(gm.regionKeys(dirty_only=True)) == n_regions  # nothing synced yet: stored regions count as well
@@ -85,11 +88,13 @@ def test_ndt_regions_keep_their_replay_mask_across_a_spill(gpu):
     assert_parity(stats)
 
 
-def test_tsdf_regions_across_a_spill(gpu):
+@pytest.mark.parametrize("writeback", [False, True])
+def test_tsdf_regions_across_a_spill(gpu, writeback):
     from ohm_amd import GpuTsdfMap
     map_ = OccupancyMap(0.1, (32, 32, 32), layers=("tsdf",))
     gm = limited_map(map_, 100, cls=GpuTsdfMap, default_truncation_distance=0.3)
     gm.setSpillToHost(True)
+    gm.setSpillWriteback(writeback)  # (TSDF: the replay mask row travels with the pre-cleaned copy)
     om = make_oracle(map_)
     opts = gm.tsdf_options
     om.set_tsdf(max_weight=opts[0], trunc=opts[1], dropoff=opts[2], sparsity=opts[3])
@@ -103,14 +108,17 @@ def test_tsdf_regions_across_a_spill(gpu):
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["tsdf"], exact_float=True))
 
 
-def test_c3_sweep_under_the_reference_cache_budget(gpu):
+@pytest.mark.parametrize("writeback", [False, True])
+def test_c3_sweep_under_the_reference_cache_budget(gpu, writeback):
     """SURVEY 8d's cache-stress variant of C3 at test size: the lidar sweep presented as 45-degree sectors to a TSDF map
     whose pool holds a third of the regions a revolution touches; a quarter of a second revolution brings the first
-    sectors back from the host store.  Bit exact against the oracle."""
+    sectors back from the host store.  Bit exact against the oracle -- also with the background write-back on, whose
+    copies race the batches by design (a copy of a region that is touched afterwards must be discarded)."""
     from ohm_amd import GpuTsdfMap
     map_ = OccupancyMap(0.05, (32, 32, 32), layers=("tsdf",))
     gm = limited_map(map_, 1500, cls=GpuTsdfMap)
     gm.setSpillToHost(True)
+    gm.setSpillWriteback(writeback)
     om = make_oracle(map_)
     opts = gm.tsdf_options
     om.set_tsdf(max_weight=opts[0], trunc=opts[1], dropoff=opts[2], sparsity=opts[3])
