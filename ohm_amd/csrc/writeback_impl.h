@@ -224,7 +224,9 @@ void scheduleWriteBack(ohmhip_map_t m, uint32_t now)
   }
   want = std::min<uint32_t>(want, uint32_t(order.size()));
   std::partial_sort(order.begin(), order.begin() + want, order.end(),
-                    [&](uint32_t a, uint32_t b) { return rank[a] != rank[b] ? rank[a] > rank[b] : a < b; });
+                    [&](uint32_t a, uint32_t b) {
+                      return rank[a] != rank[b] ? rank[a] > rank[b] : m->slot_keys_host[a] < m->slot_keys_host[b];
+                    });
   // The job list of a write-back lives in one of a few device buffers used in turn; a buffer whose kernel has not
   // finished yet means the link is still busy with earlier write-backs: skip this round.
   ohmhip_map_s::WritebackRing &ring = m->wb_ring[m->wb_next % ohmhip_map_s::kWritebackRing];
