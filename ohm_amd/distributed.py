@@ -590,12 +590,13 @@ class PartitionedIntegrator:
         return gm.integrateRaysDevice(recv.data_ptr(), 2 * n_recv, ray_update_flags)
 
 
-def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timings=None):
+def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timings=None, streams_out=None):
     """The partitioned integration for several GpuMaps living in ONE process (stand-ins for ranks on a single GPU: tests,
     and bench.py's one-GPU C4 leg).  gpu_maps[r] carries rank r's partition (setRegionPartition); shards[r]: rank r's
     (2N_r, 3) float64 host rays.  Every rank's rays are routed by its own map (the library's kernels), the blocks are
     re-assembled per destination in (source rank, ray) order -- what the all-to-all delivers -- and integrated.  Returns
-    a dict of counts: rays routed per (source, destination), rays received per rank."""
+    a dict of counts: rays routed per (source, destination), rays received per rank.  `streams_out` (a list) receives the
+    stream each rank integrated, as (k, 6) host arrays."""
     import ctypes as C
     import time
     from . import _lib as L
@@ -638,6 +639,8 @@ def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timin
     integrated = []
     for d, gm in enumerate(gpu_maps):
         stream = np.concatenate([blocks[r][d] for r in range(world)]) if world else np.zeros((0, 6))
+        if streams_out is not None:
+            streams_out.append(stream)
         if stream.shape[0]:
             buf, ptr = L._vp(), L._vp()
             L.check(L.lib.ohmhip_buffer_create(C.byref(buf), stream.nbytes, 3), "buffer_create")
@@ -653,3 +656,91 @@ def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timin
         else:
             integrated.append(0)
     return {"routed": matrix, "received": matrix.sum(axis=0), "integrated": integrated, "visits_local": visits}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Territories dealt by measured load (strong scaling of one sensor's stream).
+# ---------------------------------------------------------------------------------------------------------------------
+def estimate_region_loads(rays, region_size, map_origin=(0, 0, 0), ray_stride=16, samples_per_region=4):
+    """Ray-region segments per region, estimated on the host from every `ray_stride`-th ray: points sampled along the ray
+    every 1 / samples_per_region of a region edge, distinct (ray, region) pairs counted and scaled back.  A planning aid
+    for `territories_by_load` -- the integration itself never uses it.  Returns {(rx, ry, rz): estimated segments}."""
+    rays = np.asarray(rays, dtype=np.float64).reshape(-1, 6)[::max(1, int(ray_stride))]
+    size = np.broadcast_to(np.asarray(region_size, dtype=np.float64), (3,))
+    mo = np.asarray(map_origin, dtype=np.float64)
+    start, end = rays[:, :3], rays[:, 3:]
+    length = np.linalg.norm(end - start, axis=1)
+    n_samples = int(np.ceil(length.max() / (size.min() / samples_per_region))) + 1
+    t = np.linspace(0.0, 1.0, n_samples)
+    loads = {}
+    for at in range(0, len(rays), 8192):
+        s, e = start[at:at + 8192], end[at:at + 8192]
+        p = s[:, None, :] + (e - s)[:, None, :] * t[None, :, None]
+        r = np.floor((p - mo) / size + 0.5).astype(np.int64)
+        ray_id = np.broadcast_to(np.arange(len(s))[:, None], r.shape[:2])
+        packed = (ray_id << 48) | ((r[..., 0] + 32768) << 32) | ((r[..., 1] + 32768) << 16) | (r[..., 2] + 32768)
+        pairs = np.unique(packed.reshape(-1)) & ((1 << 48) - 1)
+        keys, counts = np.unique(pairs, return_counts=True)
+        for k, c in zip(keys.tolist(), counts.tolist()):
+            key = ((k >> 32) - 32768, ((k >> 16) & 0xFFFF) - 32768, (k & 0xFFFF) - 32768)
+            loads[key] = loads.get(key, 0.0) + float(c) * ray_stride
+    return loads
+
+
+def territories_by_load(loads, world_size, rank, centre, region_size, map_origin=(0, 0, 0), hub_radius=1):
+    """A RegionPartition (region granularity) for ONE sensor's stream, dealt by measured load: the regions are ordered by
+    the azimuth of their centre about `centre` (the sensor) and cut into `world_size` contiguous arcs of equal load -- a
+    ray then crosses one or two territories, not all of them --, except the HUB, the regions within `hub_radius` regions
+    of the sensor, which every ray crosses whatever its direction: those go one by one, heaviest first, to the rank with
+    the least load so far.  Regions without a measured load fall into the arc their azimuth points at.  `loads`:
+    {(rx, ry, rz): load} (estimate_region_loads, or segment counts from a pilot batch)."""
+    size = np.broadcast_to(np.asarray(region_size, dtype=np.float64), (3,))
+    mo = np.asarray(map_origin, dtype=np.float64)
+    keys = np.array(sorted(loads), dtype=np.int64).reshape(-1, 3)
+    weight = np.array([loads[tuple(k)] for k in keys.tolist()], dtype=np.float64)
+    c_region = np.floor((np.asarray(centre, dtype=np.float64) - mo) / size + 0.5).astype(np.int64)
+    lo = np.minimum(keys.min(axis=0), c_region) - 1
+    hi = np.maximum(keys.max(axis=0), c_region) + 1
+    dims = (hi - lo + 1).astype(np.int64)
+
+    def azimuth(region_keys):
+        centres = region_keys * size + mo
+        d = centres - np.asarray(centre, dtype=np.float64)
+        return np.arctan2(d[..., 1], d[..., 0])
+
+    hub = np.abs(keys - c_region).max(axis=1) <= hub_radius
+    rim = ~hub
+    # arcs of equal rim load; the hub's load is dealt afterwards to whoever has least
+    order = np.argsort(azimuth(keys[rim]), kind="stable")
+    rim_weight = weight[rim][order]
+    cum = np.cumsum(rim_weight)
+    total = float(cum[-1]) if len(cum) else 0.0
+    hub_total = float(weight[hub].sum())
+    share = (total + hub_total) / world_size
+    # boundaries by azimuth such that rank r's arc carries ~ share minus what it will receive from the hub: first deal
+    # the hub (LPT) against equal arcs, then re-cut the arcs to even the sums out
+    rank_load = np.zeros(world_size)
+    hub_owner = {}
+    for i in np.argsort(-weight[hub], kind="stable"):
+        r = int(np.argmin(rank_load))
+        hub_owner[tuple(keys[hub][i].tolist())] = r
+        rank_load[r] += weight[hub][i]
+    want = np.maximum(share - rank_load, 0.0)
+    want *= total / max(want.sum(), 1e-30)
+    bounds = np.cumsum(want)
+    rim_owner = np.minimum(np.searchsorted(bounds, cum - 0.5 * rim_weight), world_size - 1)
+    az_sorted = azimuth(keys[rim])[order]
+    # arc limits in azimuth: the last region of each arc
+    limits = []
+    for r in range(world_size - 1):
+        idx = np.flatnonzero(rim_owner <= r)
+        limits.append(az_sorted[idx[-1]] if len(idx) else -np.pi)
+    limits = np.array(limits)
+    ix, iy, iz = np.meshgrid(np.arange(dims[0]), np.arange(dims[1]), np.arange(dims[2]), indexing="ij")
+    cells = np.stack([ix, iy, iz], axis=-1) + lo
+    table = np.searchsorted(limits, azimuth(cells), side="left").astype(np.uint8)
+    table = np.minimum(table, world_size - 1).astype(np.uint8)
+    for key, r in hub_owner.items():
+        c = np.asarray(key) - lo
+        table[c[0], c[1], c[2]] = r
+    return RegionPartition(world_size, rank, 0, tuple(int(v) for v in lo), table)

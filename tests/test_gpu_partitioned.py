@@ -230,3 +230,30 @@ def test_tsdf_partitioned(gpu):
         gm.close()
     union = _union_of_owned(maps, part0)
     assert_parity(compare_maps(om.chunks(), union, ["tsdf"], exact_float=True))
+
+
+def test_one_sensor_dealt_by_load_is_exact(gpu):
+    """Strong scaling of ONE sensor's stream: territories dealt by measured load (azimuth arcs + the hub regions dealt one
+    by one, ohm_amd.distributed.territories_by_load), the whole stream routed from rank 0.  Non-convex territories, every
+    ray crossing the hub: the union still equals one map's result bit for bit, and the walk work is shared evenly."""
+    world = 5
+    rays = np.concatenate([synth.rays_c1(n=60_000, max_range=16.0, seed=3, first=250 * k * 64) for k in range(5)])
+    loads = D.estimate_region_loads(rays, 3.2, ray_stride=4)
+    part0 = D.territories_by_load(loads, world, 0, (0.05, 0.05, 0.05), 3.2)
+    maps = [OccupancyMap(0.1, layers=("occupancy", "mean")) for _ in range(world)]
+    gms = [GpuMap(m) for m in maps]
+    for r, g in enumerate(gms):
+        g.setRegionPartition(part0.with_rank(r))
+        g.setBatchCoalescing(0)
+    info = D.integrate_partitioned_in_process(gms, [rays] + [np.zeros((0, 3))] * (world - 1))
+    assert info["routed"][0].sum() > rays.shape[0] // 2           # rays reach several territories ...
+    assert info["routed"][0].max() < rays.shape[0] // 2 + 1       # ... and nobody more than all of them
+    segments = [g.stats()["ray_region_segments"] for g in gms]
+    om = make_oracle(maps[0])
+    om.integrate_occupancy(rays)
+    for g in gms:
+        g.syncVoxels()
+        g.close()
+    union = _union_of_owned(maps, part0)
+    assert_parity(compare_maps(om.chunks(), union, ["occupancy", "mean"], exact_float=True))
+    assert max(segments) < 1.6 * sum(segments) / world, segments

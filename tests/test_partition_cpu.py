@@ -163,3 +163,25 @@ def test_two_rank_gloo_route_exchange_integrate_matches_sequential(tmp_path):
             seen.add(key)
             assert np.array_equal(tile.view(np.uint32), seq_chunks[key]["occupancy"].view(np.uint32)), key
     assert seen == set(seq_chunks.keys())
+
+
+def test_territories_by_load_balance_one_sensor():
+    """One sensor's stream dealt over 8 ranks by measured load: every rank gets about an eighth of the segments, every
+    region has exactly one owner, the regions around the sensor (which every ray crosses) are spread over the ranks."""
+    rays = synth.rays_c1(n=1_000_000)                                  # one whole revolution
+    loads = D.estimate_region_loads(rays, 3.2, ray_stride=16)
+    assert loads[(0, 0, 0)] == pytest.approx(1_000_000, rel=0.01)    # every ray starts in the sensor's region
+    part = D.territories_by_load(loads, 8, 3, (0.05, 0.05, 0.05), 3.2)
+    keys = np.array(sorted(loads), dtype=np.int16)
+    owners = part.owners(keys)
+    weight = np.array([loads[tuple(int(v) for v in k)] for k in keys])
+    share = np.array([weight[owners == r].sum() for r in range(8)]) / weight.sum()
+    assert share.min() > 0.10 and share.max() < 0.15, share
+    hub = keys[np.abs(keys).max(axis=1) <= 1]
+    assert len(np.unique(part.owners(hub))) >= 6
+    # contiguous arcs: a rank's rim regions span a limited range of azimuth
+    rim = np.abs(keys).max(axis=1) > 1
+    az = np.arctan2(keys[rim][:, 1] * 3.2 - 0.05, keys[rim][:, 0] * 3.2 - 0.05)
+    for r in range(1, 7):
+        mine = az[owners[rim] == r]
+        assert mine.max() - mine.min() < 2 * np.pi * 0.4
