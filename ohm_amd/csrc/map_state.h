@@ -144,6 +144,8 @@ struct ohmhip_map_s
   int device = 0;
   hipStream_t stream = nullptr;       ///< compute stream
   hipStream_t copy_stream = nullptr;  ///< side stream for region upload/download
+  hipStream_t wb_stream = nullptr;    ///< background write-back of the spill path (created on first use): its device-to-host
+                                      ///< copies must not delay the re-admissions queued on copy_stream
   /// Stream of a batch's set-up pass (k_ray_setup, k_plan).  It reads the rays and the region table only, and writes
   /// per-batch scratch that exists twice (see `parity`), so the set-up of batch N+1 runs beside the sample sort of batch
   /// N and in the CUs its walk kernel vacates.  It is idle whenever no batch call is in progress: every call waits for
@@ -316,7 +318,10 @@ struct ohmhip_map_s
   static constexpr uint32_t kWritebackRing = 4;
   struct WritebackRing
   {
-    DevBuf jobs;
+    void *jobs_host = nullptr;  ///< pinned, device visible: the kernel reads its job list straight from here (no copy call:
+                                ///< a blocking hipMemcpy from pageable memory would stall the batch pipeline)
+    void *jobs_dev = nullptr;
+    size_t capacity = 0;        ///< bytes
     hipEvent_t done = nullptr;
     bool used = false;
   } wb_ring[kWritebackRing];
@@ -327,8 +332,10 @@ struct ohmhip_map_s
   uint32_t evicted_per_call = 0; ///< regions the latest eviction moved out (sizes the write-back's lead)
   bool writeback_off = true;     ///< ohmhip_map_set_spill_writeback (off by default; OHMHIP_WRITEBACK=0 / 1 overrides)
   uint64_t writebacks = 0, writeback_hits = 0, writeback_stale = 0;
+  uint32_t writeback_workgroups = 32;  ///< grid of the background copy kernel (OHMHIP_WRITEBACK_WGS): the CUs it may hold
   bool spill_enabled = false;
   uint64_t evictions = 0, readmissions = 0;
+  double wb_host_ms = 0;  ///< OHMHIP_DEBUG_FLAGS & 512: host time spent scheduling write-backs
   double spill_ms[6] = { 0, 0, 0, 0, 0, 0 };  ///< OHMHIP_DEBUG_FLAGS & 512: evict select / copy / compact, readmit copy, failed attempts, store growth
 };
 
@@ -338,6 +345,7 @@ namespace
 int queueUseStamps(ohmhip_map_t m, hipStream_t stream);
 void scheduleWriteBack(ohmhip_map_t m, uint32_t now);
 void dropPrecleaned(ohmhip_map_t m);
+int drainWriteBack(ohmhip_map_t m);
 void dropPrecleanedKey(ohmhip_map_t m, uint64_t key);
 }  // namespace
 

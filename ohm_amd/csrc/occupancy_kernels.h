@@ -3121,6 +3121,34 @@ __global__ void __launch_bounds__(256) k_copy_jobs(const CopyJob *__restrict__ j
   }
 }
 
+/// The same list of copies done by a SMALL persistent grid (the background write-back of the spill path): `gridDim.x`
+/// workgroups walk the (job, part) pairs with a stride, so the launch holds at most that many CUs while batches run --
+/// the walk kernel needs whole CUs, and a flood of short copy workgroups over all of them stalls it.
+__global__ void __launch_bounds__(256) k_copy_jobs_few(const CopyJob *__restrict__ jobs, uint32_t n_jobs)
+{
+  const uint32_t units = n_jobs * kCopyBlocksPerJob;
+  for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x)
+  {
+    const CopyJob job = jobs[unit / kCopyBlocksPerJob];
+    const uint32_t part = unit % kCopyBlocksPerJob;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(job.src) | reinterpret_cast<uintptr_t>(job.dst)) & 15u) == 0;
+    const uint64_t vectors = aligned ? job.bytes / 16u : 0u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(job.src);
+    uint4 *dst = reinterpret_cast<uint4 *>(job.dst);
+    for (uint64_t i = uint64_t(part) * 256u + threadIdx.x; i < vectors; i += uint64_t(kCopyBlocksPerJob) * 256u)
+    {
+      dst[i] = src[i];
+    }
+    if (part == 0)
+    {
+      for (uint64_t i = vectors * 16u + threadIdx.x; i < job.bytes; i += 256u)
+      {
+        job.dst[i] = job.src[i];
+      }
+    }
+  }
+}
+
 /// use[2 * index[i]] is touched with `stamp` (touchRegionUse)
 __global__ void k_touch_use_at(uint32_t *use, const uint32_t *__restrict__ index, size_t count, uint32_t stamp)
 {

@@ -250,6 +250,10 @@ try
   {
     m->writeback_off = std::atoi(env) == 0;
   }
+  if (const char *env = std::getenv("OHMHIP_WRITEBACK_WGS"))
+  {
+    m->writeback_workgroups = uint32_t(std::max(1, std::min(4096, std::atoi(env))));
+  }
   if (const char *env = std::getenv("OHMHIP_BIN_RAYS"))
   {
     m->bin_rays_per_block = uint32_t(std::max(128, std::min(int(kBinRaysPerBlock), std::atoi(env))));
@@ -334,13 +338,21 @@ try
   m->merge_keys_dev.release();
   m->merge_delta.release();
   m->merge_observers.release();
+  if (m->wb_stream)
+  {
+    (void)hipStreamSynchronize(m->wb_stream);
+    (void)hipStreamDestroy(m->wb_stream);
+  }
   if (m->h_use)
   {
     (void)hipHostFree(m->h_use);
   }
   for (auto &ring : m->wb_ring)
   {
-    ring.jobs.release();
+    if (ring.jobs_host)
+    {
+      (void)hipHostFree(ring.jobs_host);
+    }
     if (ring.done)
     {
       (void)hipEventDestroy(ring.done);
@@ -386,9 +398,9 @@ try
   {
     std::fprintf(stderr,
                  "[ohmhip spill] evictions %llu readmissions %llu | ms: select %.1f copy-out %.1f compact %.1f copy-in %.1f "
-                 "store-growth %.1f\n",
+                 "store-growth %.1f write-back scheduling (host) %.1f\n",
                  (unsigned long long)m->evictions, (unsigned long long)m->readmissions, m->spill_ms[0], m->spill_ms[1],
-                 m->spill_ms[2], m->spill_ms[3], m->spill_ms[5]);
+                 m->spill_ms[2], m->spill_ms[3], m->spill_ms[5], m->wb_host_ms);
   }
   freeHostStore(m);
   for (auto &sl : m->ray_slots)
@@ -736,6 +748,16 @@ try
   if (!m)
   {
     return OHMHIP_ERR_INVALID_ARG;
+  }
+  if (enable && m->spill_enabled)
+  {
+    // the copies the write-back keeps ahead of the evictions live in store records of their own: pinned here, not in
+    // the middle of a batch (up to half the pool, capped like the store's eager reservation)
+    const uint64_t per_region = bytesPerRegionAllLayers(m->config, m->mc.region_voxels);
+    const uint64_t pool_regions =
+      m->memory_limit ? std::min<uint64_t>(m->memory_limit / per_region, kMaxRegionSlots) : m->slot_capacity;
+    const uint64_t extra = std::min<uint64_t>(pool_regions / 2 + 64, (uint64_t(4) << 30) / std::max<uint64_t>(per_region, 1));
+    OHMHIP_CHECK(reserveStoreRecords(m, m->store.free_records.size() + size_t(extra)));
   }
   m->writeback_off = enable == 0;
   if (m->writeback_off)

@@ -147,9 +147,9 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
   const size_t rv = size_t(m->mc.region_voxels);
   const uint32_t hash_cap = nextPow2(std::max<uint32_t>(1024u, capacity * 2u));
   hipStream_t s = m->stream;
-  if (m->copy_stream && (!m->precleaned.empty() || !m->stale_records.empty()))
+  if (!m->precleaned.empty() || !m->stale_records.empty())
   {
-    OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));  // background write-back copies read the pool being replaced
+    OHMHIP_CHECK(drainWriteBack(m));  // background write-back copies read the pool being replaced
   }
 
   std::vector<void *> fresh;  // released again if any step fails

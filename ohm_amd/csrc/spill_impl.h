@@ -17,7 +17,7 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
   if (!m->precleaned.empty() || !m->stale_records.empty())
   {
     // background write-back copies read the slots that are about to move
-    OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
+    OHMHIP_CHECK(drainWriteBack(m));
   }
   int err = refreshHostRegionTable(m);
   if (err)
@@ -187,7 +187,16 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
   // The victims' content goes straight from the pool into pinned store records, all regions and layers by ONE kernel
   // that writes the mapped host memory itself (k_copy_jobs); the compute stream is idle here -- it was drained above.
   lap(0, t_mark);
-  OHMHIP_CHECK(reserveStoreRecords(m, k));
+  {
+    // records for the victims that do not have a valid pre-cleaned copy in the store already
+    uint32_t fresh = 0;
+    for (uint32_t v = 0; v < k; ++v)
+    {
+      const auto pre = m->precleaned.find(m->slot_keys_host[order[v]]);
+      fresh += (pre != m->precleaned.end() && pre->second.last_use == stamps[2 * size_t(order[v])]) ? 0u : 1u;
+    }
+    OHMHIP_CHECK(reserveStoreRecords(m, fresh));
+  }
   lap(5, t_mark);
   std::vector<int16_t> victim_keys(3 * size_t(k));
   std::vector<ohmhip_map_s::SpilledRegion> content(k);
@@ -250,7 +259,11 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
     }
   }
   {
-    const int err = int(hipStreamSynchronize(m->copy_stream));
+    int err = int(hipStreamSynchronize(m->copy_stream));
+    if (!err && !precleaned_used.empty())
+    {
+      err = drainWriteBack(m);  // (a pre-cleaned victim's record must be complete before it stands for the region)
+    }
     if (err)
     {
       giveBack();

@@ -100,6 +100,12 @@ void appendSlotToRecordJobs(ohmhip_map_t m, uint32_t slot, char *record, std::ve
   }
 }
 
+/// Wait for the write-back copies in flight (they read pool slots and write store records).
+int drainWriteBack(ohmhip_map_t m)
+{
+  return m->wb_stream ? int(hipStreamSynchronize(m->wb_stream)) : OHMHIP_OK;
+}
+
 /// Forget every pre-cleaned copy (the pool is about to be rebuilt, cleared or destroyed): waits for copies in flight.
 void dropPrecleaned(ohmhip_map_t m)
 {
@@ -107,7 +113,7 @@ void dropPrecleaned(ohmhip_map_t m)
   {
     return;
   }
-  (void)hipStreamSynchronize(m->copy_stream);
+  (void)drainWriteBack(m);
   for (auto &entry : m->precleaned)
   {
     releaseStoreRecord(m, entry.second.record);
@@ -121,7 +127,7 @@ void dropPrecleanedKey(ohmhip_map_t m, uint64_t key)
   const auto it = m->precleaned.find(key);
   if (it != m->precleaned.end())
   {
-    (void)hipStreamSynchronize(m->copy_stream);  // (its copy may still be in flight: the record goes back to the free list)
+    (void)drainWriteBack(m);  // (its copy may still be in flight: the record goes back to the free list)
     releaseStoreRecord(m, it->second.record);
     m->precleaned.erase(it);
   }
@@ -164,6 +170,12 @@ void scheduleWriteBack(ohmhip_map_t m, uint32_t now)
   {
     return;
   }
+  struct HostTimer
+  {
+    ohmhip_map_t m;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~HostTimer() { m->wb_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  } host_timer{ m };
   if (m->slot_keys_host.size() < m->h_use_slots && refreshHostRegionTable(m) != OHMHIP_OK)
   {
     return;
@@ -242,7 +254,7 @@ void scheduleWriteBack(ohmhip_map_t m, uint32_t now)
   }
   // records handed back by step 1 may still be written by an earlier copy kernel: recycle them only once the copy
   // stream has run dry
-  if (!m->stale_records.empty() && hipStreamQuery(m->copy_stream) == hipSuccess)
+  if (!m->stale_records.empty() && (!m->wb_stream || hipStreamQuery(m->wb_stream) == hipSuccess))
   {
     for (char *rec : m->stale_records)
     {
@@ -274,7 +286,16 @@ void scheduleWriteBack(ohmhip_map_t m, uint32_t now)
     return;
   }
   // behind the batch BEFORE the running one (the running one does not touch these regions; an earlier one may have)
-  hipStream_t cs = m->copy_stream;
+  if (!m->wb_stream && hipStreamCreateWithFlags(&m->wb_stream, hipStreamNonBlocking) != hipSuccess)
+  {
+    m->wb_stream = nullptr;
+    for (auto &t : taken)
+    {
+      releaseStoreRecord(m, t.second.record);
+    }
+    return;
+  }
+  hipStream_t cs = m->wb_stream;
   bool ok = true;
   if (m->batch_done_recorded[m->parity ^ 1u])
   {
@@ -282,15 +303,29 @@ void scheduleWriteBack(ohmhip_map_t m, uint32_t now)
   }
   if (ok)
   {
-    // (a blocking copy of a few KiB: the list is in device memory when the kernel is queued; the streams are
-    // non-blocking, so nothing else waits for it)
-    ok = ring.jobs.ensure(sizeof(CopyJob) * jobs.size(), false, cs) == OHMHIP_OK &&
-         hipMemcpy(ring.jobs.ptr, jobs.data(), sizeof(CopyJob) * jobs.size(), hipMemcpyHostToDevice) == hipSuccess;
+    const size_t bytes = sizeof(CopyJob) * jobs.size();
+    if (bytes > ring.capacity)
+    {
+      if (ring.jobs_host)
+      {
+        (void)hipHostFree(ring.jobs_host);  // (its last kernel has finished: checked above)
+        ring.jobs_host = ring.jobs_dev = nullptr;
+        ring.capacity = 0;
+      }
+      const size_t cap = std::max<size_t>(bytes + bytes / 2, size_t(1) << 16);
+      ok = hipHostMalloc(&ring.jobs_host, cap, hipHostMallocMapped) == hipSuccess &&
+           hipHostGetDevicePointer(&ring.jobs_dev, ring.jobs_host, 0) == hipSuccess;
+      ring.capacity = ok ? cap : 0;
+    }
+    if (ok)
+    {
+      std::memcpy(ring.jobs_host, jobs.data(), bytes);
+    }
   }
   if (ok)
   {
-    hipLaunchKernelGGL(k_copy_jobs, dim3(uint32_t(jobs.size()) * kCopyBlocksPerJob), dim3(256), 0, cs,
-                       static_cast<const CopyJob *>(ring.jobs.ptr), uint32_t(jobs.size()));
+    hipLaunchKernelGGL(k_copy_jobs_few, dim3(m->writeback_workgroups), dim3(256), 0, cs,
+                       static_cast<const CopyJob *>(ring.jobs_dev), uint32_t(jobs.size()));
     ok = hipGetLastError() == hipSuccess && hipEventRecord(ring.done, cs) == hipSuccess;
     ring.used = ok;
     ++m->wb_next;
