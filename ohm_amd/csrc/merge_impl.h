@@ -13,6 +13,7 @@ struct ohmhip_comm_s
   ncclComm_t comm = nullptr;
   int world = 1;
   int rank = 0;
+  int64_t *d_words = nullptr;    ///< [world + 2] small words of ohmhip_map_merge_replicas: counts, own count, status pair
   uint32_t *d_counts = nullptr;  ///< [world + world * world] scratch of ohmhip_comm_exchange_counts (partition_impl.h)
 };
 
@@ -140,6 +141,13 @@ try
     delete c;
     return err;
   }
+  if (hipMalloc(&c->d_words, sizeof(int64_t) * size_t(world_size + 2)) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    (void)ncclCommDestroy(c->comm);
+    delete c;
+    return OHMHIP_ERR_CAPACITY;
+  }
   *comm = c;
   return OHMHIP_OK;
 }
@@ -153,6 +161,10 @@ try
     if (comm->comm)
     {
       (void)ncclCommDestroy(comm->comm);
+    }
+    if (comm->d_words)
+    {
+      (void)hipFree(comm->d_words);
     }
     if (comm->d_counts)
     {
@@ -327,6 +339,17 @@ try
   }
   hipStream_t s = m->stream;
   const int world = comm->world;
+  // One-word agreement: 0 when the step succeeded on every rank.  Every rank calls it at the same points whatever
+  // happened locally (a rank that left early would leave its peers blocked in the next collective).
+  auto anyRankFailed = [&](int local_err, int32_t *any_failed) -> int {
+    int32_t *d_status = reinterpret_cast<int32_t *>(comm->d_words + world + 1);
+    const int32_t failed = local_err ? 1 : 0;
+    *any_failed = 0;
+    OHMHIP_CHECK(hipMemcpyAsync(d_status, &failed, sizeof(failed), hipMemcpyHostToDevice, s));
+    OHMHIP_CHECK(ncclStatus(ncclAllReduce(d_status, d_status + 1, 1, ncclInt32, ncclMax, comm->comm, s)));
+    OHMHIP_CHECK(hipMemcpyAsync(any_failed, d_status + 1, sizeof(*any_failed), hipMemcpyDeviceToHost, s));
+    return hipStreamSynchronize(s);
+  };
   // 1. this rank's pending regions.  A failure here does not leave the call: it travels as a negative count in the
   //    first collective, so that every rank returns together (a rank that returned early would leave its peers blocked).
   size_t n_local = 0;
@@ -340,9 +363,10 @@ try
   {
     n_local = 0;
   }
-  // 2. all-gather the key lists: counts first (one word per rank), then the lists padded to the longest.
-  OHMHIP_CHECK(m->merge_keys_dev.ensure(sizeof(int64_t) * size_t(world + 1), false, s));
-  int64_t *d_counts = static_cast<int64_t *>(m->merge_keys_dev.ptr);
+  // 2. all-gather the key lists: counts first (one word per rank), then the lists padded to the longest.  The small
+  //    words of this call live in the communicator's own scratch (allocated with it), so that no allocation -- nothing
+  //    that can fail on one rank alone -- sits between two collectives without the ranks agreeing on its outcome.
+  int64_t *d_counts = comm->d_words;
   const int64_t my_count = keys_err ? int64_t(-1) : int64_t(n_local);
   OHMHIP_CHECK(hipMemcpyAsync(d_counts + world, &my_count, sizeof(int64_t), hipMemcpyHostToDevice, s));
   OHMHIP_CHECK(ncclStatus(ncclAllGather(d_counts + world, d_counts, 1, ncclInt64, comm->comm, s)));
@@ -363,7 +387,13 @@ try
     {
       packed[i] = packSortable(&local_keys[3 * i]);
     }
-    OHMHIP_CHECK(m->merge_keys_dev.ensure(sizeof(int64_t) * longest * size_t(world + 1), false, s));
+    const int alloc_err = m->merge_keys_dev.ensure(sizeof(int64_t) * longest * size_t(world + 1), false, s);
+    int32_t alloc_failed = 0;
+    OHMHIP_CHECK(anyRankFailed(alloc_err, &alloc_failed));
+    if (alloc_failed)
+    {
+      return alloc_err ? alloc_err : OHMHIP_ERR_PEER;
+    }
     int64_t *d_all = static_cast<int64_t *>(m->merge_keys_dev.ptr);
     int64_t *d_mine = d_all + longest * size_t(world);
     OHMHIP_CHECK(hipMemcpyAsync(d_mine, packed.data(), sizeof(int64_t) * longest, hipMemcpyHostToDevice, s));
@@ -417,14 +447,8 @@ try
       local_err = ohmhip_map_merge_pack(m, shared_keys.data(), n_shared, d_delta, d_obs);
     }
   }
-  OHMHIP_CHECK(m->merge_keys_dev.ensure(sizeof(int64_t) * 2, true, s));
-  int32_t *d_status = static_cast<int32_t *>(m->merge_keys_dev.ptr);
-  const int32_t failed = local_err ? 1 : 0;
   int32_t any_failed = 0;
-  OHMHIP_CHECK(hipMemcpyAsync(d_status, &failed, sizeof(failed), hipMemcpyHostToDevice, s));
-  OHMHIP_CHECK(ncclStatus(ncclAllReduce(d_status, d_status + 1, 1, ncclInt32, ncclMax, comm->comm, s)));
-  OHMHIP_CHECK(hipMemcpyAsync(&any_failed, d_status + 1, sizeof(any_failed), hipMemcpyDeviceToHost, s));
-  OHMHIP_CHECK(hipStreamSynchronize(s));
+  OHMHIP_CHECK(anyRankFailed(local_err, &any_failed));
   if (any_failed)
   {
     return local_err ? local_err : OHMHIP_ERR_PEER;  // every rank leaves here together; nothing was applied
