@@ -265,7 +265,13 @@ int ohmhip_map_set_async_launch(ohmhip_map_t map, int enable);
  * the coalescing threshold are collected like small host batches (round 3): their arrays are copied device to device
  * behind the rays already waiting and run as one batch once min_rays have accumulated or anything observes the map.
  * With `integrated` non-NULL the call waits for that copy (it reports its own count from a filter pass over the copy),
- * so the caller's arrays are free when it returns; with NULL they must stay valid until the next ohmhip_map_sync. */
+ * so the caller's arrays are free when it returns; with NULL they must stay valid until the next ohmhip_map_sync.
+ * A call at or above the threshold is a device batch of its own and returns with that batch IN FLIGHT (its kernels read
+ * the arrays until it ends).  At most two batches are in flight: when any integrate call returns, every batch but the
+ * two launched last has completed (the map double-buffers its per-batch scratch and the set-up pass of a batch waits for
+ * the one before the previous).  So the arrays of a batch may be reused once the THIRD call after it is being made --
+ * three buffers used in turn never need a sync (ohm_amd/distributed.py, PartitionedIntegrator) -- or after
+ * ohmhip_map_sync. */
 int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, size_t element_count,
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
                                      size_t *integrated);
@@ -421,7 +427,8 @@ int ohmhip_region_owner(const int16_t *keys_xyz, size_t count, int block_shift, 
  * ray's index in the input, for callers that route side arrays (time stamps, intensities) themselves.  counts (host,
  * world_size entries) = rays per destination; *visits (may be NULL) = voxel visits of the input rays.  Returns
  * OHMHIP_ERR_CAPACITY -- with counts valid -- when d_routed holds fewer than sum(counts) rays: grow and repeat.
- * Synchronous.
+ * Synchronous, on a stream of its own: it reads nothing a batch writes, so it runs beside the batches in flight (the
+ * next batch is routed and exchanged while the previous one integrates).
  * ohmhip_comm_exchange_counts / _rays: the all-to-all of the routed rays over RCCL (both collective).  First the counts
  * (recv_counts[s] = rays rank s addressed to this rank), then, with d_recv holding sum(recv_counts) rays, the blocks:
  * on return (stream order) d_recv holds the rays addressed to this rank in source-rank order, ready for

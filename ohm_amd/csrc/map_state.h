@@ -210,6 +210,7 @@ struct ohmhip_map_s
     DevBuf table_dev, masks, block_counts, totals;
     uint32_t *h_totals = nullptr;      ///< pinned, device visible: rays per destination of the last routing
     uint32_t *h_totals_dev = nullptr;
+    hipStream_t route_stream = nullptr;  ///< routing runs beside the batches in flight: it reads no map state
   } partition;
   DevBuf use_scratch;  ///< (slot, stamp) pairs of re-admitted regions (queueReadmission)
   /// After how many batches the regions re-admitted lately came back (ring of the last 256): their median stands in as

@@ -362,6 +362,10 @@ try
   m->partition.masks.release();
   m->partition.block_counts.release();
   m->partition.totals.release();
+  if (m->partition.route_stream)
+  {
+    (void)hipStreamDestroy(m->partition.route_stream);
+  }
   if (m->partition.h_totals)
   {
     (void)hipHostFree(m->partition.h_totals);

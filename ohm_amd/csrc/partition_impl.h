@@ -352,7 +352,13 @@ try
                                hipHostMallocMapped));
     OHMHIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&ps.h_totals_dev), ps.h_totals, 0));
   }
-  hipStream_t s = m->stream;
+  // A stream of its own: routing reads the rays, the map's constants and the territory table -- nothing a batch writes --
+  // so the routing of the next batch runs beside the batches still in flight (the call itself stays synchronous).
+  if (!ps.route_stream)
+  {
+    OHMHIP_CHECK(hipStreamCreateWithFlags(&ps.route_stream, hipStreamNonBlocking));
+  }
+  hipStream_t s = ps.route_stream;
   const uint32_t n = uint32_t(ray_count);
   const uint32_t blocks = (n + kRouteThreads - 1) / kRouteThreads;
   OHMHIP_CHECK(ps.masks.ensure(sizeof(unsigned long long) * size_t(n), false, s));

@@ -518,27 +518,56 @@ class PartitionedIntegrator:
         self.comm = comm
         gpu_map.setRegionPartition(partition)
         self._routed = None
-        self._recv = None
-        self._stream = None
+        # A batch reads its rays until it ends and the map keeps two batches in flight (include/ohmhip.h,
+        # ohmhip_map_integrate_rays_device): three receive buffers used in turn are never written while a batch reads
+        # them, so a step does not wait for the previous one -- the next batch is routed (the library routes on a stream
+        # of its own) and exchanged while the previous one integrates.
+        self._recv = [None, None, None]
+        self._calls = 0
+        self._xstream = None
         self.last = {}
 
-    def _ensure(self, name, rays):
+    def close(self):
+        from . import _lib as L
+        if self._xstream is not None:
+            L.lib.ohmhip_stream_destroy(self._xstream)
+            self._xstream = None
+
+    def _exchange_stream(self):
+        import ctypes as C
+        from . import _lib as L
+        if self._xstream is None:
+            handle = L._vp()
+            L.check(L.lib.ohmhip_stream_create(C.byref(handle)), "stream_create")
+            self._xstream = handle
+        return self._xstream
+
+    def _ensure_routed(self, rays):
         import torch
-        t = getattr(self, name)
+        t = self._routed
         if t is None or t.shape[0] < rays:
             t = torch.empty((max(int(rays * 1.25) + 1024, 4096), 6), dtype=torch.float64, device="cuda")
-            setattr(self, name, t)
+            self._routed = t
+        return t
+
+    def _ensure_recv(self, slot, rays):
+        import torch
+        t = self._recv[slot]
+        if t is None or t.shape[0] < rays:
+            # (the batch that read the old buffer -- three calls ago -- has ended: it may go)
+            t = torch.empty((max(int(rays * 1.25) + 1024, 4096), 6), dtype=torch.float64, device="cuda")
+            self._recv[slot] = t
         return t
 
     def route(self, d_rays, n_rays, ray_update_flags=0):
         """Route `n_rays` rays at device pointer `d_rays`; returns (routed tensor, counts, visits)."""
-        routed = self._ensure("_routed", 2 * n_rays)
+        routed = self._ensure_routed(2 * n_rays)
         while True:
             counts, visits, fits = self.gpu_map.routeRays(d_rays, n_rays, routed.data_ptr(), routed.shape[0],
                                                           ray_update_flags)
             if fits:
                 return routed, counts, visits
-            routed = self._ensure("_routed", int(counts.sum()))
+            routed = self._ensure_routed(int(counts.sum()))
 
     def integrateRays(self, local_rays, ray_update_flags=0):
         """local_rays: (2N, 3) float64 CUDA tensor (origin, sample pairs).  Collective.  Returns the number of points
@@ -550,24 +579,27 @@ class PartitionedIntegrator:
         return self.integrateRaysDevice(local.data_ptr(), 2 * local.shape[0], ray_update_flags)
 
     def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=0):
-        """The same for a raw device pointer to element_count dvec3 (complete when the call is made)."""
+        """The same for a raw device pointer to element_count dvec3 (complete when the call is made; free again when the
+        call returns).  The batch the call launches is left in flight: GpuMap.wait() / syncVoxels() settle it."""
         import torch
         from . import _lib as L
         gm = self.gpu_map
         n_local = int(element_count) // 2
-        gm.wait()  # the previous batch may still read the receive buffer
+        slot = self._calls % 3
+        self._calls += 1
         routed, counts, visits = self.route(d_rays_ptr, n_local, ray_update_flags)
         sent = int(counts.sum())
         if self.comm is not None:
+            xs = self._exchange_stream()
             send_counts = np.ascontiguousarray(counts, dtype=np.uint32)
             recv_counts = np.zeros_like(send_counts)
             L.check(L.lib.ohmhip_comm_exchange_counts(self.comm._handle, send_counts.ctypes.data,
-                                                      recv_counts.ctypes.data, None), "exchange_counts")
+                                                      recv_counts.ctypes.data, xs), "exchange_counts")
             n_recv = int(recv_counts.sum())
-            recv = self._ensure("_recv", n_recv)
+            recv = self._ensure_recv(slot, n_recv)
             L.check(L.lib.ohmhip_comm_exchange_rays(self.comm._handle, routed.data_ptr(), send_counts.ctypes.data,
-                                                    recv.data_ptr(), recv_counts.ctypes.data, None), "exchange_rays")
-            L.check(L.lib.ohmhip_device_synchronize(), "device_synchronize")
+                                                    recv.data_ptr(), recv_counts.ctypes.data, xs), "exchange_rays")
+            L.check(L.lib.ohmhip_stream_finish(xs), "stream_finish")  # (not the device: batches stay in flight)
             recv_counts = [int(c) for c in recv_counts]
         else:
             import torch.distributed as dist
@@ -575,13 +607,13 @@ class PartitionedIntegrator:
             if dist.get_backend(self.group) == "gloo":
                 got, recv_counts = exchange_routed_rays(block.cpu(), counts, self.group)
                 n_recv = got.shape[0]
-                recv = self._ensure("_recv", n_recv)
+                recv = self._ensure_recv(slot, n_recv)
                 recv[:n_recv].copy_(got)
             else:
                 got, recv_counts = exchange_routed_rays(block, counts, self.group)
                 n_recv = got.shape[0]
                 recv = got
-                self._recv = got  # stays alive while the batch reads it
+                self._recv[slot] = got  # stays alive while the batch reads it
             torch.cuda.current_stream().synchronize()
         self.last = {"rays_local": n_local, "rays_routed": sent, "rays_kept": int(counts[self.partition.rank]),
                      "rays_received": n_recv, "recv_counts": recv_counts, "visits_local": visits}
@@ -656,6 +688,49 @@ def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timin
         else:
             integrated.append(0)
     return {"routed": matrix, "received": matrix.sum(axis=0), "integrated": integrated, "visits_local": visits}
+
+
+def pipelined_rank_step_ms(gpu_map, shard, received, steps=8, warmup=2, ray_update_flags=0):
+    """Steady-state time of ONE rank's step without the exchange, on this GPU (bench.py's one-GPU C4 leg): the rank's
+    shard is routed (library kernels on the routing stream, host-synchronised as in PartitionedIntegrator) and the stream
+    it receives -- `received`, (k, 6) host rays, the same every step here -- is integrated, steps back to back with the
+    batches left in flight exactly as PartitionedIntegrator leaves them.  Returns milliseconds per step."""
+    import ctypes as C
+    import time
+    from . import _lib as L
+    shard = np.ascontiguousarray(shard, dtype=np.float64).reshape(-1, 6)
+    received = np.ascontiguousarray(received, dtype=np.float64).reshape(-1, 6)
+    bufs = []
+
+    def device_copy(arr, extra=0):
+        buf, ptr = L._vp(), L._vp()
+        L.check(L.lib.ohmhip_buffer_create(C.byref(buf), max(arr.nbytes + extra, 48), 3), "buffer_create")
+        if arr.nbytes:
+            L.check(L.lib.ohmhip_buffer_write(buf, arr.ctypes.data, arr.nbytes, 0, None, None, None), "buffer_write")
+        L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(ptr)), "buffer_ptr")
+        bufs.append(buf)
+        return ptr
+
+    d_src = device_copy(shard)
+    d_recv = device_copy(received)  # read-only here: no buffer rotation needed
+    cap = 2 * shard.shape[0] + 1024
+    d_out = device_copy(np.zeros((0, 6)), extra=48 * cap)
+    try:
+        t0 = 0.0
+        for i in range(warmup + steps):
+            if i == warmup:
+                gpu_map.wait()
+                t0 = time.perf_counter()
+            _, _, fits = gpu_map.routeRays(d_src, shard.shape[0], d_out, cap, ray_update_flags)
+            if not fits:
+                raise RuntimeError("routing buffer too small")
+            if received.shape[0]:
+                gpu_map.integrateRaysDevice(d_recv, 2 * received.shape[0], ray_update_flags)
+        gpu_map.wait()
+        return 1e3 * (time.perf_counter() - t0) / steps
+    finally:
+        for b in bufs:
+            L.lib.ohmhip_buffer_destroy(b)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -87,6 +87,26 @@ def main():
             gm3.syncVoxels()
             for key, layers in om2.chunks().items():
                 assert np.array_equal(map3.chunks[key]["occupancy"].view(np.uint32), layers["occupancy"].view(np.uint32))
+            # Batches left in flight (no wait between steps; every step its own device batch with rays of its own): the
+            # three receive buffers used in turn are never written under a batch that still reads them.
+            map4, map5 = OccupancyMap(0.1), OccupancyMap(0.1)
+            gm4, gm5 = GpuMap(map4), GpuMap(map5)
+            pin4 = D.PartitionedIntegrator(gm4, part, comm=comm3)
+            steps = [torch.from_numpy(synth.rays_c1(n=90000 + 7000 * k, seed=50 + k, first=40000 * k)).cuda()
+                     for k in range(7)]
+            for t in steps:
+                assert pin4.integrateRays(t) == t.shape[0]
+            for t in steps:
+                gm5.integrateRays(t.cpu().numpy())
+            gm4.syncVoxels()
+            gm5.syncVoxels()
+            assert set(map4.chunks) == set(map5.chunks)
+            for key, layers in map5.chunks.items():
+                assert np.array_equal(map4.chunks[key]["occupancy"].view(np.uint32), layers["occupancy"].view(np.uint32))
+            pin4.close()
+            pinteg.close()
+            gm4.close()
+            gm5.close()
             if comm3 is not None:
                 comm3.close()
             gm3.close()
