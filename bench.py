@@ -574,13 +574,13 @@ def main():
                         "re-admission (pinned host store; one device kernel per eviction / re-admission moves all "
                         "regions over PCIe, synchronous with the batch)"}
             g4.close()
-            # "map >> cache": the same sweep against a quarter of that budget -- 256 MiB hold 612 of the map's 4 465
-            # regions (7.3 x oversubscribed) -- in 128 sectors (a batch must fit the pool on its own)
+            # "map >> cache": the same sweep against an eighth of that budget -- 128 MiB hold 335 of the map's 4 465
+            # regions (13 x oversubscribed) -- in 256 sectors (a batch must fit the pool on its own)
             m5 = ohm_amd.OccupancyMap(0.05, (32, 32, 32), layers=("tsdf",))
             g5 = ohm_amd.GpuTsdfMap(m5, region_capacity=256)
-            g5.setMemoryLimit(256 << 20)
+            g5.setMemoryLimit(128 << 20)
             g5.setSpillToHost(True)
-            sectors5 = 128
+            sectors5 = 256
             per5 = (r4.shape[0] // 2) // sectors5
             t1 = time.perf_counter()
             done5 = 0
@@ -590,14 +590,14 @@ def main():
             dt5 = time.perf_counter() - t1
             cs5 = g5.cacheStats()
             total5 = int(cs5["regions_resident"]) + int(cs5["regions_spilled"])
-            extra["C3_tsdf_cache_stress_256MiB"] = {
+            extra["C3_tsdf_cache_stress_128MiB"] = {
                 "rays_per_s": (done5 // 2) / dt5, "seconds": dt5, "rays": done5 // 2, "calls": sectors5,
                 "memory_limit_bytes": int(cs5["memory_limit"]), "regions_resident": int(cs5["regions_resident"]),
                 "regions_in_host_store": int(cs5["regions_spilled"]),
                 "oversubscription": total5 / max(1.0, cs5["memory_limit"] / cs5["bytes_per_region"]),
                 "evictions": int(cs5["evictions"]), "readmissions": int(cs5["readmissions"]),
                 "bytes_over_pcie": int((cs5["evictions"] + cs5["readmissions"]) * (8 * 32 ** 3 + 4096)),  # TSDF block + mask row
-                "note": "every region leaves and returns about three times per revolution: the leg is bound by the "
+                "note": "regions resident / regions of the map = 1 / oversubscription (>= 8 asked for by the round-3 review); every region leaves and returns about three times per revolution: the leg is bound by the "
                         "PCIe traffic of the moves (one device kernel per eviction / re-admission, synchronous with "
                         "the batch; the opt-in background write-back -- ohmhip_map_set_spill_writeback -- takes "
                         "copy-outs off that path but was measured slower here, DESIGN.md 3)"}
