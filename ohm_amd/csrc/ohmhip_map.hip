@@ -822,6 +822,9 @@ try
   }
   if (count)
   {
+    // (the caller rewrote these slots behind the library's back: no use stamp moved, so the background write-back's
+    // copies cannot tell -- all of them are void)
+    dropPrecleaned(m);
     OHMHIP_CHECK(m->merge_slots.ensure(sizeof(uint32_t) * count, false, m->stream));
     OHMHIP_CHECK(hipMemcpyAsync(m->merge_slots.ptr, slots, sizeof(uint32_t) * count, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(k_or_at_u32, dim3(64), dim3(256), 0, m->stream, m->d_dirty,

@@ -109,7 +109,7 @@ int drainWriteBack(ohmhip_map_t m)
 /// Forget every pre-cleaned copy (the pool is about to be rebuilt, cleared or destroyed): waits for copies in flight.
 void dropPrecleaned(ohmhip_map_t m)
 {
-  if (m->precleaned.empty())
+  if (m->precleaned.empty() && m->stale_records.empty())
   {
     return;
   }
@@ -119,6 +119,11 @@ void dropPrecleaned(ohmhip_map_t m)
     releaseStoreRecord(m, entry.second.record);
   }
   m->precleaned.clear();
+  for (char *rec : m->stale_records)  // (no copy is in flight any more: discarded copies' records are free again)
+  {
+    releaseStoreRecord(m, rec);
+  }
+  m->stale_records.clear();
 }
 
 /// The pre-cleaned copy of one region is void (an upload rewrote the region, or it left the map).
