@@ -1114,6 +1114,133 @@ private:
   std::vector<Key> intersected_voxels_;
 };
 
+/// Not in the reference (ohm is single device): the RCCL communicator the library owns (include/ohmhip.h, ohmhip_comm_*).
+/// Rank 0 makes the id (uniqueId) and the host program carries its 128 bytes to the other ranks over whatever it has
+/// (MPI, a socket, a file); every rank then constructs its communicator -- a collective call.
+class RayCommunicator
+{
+public:
+  static std::array<unsigned char, OHMHIP_COMM_ID_BYTES> uniqueId()
+  {
+    std::array<unsigned char, OHMHIP_COMM_ID_BYTES> id{};
+    OHMHIP_GPUAPICHECK(ohmhip_comm_unique_id(id.data()));
+    return id;
+  }
+  RayCommunicator(const std::array<unsigned char, OHMHIP_COMM_ID_BYTES> &id, int world_size, int rank)
+    : world_(world_size)
+    , rank_(rank)
+  {
+    OHMHIP_GPUAPICHECK(ohmhip_comm_init_rank(&handle_, id.data(), world_size, rank));
+  }
+  RayCommunicator(const RayCommunicator &) = delete;
+  RayCommunicator &operator=(const RayCommunicator &) = delete;
+  ~RayCommunicator()
+  {
+    if (handle_)
+    {
+      ohmhip_comm_destroy(handle_);
+    }
+  }
+  ohmhip_comm_t handle() const { return handle_; }
+  int worldSize() const { return world_; }
+  int rank() const { return rank_; }
+
+private:
+  ohmhip_comm_t handle_ = nullptr;
+  int world_ = 1;
+  int rank_ = 0;
+};
+
+/// Not in the reference: exact multi-GPU integration into a region-partitioned map (include/ohmhip.h "Partitioned map";
+/// the C++ face of ohm_amd.distributed.PartitionedIntegrator).  Every rank constructs one around its EMPTY GpuMap with the
+/// same territory table and calls integrateRays() with its own rays, all ranks the same number of times: the rays are
+/// routed on the device to the owners of the regions they cross, exchanged over RCCL (48 B per routed ray) and what
+/// arrives is integrated in (source rank, ray) order.  The union of the ranks' maps is bit-identical to one map
+/// integrating rank 0's batch, then rank 1's, ...  The batch a call launches stays in flight; three receive buffers are
+/// used in turn because the map keeps at most two batches in flight (ohmhip_map_integrate_rays_device).
+class PartitionedIntegrator
+{
+public:
+  PartitionedIntegrator(GpuMap &gpu_map, const GpuMap::RegionPartition &partition, RayCommunicator &comm)
+    : map_(gpu_map)
+    , comm_(comm)
+    , exchange_queue_(gputil::Queue::create())
+  {
+    map_.setRegionPartition(partition);
+  }
+
+  /// Collective.  @p device_rays: this rank's rays (origin, sample pairs; element_count points), complete when the call
+  /// is made and free again when it returns.  Returns the points this rank integrated (its own and received rays that
+  /// pass the ray filter), 0 on failure (lastStatus()).
+  size_t integrateRays(const gputil::Buffer &device_rays, size_t element_count, unsigned ray_update_flags = kRfDefault)
+  {
+    const int world = comm_.worldSize();
+    send_counts_.assign(size_t(world), 0u);
+    recv_counts_.assign(size_t(world), 0u);
+    if (element_count >= 2 && device_rays.isValid())
+    {
+      map_.routeRays(device_rays, element_count, ray_update_flags, routed_, send_counts_);
+    }
+    last_status_ = ohmhip_comm_exchange_counts(comm_.handle(), send_counts_.data(), recv_counts_.data(),
+                                               exchange_queue_.handle());
+    if (last_status_ != OHMHIP_OK)
+    {
+      return 0;
+    }
+    size_t n_in = 0;
+    for (uint32_t c : recv_counts_)
+    {
+      n_in += c;
+    }
+    gputil::Buffer &in = recv_[calls_++ % 3];
+    const size_t in_bytes = std::max<size_t>(n_in, 1) * 6 * sizeof(double);
+    if (!in.isValid())
+    {
+      in.create(in_bytes + in_bytes / 4);
+    }
+    else if (in.size() < in_bytes)
+    {
+      in.resize(in_bytes + in_bytes / 4);  // (the batch that read it -- three calls ago -- has ended)
+    }
+    void *d_routed = nullptr, *d_in = nullptr;
+    if (routed_.isValid())
+    {
+      OHMHIP_GPUAPICHECK(ohmhip_buffer_ptr(routed_.handle(), &d_routed));
+    }
+    OHMHIP_GPUAPICHECK(ohmhip_buffer_ptr(in.handle(), &d_in));
+    last_status_ = ohmhip_comm_exchange_rays(comm_.handle(), static_cast<const double *>(d_routed), send_counts_.data(),
+                                             static_cast<double *>(d_in), recv_counts_.data(), exchange_queue_.handle());
+    if (last_status_ != OHMHIP_OK)
+    {
+      return 0;
+    }
+    exchange_queue_.finish();  // the exchange only: the batches in flight stay in flight
+    rays_received_ = n_in;
+    if (n_in == 0)
+    {
+      return 0;
+    }
+    const size_t done = map_.integrateRays(in, 2 * n_in, ray_update_flags);
+    last_status_ = map_.lastStatus();
+    return done;
+  }
+
+  size_t raysReceived() const { return rays_received_; }
+  const std::vector<uint32_t> &sendCounts() const { return send_counts_; }
+  const std::vector<uint32_t> &receiveCounts() const { return recv_counts_; }
+  int lastStatus() const { return last_status_; }
+
+private:
+  GpuMap &map_;
+  RayCommunicator &comm_;
+  gputil::Queue exchange_queue_;
+  gputil::Buffer routed_, recv_[3];
+  std::vector<uint32_t> send_counts_, recv_counts_;
+  size_t calls_ = 0;
+  size_t rays_received_ = 0;
+  int last_status_ = OHMHIP_OK;
+};
+
 /// ohm::configureGpu / gpuDevice (ohmgpu/OhmGpu.h:40-66): select the process-wide device.
 inline int configureGpu(int device_index = 0)
 {

@@ -143,7 +143,7 @@ int main(int argc, char **argv)
     ohm::OccupancyMap map(resolution);
     std::unique_ptr<ohm::GpuMap> gpu_map;
     if (mode == "occ" || mode == "occmean" || mode == "occdev" || mode == "occcoalesce" || mode == "occowner" ||
-        mode == "occclipbox" || mode == "occpart")
+        mode == "occclipbox" || mode == "occpart" || mode == "occpartint")
     {
       if (mode == "occmean")
       {
@@ -222,6 +222,32 @@ int main(int argc, char **argv)
         const unsigned elements = transform.transform(times, translations, rotations, 2, sample_times.data(),
                                                       samples.data(), unsigned(samples.size()), queue, device_rays);
         total += gpu_map->integrateRays(device_rays, elements, ohm::kRfDefault);
+      }
+    }
+    else if (mode == "occpartint")
+    {
+      // ohm::PartitionedIntegrator at world size 1 over the library's own RCCL communicator: every batch is routed on
+      // the device, exchanged (count all-gather + the block a rank addresses to itself) and integrated with the previous
+      // batches still in flight -- each batch from a device buffer of its own, rewritten without any wait in between.
+      const auto id = ohm::RayCommunicator::uniqueId();
+      ohm::RayCommunicator comm(id, 1, 0);
+      ohm::GpuMap::RegionPartition whole;  // world size 1: everything belongs to rank 0
+      ohm::PartitionedIntegrator integrator(*gpu_map, whole, comm);
+      gputil::Buffer device_rays;
+      for (size_t i = 0; i < n_points; i += batch_points)
+      {
+        const size_t count = std::min<size_t>(batch_points, n_points - i);
+        if (!device_rays.isValid())
+        {
+          device_rays.create(batch_points * sizeof(ohm::dvec3));
+        }
+        device_rays.write(rays.data() + i, count * sizeof(ohm::dvec3));  // (free again when integrateRays returned)
+        const size_t done = integrator.integrateRays(device_rays, count, ohm::kRfDefault);
+        if (integrator.lastStatus() != OHMHIP_OK || integrator.raysReceived() * 2 != integrator.sendCounts()[0] * 2)
+        {
+          return 12;
+        }
+        total += done;
       }
     }
     else if (mode == "occpart")

@@ -154,6 +154,19 @@ def test_cpp_region_partition_and_ray_routing(gpu):
     assert_parity(compare_maps({k: expect[k] for k in mine}, owned, ["occupancy"], exact_float=True))
 
 
+def test_cpp_partitioned_integrator_keeps_batches_in_flight(gpu):
+    """ohm::PartitionedIntegrator + ohm::RayCommunicator (ohm_amd/host/OhmGpuMap.h) at world size 1: routing kernels, the
+    library's RCCL exchange and the integration of what arrives, batch after batch without a wait -- the caller's ray
+    buffer is rewritten as soon as a call returns, the receive buffers rotate.  Batches of 70 000 rays: each is a device
+    batch of its own (above the coalescing threshold), so two are in flight while the third is being routed."""
+    rays = synth.rays_c1(n=420000, max_range=14.0, seed=61)
+    om = OracleMap(0.1, layers=("occupancy",))
+    for i in range(0, rays.shape[0], 2 * 70000):
+        om.integrate_occupancy(rays[i:i + 2 * 70000])
+    got = run_driver("occpartint", 0.1, 70000, rays, 1)
+    assert_parity(compare_maps(om.chunks(), got, ["occupancy"], exact_float=True))
+
+
 def test_cpp_set_ray_filter_clip_box(gpu):
     """GpuMap::setRayFilter with a RayFilterFunction wrapping clipBounded, as GpuMap.ClipBox does
     (tests/ohmtestgpu/GpuMapTest.cpp:633-647): the C++ mirror's Aabb / clipBounded against the numpy restatement."""
