@@ -364,13 +364,14 @@ int tiledWriteRegions(ohmhip_map_t m, int layer_id, const int16_t *keys_xyz, siz
 int tiledRemoveRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed);
 }  // namespace
 
-// Defined further down (they use the region read / remove machinery of the C ABI section).
-int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed);
-int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict = 0xffffffffu);
-int makeRoomForNamedRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count);
-int growPoolForNamedRegions(ohmhip_map_t m, uint32_t total, uint32_t keep);
-int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot);
-int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count);
+// Defined further down (they use the region read / remove machinery of the C ABI section).  Internal linkage: the
+// shared library exports the C ABI of include/ohmhip.h and nothing else (tests/test_cabi.py).
+static int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed);
+static int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict = 0xffffffffu);
+static int makeRoomForNamedRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count);
+static int growPoolForNamedRegions(ohmhip_map_t m, uint32_t total, uint32_t keep);
+static int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot);
+static int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count);
 
 
 #endif  // OHMHIP_MAP_STATE_H

@@ -6,7 +6,7 @@
 #define OHMHIP_SPILL_IMPL_H
 
 /// Drop resident regions from the pool (ohmhip_map_remove_regions; also the second half of an eviction).
-int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed)
+static int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count, size_t *removed)
 {
   if (removed)
   {
@@ -149,7 +149,7 @@ int removeResidentRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count,
 /// Regions the current batch attempt touched carry the newest stamp (k_plan) and go last.
 #include "writeback_impl.h"
 
-int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
+static int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
 {
   const auto t_begin = std::chrono::steady_clock::now();
   auto lap = [&](int slot, std::chrono::steady_clock::time_point &from) {
@@ -306,7 +306,7 @@ int evictColdRegions(ohmhip_map_t m, uint32_t want_free, uint32_t max_evict)
 
 /// Pool growth on behalf of regions created by name (ohmhip_map_write_regions / ohmhip_map_ensure_regions): the same
 /// budget rules as a batch's growth (rollbackAndGrow) -- the map's memory limit and the device's free memory.
-int growPoolForNamedRegions(ohmhip_map_t m, uint32_t total, uint32_t keep)
+static int growPoolForNamedRegions(ohmhip_map_t m, uint32_t total, uint32_t keep)
 {
   uint32_t cap = 0;
   if (!grownCapacity(m->slot_capacity, total, cap))
@@ -336,7 +336,7 @@ int growPoolForNamedRegions(ohmhip_map_t m, uint32_t total, uint32_t keep)
 /// Before regions are created by name under a memory limit: if the named keys that are not resident yet would push the
 /// pool past the limit, the least recently used OTHER regions go to the host store first (spill to host) -- or the
 /// call fails with OHMHIP_ERR_CAPACITY and changes nothing.
-int makeRoomForNamedRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count)
+static int makeRoomForNamedRegions(ohmhip_map_t m, const int16_t *keys_xyz, size_t count)
 {
   if (!m->memory_limit || count == 0)
   {
@@ -468,7 +468,7 @@ int queueReadmission(ohmhip_map_t m, const std::vector<std::pair<uint32_t, ohmhi
 /// Spill to host, second half: a batch's set-up pass has just created the slots [first_slot, end_slot); those whose key
 /// is in the host store get their content back before anything reads or updates the layers.  Entries leave the store
 /// only once their content is safely back in the pool (a failure on the way must not lose a region).
-int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot)
+static int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot)
 {
   if (m->spilled.empty() || end_slot <= first_slot)
   {
@@ -514,7 +514,7 @@ int readmitSpilledSlots(ohmhip_map_t m, uint32_t first_slot, uint32_t end_slot)
 
 /// Bring stored regions back for an upload / a caller that wants their slots (ohmhip_map_write_regions,
 /// ohmhip_map_ensure_regions): afterwards the keys are ordinary resident regions.
-int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count)
+static int readmitSpilledKeys(ohmhip_map_t m, const int16_t *keys_xyz, size_t count)
 {
   if (m->spilled.empty())
   {
