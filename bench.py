@@ -457,6 +457,7 @@ def main():
                 "note": "union of the ranks' territories after ONE batch per rank vs one map integrating the shards of "
                         "all ranks in rank order: every count but the first three must be 0 (bit-identical)"}
             sg.close()
+            dinteg.close()
             dg.close()
         except Exception as exc:
             out["multi_gpu"]["deviation"] = {"error": repr(exc)}
@@ -953,6 +954,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     L.lib.ohmhip_buffer_destroy(buf)
+    if integ is not None:
+        integ.close()
     if comm is not None:
         comm.close()
     gm.close()
