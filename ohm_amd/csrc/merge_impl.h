@@ -141,8 +141,15 @@ try
     delete c;
     return err;
   }
-  if (hipMalloc(&c->d_words, sizeof(int64_t) * size_t(world_size + 2)) != hipSuccess)
+  // (the small device words of the collectives are allocated here, with the communicator: an allocation that fails on
+  // one rank in the middle of a collective call would leave its peers blocked)
+  if (hipMalloc(&c->d_words, sizeof(int64_t) * size_t(world_size + 2)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&c->d_counts), sizeof(uint32_t) * size_t(world_size) * size_t(world_size + 1)) != hipSuccess)
   {
+    if (c->d_words)
+    {
+      (void)hipFree(c->d_words);
+    }
     (void)hipGetLastError();
     (void)ncclCommDestroy(c->comm);
     delete c;

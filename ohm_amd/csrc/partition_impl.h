@@ -408,10 +408,6 @@ try
   }
   const int world = comm->world;
   hipStream_t s = stream ? stream->stream : nullptr;
-  if (!comm->d_counts)
-  {
-    OHMHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&comm->d_counts), sizeof(uint32_t) * size_t(world) * size_t(world + 1)));
-  }
   uint32_t *row = comm->d_counts;
   uint32_t *matrix = comm->d_counts + world;
   OHMHIP_CHECK(hipMemcpyAsync(row, send_counts, sizeof(uint32_t) * world, hipMemcpyHostToDevice, s));
