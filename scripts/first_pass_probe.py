@@ -1,0 +1,16 @@
+import sys, time, ctypes as C
+sys.path.insert(0, '.')
+import ohm_amd
+from ohm_amd import _lib as L, synth
+rays = synth.rays_c1(n=1_000_000)
+buf = L._vp(); L.check(L.lib.ohmhip_buffer_create(C.byref(buf), rays.nbytes, 3)); L.check(L.lib.ohmhip_buffer_write(buf, rays.ctypes.data, rays.nbytes, 0, None, None, None))
+p = L._vp(); L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(p)))
+for rep in range(2):
+    m = ohm_amd.OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    g = ohm_amd.GpuMap(m, gpu_mem_size=8 << 30)
+    g.wait()
+    for k in range(3):
+        t0 = time.perf_counter(); g.integrateRaysDevice(p, rays.shape[0]); g.wait(); dt = time.perf_counter() - t0
+        bt = g.batchTimings(0)
+        print("rep %d pass %d  host %.3f ms  device total %.3f setup %.3f walk %.3f apply %.3f" % (rep, k, dt * 1e3, bt["ms_total"], bt["ms_setup"], bt["ms_walk"], bt["ms_apply"]))
+    g.close()
