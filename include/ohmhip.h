@@ -269,9 +269,10 @@ int ohmhip_map_set_async_launch(ohmhip_map_t map, int enable);
  * A call at or above the threshold is a device batch of its own and returns with that batch IN FLIGHT (its kernels read
  * the arrays until it ends).  At most two batches are in flight: when any integrate call returns, every batch but the
  * two launched last has completed (the map double-buffers its per-batch scratch and the set-up pass of a batch waits for
- * the one before the previous).  So the arrays of a batch may be reused once the THIRD call after it is being made --
- * three buffers used in turn never need a sync (ohm_amd/distributed.py, PartitionedIntegrator) -- or after
- * ohmhip_map_sync. */
+ * the one before the previous).  So the arrays of a batch may be reused once two further batches have been LAUNCHED and
+ * the call that launched the second has returned -- three buffers used in turn, advanced per launch
+ * (ohmhip_map_batches_launched; a call that launches nothing must not advance the turn), never need a sync
+ * (ohm_amd/distributed.py, PartitionedIntegrator) -- or after ohmhip_map_sync. */
 int ohmhip_map_integrate_rays_device(ohmhip_map_t map, const double *d_rays, size_t element_count,
                                      const float *d_intensities, const double *d_timestamps, unsigned ray_flags,
                                      size_t *integrated);
@@ -339,6 +340,22 @@ int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);
  * hipEvents on the map's streams (the gputil::Event / Queue::mark() bookkeeping of ohmgpu/GpuMap.cpp:1036-1191 serves
  * the same purpose); waits for that batch only.  Lets a caller time a run of batches without synchronising after each. */
 int ohmhip_map_batch_timings(ohmhip_map_t map, uint32_t batches_back, float ms[4]);
+/* What the phase times are read from (round 5).  The end of a batch's binning, sample ordering, walk and apply phases and
+ * of its plan are the STOP EVENTS of the kernels themselves (hipExtLaunchKernelGGL: bound to the kernel's completion
+ * signal, free), so ms[0] (as the interval between consecutive batches' ends; for a batch on its own: plan end -> batch
+ * end), ms[2] (end of the kernel before the walk -> end of the walk kernel, on the stream it runs on) and ms[3] are
+ * always available.  The START of the set-up pass and of the binning pass have no kernel in front of them to carry an
+ * event: they are hipEventRecord markers, and a marker idles the queue for 3-7 us before the next kernel
+ * (scripts/probes/event_probe.hip) -- round 4 paid eight of them per batch, 5 % of a C1 batch.  They are therefore
+ * recorded only with phase timing on (this call, OHMHIP_PHASE_TIMING=1): ms[1], and ms[0] of a batch on its own as first
+ * kernel start -> last kernel end, need it and read 0 / the shorter span otherwise.  Default: off. */
+int ohmhip_map_set_phase_timing(ohmhip_map_t map, int enable);
+/* Device batches the map has launched since it was created.  An integrate call that only collects its rays (batch
+ * coalescing) or is rejected launches none: callers that recycle device ray buffers by the "two batches in flight" rule
+ * of ohmhip_map_integrate_rays_device count LAUNCHES with this, not calls -- a buffer handed to the call that made the
+ * count L is free once the count has reached L + 2 and a later integrate call has returned (or after ohmhip_map_sync).
+ * Does not flush collected rays. */
+int ohmhip_map_batches_launched(ohmhip_map_t map, uint64_t *count);
 
 /* Region table (replaces GpuLayerCache::lookup, ohmgpu/GpuLayerCache.cpp:104-119). keys = int16 xyz triples. */
 int ohmhip_map_region_count(ohmhip_map_t map, size_t *count);

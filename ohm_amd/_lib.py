@@ -135,6 +135,8 @@ _sigs = {
     "ohmhip_transform_samples": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_double, _vp, _vp,
                                            C.POINTER(C.c_uint32)]),
     "ohmhip_map_batch_timings": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_float)]),
+    "ohmhip_map_set_phase_timing": (C.c_int, [_vp, C.c_int]),
+    "ohmhip_map_batches_launched": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ohmhip_map_line_keys": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
     "ohmhip_map_device_layer_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "ohmhip_map_region_slot": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),

@@ -28,6 +28,7 @@ struct BatchRun
   unsigned ray_flags;
   hipStream_t s, f;
   hipEvent_t *tev;
+  uint32_t ring;  ///< this batch's entry of the timing ring
   // decided once per call
   uint32_t next_info_index = 0;
   bool info_clean = false;
@@ -47,12 +48,18 @@ struct BatchRun
   uint32_t event_capacity = 0, n_events = 0;
   float *direct_occ = nullptr;
   uint32_t direct_segments = 0;
+  bool batch_end_marked = false;  ///< tev[4] is the stop event of the batch's last kernel already
+
+  /// The batch recorded (or bound to a kernel) event k of its ring entry.
+  void mark(int k) { m->tev_mask[ring] = uint8_t(m->tev_mask[ring] | (1u << k)); }
 
   int prepare()
   {
     // This batch's summary block: the next of the three, zeroed by the previous batch's k_plan if that ran.  (Three: the
     // set-up pass of this batch runs under the previous batch's apply kernels, which still read theirs, and zeroes the
     // following batch's.)
+    m->tev_mask[ring] = 0;
+    m->tev_pre_walk[ring] = 0;
     m->info_index = (m->info_index + 1u) % 3u;
     next_info_index = (m->info_index + 1u) % 3u;
     info_clean = m->info_clean;
@@ -130,29 +137,35 @@ struct BatchRun
   void launchBin(bool bucket, uint32_t seg_capacity, unsigned long long *hit_keys)
   {
     // (small batches -- 128-ray workgroups -- run the instantiation with the small LDS table: more workgroups per CU)
+    // tev[1], the kernel's own stop event, is what the next batch's set-up pass waits for (see map_state.h: a stop event
+    // costs nothing, an event record behind the kernel would idle the queue for microseconds).
     if (bin_tab_mask < kLtabSmall)
     {
-      hipLaunchKernelGGL(k_ray_bin<kLtabSmall>, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m),
-                         batchScratch(m), static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays,
-                         static_cast<Segment *>(m->segments.ptr), seg_capacity, hit_keys, m->d_hit_mask, ray_shift,
-                         bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
+      hipExtLaunchKernelGGL(k_ray_bin<kLtabSmall>, dim3(bin_blocks), dim3(bin_threads), 0, s, nullptr, tev[1], 0, m->mc,
+                            regionTable(m), batchScratch(m), static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays,
+                            static_cast<Segment *>(m->segments.ptr), seg_capacity, hit_keys, m->d_hit_mask, ray_shift,
+                            bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
     }
     else
     {
-      hipLaunchKernelGGL(k_ray_bin<kLtabSize>, dim3(bin_blocks), dim3(bin_threads), 0, s, m->mc, regionTable(m),
-                         batchScratch(m), static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays,
-                         static_cast<Segment *>(m->segments.ptr), seg_capacity, hit_keys, m->d_hit_mask, ray_shift,
-                         bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
+      hipExtLaunchKernelGGL(k_ray_bin<kLtabSize>, dim3(bin_blocks), dim3(bin_threads), 0, s, nullptr, tev[1], 0, m->mc,
+                            regionTable(m), batchScratch(m), static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays,
+                            static_cast<Segment *>(m->segments.ptr), seg_capacity, hit_keys, m->d_hit_mask, ray_shift,
+                            bucket ? 1 : 0, bin_rays_per_block, bin_tab_mask);
     }
-    (void)hipEventRecord(m->ev_bin_done, s);
-    m->bin_done_recorded = true;
+    mark(1);
+    m->tev_pre_walk[ring] = 1;
+    m->bin_done_event = tev[1];
   }
 
   void launchRegionSort()
   {
-    hipLaunchKernelGGL(k_sort_region_hits, dim3(4 * m->walk_workgroups), dim3(kSortThreads), 0, s, regionTable(m),
-                       batchScratch(m), static_cast<const unsigned long long *>(m->hit_keys_a.ptr),
-                       static_cast<unsigned long long *>(m->hit_keys_b.ptr), m->mc.region_voxels);
+    hipExtLaunchKernelGGL(k_sort_region_hits, dim3(4 * m->walk_workgroups), dim3(kSortThreads), 0, s, nullptr, tev[2],
+                          0, regionTable(m), batchScratch(m),
+                          static_cast<const unsigned long long *>(m->hit_keys_a.ptr),
+                          static_cast<unsigned long long *>(m->hit_keys_b.ptr), m->mc.region_voxels);
+    mark(2);
+    m->tev_pre_walk[ring] = 2;
   }
 
   int frontHalf()
@@ -165,19 +178,23 @@ struct BatchRun
     // kernel vacates (C1: 1.06 -> 1.03 ms per batch; holding the pass until the walk has ended loses the gain again,
     // and so does a stream priority above the compute stream's).  In a kernel trace k_plan therefore shows the walk's
     // duration: its dispatch waits for a CU.
-    if (m->batch_done_recorded[m->parity])
+    if (m->batch_done_event[m->parity])
     {
-      OHMHIP_CHECK(hipStreamWaitEvent(f, m->ev_batch_done[m->parity], 0));
+      OHMHIP_CHECK(hipStreamWaitEvent(f, m->batch_done_event[m->parity], 0));
     }
-    if (m->bin_done_recorded)
+    if (m->bin_done_event)
     {
-      OHMHIP_CHECK(hipStreamWaitEvent(f, m->ev_bin_done, 0));
+      OHMHIP_CHECK(hipStreamWaitEvent(f, m->bin_done_event, 0));
     }
     if (attempt > 0 || !info_clean)
     {
       OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), f));
     }
-    OHMHIP_CHECK(hipEventRecord(tev[0], f));
+    if (m->phase_timing)
+    {
+      OHMHIP_CHECK(hipEventRecord(tev[0], f));
+      mark(0);
+    }
     if (bin_tab_mask < kLtabSmall)
     {
       hipLaunchKernelGGL(k_ray_setup<kLtabSmall>, dim3(bin_blocks), dim3(bin_threads), 0, f, m->mc, regionTable(m),
@@ -190,15 +207,27 @@ struct BatchRun
                          batchScratch(m), d_rays, n_rays, ray_flags, static_cast<RayWalk *>(batchWalks(m).ptr),
                          bin_rays_per_block, bin_tab_mask);
     }
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, f, regionTable(m), batchScratch(m), batchChunks(m),
-                       m->chunk_capacity, batch_chunk_segments, m->h_info_dev, m->d_info + next_info_index,
-                       batchEventCount(m));
+    // The plan's stop event, tev[5], is what the compute stream and the host wait for.  (Spill to host: the regions' use
+    // stamps reach the host with the summary -- a copy queued behind the plan, so there the wait is on an event
+    // recorded behind that copy.)
+    hipExtLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, f, nullptr, tev[5], 0, regionTable(m), batchScratch(m),
+                          batchChunks(m), m->chunk_capacity, batch_chunk_segments, m->h_info_dev,
+                          m->d_info + next_info_index, batchEventCount(m));
+    mark(5);
     m->info_clean = true;
-    OHMHIP_CHECK(queueUseStamps(m, f));  // (spill to host: the regions' use stamps reach the host with the summary)
-    OHMHIP_CHECK(hipEventRecord(tev[5], f));
-    OHMHIP_CHECK(hipEventRecord(m->ev[7], f));
-    OHMHIP_CHECK(hipStreamWaitEvent(s, m->ev[7], 0));
-    OHMHIP_CHECK(hipEventRecord(tev[6], s));
+    hipEvent_t plan_done = tev[5];
+    if (m->spill_enabled)
+    {
+      OHMHIP_CHECK(queueUseStamps(m, f));
+      OHMHIP_CHECK(hipEventRecord(m->ev[7], f));
+      plan_done = m->ev[7];
+    }
+    OHMHIP_CHECK(hipStreamWaitEvent(s, plan_done, 0));
+    if (m->phase_timing)
+    {
+      OHMHIP_CHECK(hipEventRecord(tev[6], s));
+      mark(6);
+    }
     // The host needs the batch summary (segment count, sample distribution, pool state) before it can size and launch
     // the rest -- a round trip during which the device would idle.  In steady state (occupancy, previous batch sorted
     // its samples per region) the binning and the sample sort are launched right away with the buffers of the previous
@@ -208,11 +237,9 @@ struct BatchRun
     if (speculated)
     {
       launchBin(true, spec_seg_cap, static_cast<unsigned long long *>(m->hit_keys_a.ptr));
-      OHMHIP_CHECK(hipEventRecord(tev[1], s));
       launchRegionSort();
-      OHMHIP_CHECK(hipEventRecord(tev[2], s));
     }
-    OHMHIP_CHECK(hipEventSynchronize(m->ev[7]));
+    OHMHIP_CHECK(hipEventSynchronize(plan_done));
     OHMHIP_CHECK(hipGetLastError());
     info = *m->h_info;
     return OHMHIP_OK;
@@ -353,10 +380,11 @@ struct BatchRun
       launchBin(bucket_hits, seg_cap, keys_a);
       if (tsdf_mode)
       {
-        hipLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
-                           static_cast<const RayWalk *>(batchWalks(m).ptr), d_rays, n_rays, m->d_hit_mask);
+        hipExtLaunchKernelGGL(k_tsdf_flag, dim3(ray_blocks), dim3(256), 0, s, nullptr, tev[2], 0, m->mc, regionTable(m),
+                              static_cast<const RayWalk *>(batchWalks(m).ptr), d_rays, n_rays, m->d_hit_mask);
+        mark(2);
+        m->tev_pre_walk[ring] = 2;
       }
-      OHMHIP_CHECK(hipEventRecord(tev[1], s));
       if (bucket_hits)
       {
         if (info.n_hit_regions)
@@ -371,10 +399,11 @@ struct BatchRun
         // leaves each voxel's samples in ray order.
         OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(m->sort_temp.ptr, temp_bytes, keys_a, keys_b, size_t(n_rays),
                                                           kHitRayBits, sortEndBit(info.n_slots), s));
-        hipLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, sorted, batchScratch(m),
-                           m->mc.region_voxels);
+        hipExtLaunchKernelGGL(k_hit_bounds, dim3(ray_blocks), dim3(256), 0, s, nullptr, tev[2], 0, sorted,
+                              batchScratch(m), m->mc.region_voxels);
+        mark(2);
+        m->tev_pre_walk[ring] = 2;
       }
-      OHMHIP_CHECK(hipEventRecord(tev[2], s));
     }
     return OHMHIP_OK;
   }
@@ -436,17 +465,19 @@ struct BatchRun
         const bool special = (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) != 0;
         const dim3 wgrid(std::min<uint32_t>(info.n_chunks, m->walk_workgroups)), wblock(kWalkThreads);
         const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments);
+        // tev[3] -- the end of the walk phase -- is the stop event of the phase's last kernel.
+        hipEvent_t walk_stop = traversal_pass ? nullptr : tev[3];
         if (special)
         {
-          hipLaunchKernelGGL((k_region_walk<true, false>), wgrid, wblock, wlds, s, wa);
+          hipExtLaunchKernelGGL((k_region_walk<true, false>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
         }
         else if (trace)
         {
-          hipLaunchKernelGGL((k_region_walk<false, true>), wgrid, wblock, wlds, s, wa);
+          hipExtLaunchKernelGGL((k_region_walk<false, true>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
         }
         else
         {
-          hipLaunchKernelGGL((k_region_walk<false, false>), wgrid, wblock, wlds, s, wa);
+          hipExtLaunchKernelGGL((k_region_walk<false, false>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
         }
         if (traversal_pass)
         {
@@ -459,16 +490,25 @@ struct BatchRun
           ta.traversal_acc = m->d_traversal_acc;
           ta.unit_bits = traversalUnitBits(m->mc.resolution);
           ta.refill_min_idle = 16;  // (8: +8 %, 32: the same, measured on C1)
-          hipLaunchKernelGGL(k_region_traversal, dim3(info.n_chunks), dim3(kWalkThreads), traversalLdsBytes(m->mc), s,
-                             ta);
+          hipExtLaunchKernelGGL(k_region_traversal, dim3(info.n_chunks), dim3(kWalkThreads), traversalLdsBytes(m->mc),
+                                s, nullptr, tev[3], 0, ta);
         }
-        OHMHIP_CHECK(hipEventRecord(tev[3], s));
+        mark(3);
         if (occupancy_mode)
         {
-          hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m), events, event_capacity,
-                             batchEventCount(m), sorted, m->d_miss_counts,
-                             static_cast<uint32_t *>(m->interval_counts.ptr), m->mc.region_voxels,
-                             reinterpret_cast<uint32_t *>(m->h_info_dev + 1));
+          // Deferred misses reach the global event list only from regions whose samples do not fit the walk's LDS
+          // staging (lds_resolve in k_region_walk): no such region, no list to resolve, no launch.
+          if (info.max_region_hits > uint32_t(kLdsHits))
+          {
+            hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m), events, event_capacity,
+                               batchEventCount(m), sorted, m->d_miss_counts,
+                               static_cast<uint32_t *>(m->interval_counts.ptr), m->mc.region_voxels,
+                               reinterpret_cast<uint32_t *>(m->h_info_dev + 1));
+          }
+          else
+          {
+            *reinterpret_cast<volatile uint32_t *>(&m->h_info[1]) = 0;  // (the event demand the next batch is sized from)
+          }
           break;
         }
         // NDT / TSDF: the host needs the event count to size the sort; an overflowing list is re-walked.
@@ -504,8 +544,8 @@ struct BatchRun
     else
     {
       OHMHIP_CHECK(hipEventRecord(tev[3], s));
+      mark(3);
     }
-    OHMHIP_CHECK(hipEventRecord(m->ev[3], s));
     return OHMHIP_OK;
   }
 
@@ -513,19 +553,26 @@ struct BatchRun
   {
     // (One launch for both halves -- k_apply_occupancy -- measured slower than the two below: 0.167 vs 0.147 ms for
     // sort + apply in C1; the sample replay wants small workgroups and few registers.)
-    hipLaunchKernelGGL(k_apply_hits, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
-                       ray_flags, sorted, static_cast<uint32_t *>(m->interval_counts.ptr), m->d_miss_counts, d_rays,
-                       static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
-                       static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]), sec,
-                       static_cast<const RayWalk *>(batchWalks(m).ptr));
+    // (tev[4], the end of the batch, is the stop event of its last kernel: what the set-up pass of the batch after the
+    // next waits for before it reuses this batch's scratch copy)
+    float *occ = static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]);
+    uint32_t *mean_layer = static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]);
+    uint32_t *intervals = static_cast<uint32_t *>(m->interval_counts.ptr);
+    const RayWalk *walks = static_cast<const RayWalk *>(batchWalks(m).ptr);
+    // (one launch with a workgroup per region that receives samples, and the count application shared by eight
+    // workgroups per region, were both measured slower in round 5 -- 1.01 and 0.93 against 0.91 ms per C1 batch: short-lived
+    // workgroups that leave after three dependent loads cost more than the idle lanes they replace)
+    hipExtLaunchKernelGGL(k_apply_hits, dim3(ray_blocks), dim3(256), 0, s, nullptr, info.n_touched ? nullptr : tev[4], 0,
+                          m->mc, regionTable(m), batchScratch(m), ray_flags, sorted, intervals, m->d_miss_counts, d_rays,
+                          occ, mean_layer, sec, walks);
     if (info.n_touched)
     {
-      hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
-                         batchScratch(m), ray_flags, m->d_miss_counts, m->d_hit_mask,
-                         static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]), 1,
-                         static_cast<uint32_t *>(nullptr), direct_segments, 0, sec.traversal,
-                         sec.traversal ? m->d_traversal_acc : nullptr);
+      hipExtLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, nullptr, tev[4], 0, m->mc,
+                            regionTable(m), batchScratch(m), ray_flags, m->d_miss_counts, m->d_hit_mask, occ, 1,
+                            static_cast<uint32_t *>(nullptr), direct_segments, 0, sec.traversal,
+                            sec.traversal ? m->d_traversal_acc : nullptr);
     }
+    batch_end_marked = true;
     return OHMHIP_OK;
   }
 
@@ -631,9 +678,12 @@ struct BatchRun
 
   int finish()
   {
-    OHMHIP_CHECK(hipEventRecord(tev[4], s));
-    OHMHIP_CHECK(hipEventRecord(m->ev_batch_done[m->parity], s));
-    m->batch_done_recorded[m->parity] = true;
+    if (!batch_end_marked)
+    {
+      OHMHIP_CHECK(hipEventRecord(tev[4], s));  // (NDT / TSDF / stop-flag batches: their tails end in different kernels)
+    }
+    mark(4);
+    m->batch_done_event[m->parity] = tev[4];
     OHMHIP_CHECK(hipGetLastError());
 
     m->stats = {};
@@ -654,7 +704,7 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
                    uint32_t n_rays, unsigned ray_flags)
 {
   BatchRun run{ m, d_rays, d_intensities, d_timestamps, n_rays, ray_flags, m->stream, m->front_stream,
-                m->tev[m->batch_seq % kTimingRing] };
+                m->tev[m->batch_seq % kTimingRing], uint32_t(m->batch_seq % kTimingRing) };
   OHMHIP_CHECK(run.prepare());
   for (run.attempt = 0; run.attempt < 8; ++run.attempt)
   {

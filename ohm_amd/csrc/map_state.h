@@ -151,16 +151,23 @@ struct ohmhip_map_s
   /// N and in the CUs its walk kernel vacates.  It is idle whenever no batch call is in progress: every call waits for
   /// its own plan summary.
   hipStream_t front_stream = nullptr;
-  hipEvent_t ev_batch_done[2] = { nullptr, nullptr };  ///< per parity: the batch that last used this scratch copy is done
-  bool batch_done_recorded[2] = { false, false };
-  hipEvent_t ev_bin_done = nullptr;  ///< the latest k_ray_bin has finished
-  bool bin_done_recorded = false;
+  /// Cross-stream ordering uses the STOP EVENTS of the kernels themselves (hipExtLaunchKernelGGL binds an event to the
+  /// kernel's own completion signal: free), never a hipEventRecord behind a kernel -- on gfx950 / ROCm 7.2 a record is a
+  /// barrier packet that idles the queue for 3-7 us before the next kernel starts (scripts/probes/event_probe.hip,
+  /// profiles/r05_event_probe.txt; round 4 paid eight of them per batch).  The events live in the timing ring below.
+  hipEvent_t batch_done_event[2] = { nullptr, nullptr };  ///< per parity: stop event of the last kernel of the batch that last used this scratch copy
+  hipEvent_t bin_done_event = nullptr;  ///< stop event of the latest k_ray_bin
   uint32_t parity = 0;  ///< which copy of the doubled per-batch scratch (RayWalk array, per-hash / per-slot counters,
                         ///< chunk list, event counters) the current batch uses
   hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  /// Timing events of the last kTimingRing batches (start, binned, samples ordered, walked, done): reading a batch's
-  /// phase times does not have to synchronise the host with every batch.
-  hipEvent_t tev[kTimingRing][7] = {};  // ([5]: set-up pass done, [6]: binning starts)
+  /// Events of the last kTimingRing batches: [1] binned, [2] samples ordered (the kernel before the walk), [3] walked,
+  /// [4] batch done, [5] plan done -- all stop events of kernels --, and with `phase_timing` [0] set-up pass starts, [6]
+  /// binning starts (records: they cost the batch a few microseconds each).  tev_mask: which of them the batch recorded;
+  /// tev_pre_walk: the event that marks the start of the batch's walk phase ([2], or [1] when nothing ran in between).
+  hipEvent_t tev[kTimingRing][7] = {};
+  uint8_t tev_mask[kTimingRing] = {};
+  uint8_t tev_pre_walk[kTimingRing] = {};
+  bool phase_timing = false;  ///< ohmhip_map_set_phase_timing / OHMHIP_PHASE_TIMING=1 / OHMHIP_DEBUG_FLAGS & 256
   uint64_t batch_seq = 0;
 
   uint32_t slot_capacity = 0;

@@ -35,6 +35,9 @@
 #ifndef OHMHIP_BIN_FUSE_STEPS
 #define OHMHIP_BIN_FUSE_STEPS 1  // k_ray_bin: sample key emitted in the segment loop (one RayWalk load per ray)
 #endif
+#ifndef OHMHIP_LTAB_HASH24
+#define OHMHIP_LTAB_HASH24 1  // binning kernels: LDS region table hashed with three 24-bit multiplies (0: the 64-bit hash)
+#endif
 
 #include "secondary_device.h"
 #include "walk_device.h"
@@ -300,13 +303,29 @@ struct LdsRegionTableT
                           ///< (next free global position of the workgroup's reserved range)
 };
 
+/// Hash of a packed region key for the workgroups' LDS tables.  The global table's hashRegionKey multiplies 64-bit
+/// values -- four quarter-rate 32-bit multiplies on gfx950, ~60 cycles of issue per look-up, and the binning kernels look
+/// a region up for every ray-region segment.  Three full-rate 24-bit multiplies of the 16-bit coordinates do here: a
+/// workgroup's regions are a compact neighbourhood, odd multipliers spread neighbours over the table.
+__device__ inline uint32_t ltabHash(uint64_t key, uint32_t mask)
+{
+#if OHMHIP_LTAB_HASH24
+  const uint32_t lo = uint32_t(key);
+  const uint32_t h = __umul24(lo & 0xffffu, 0x9E3Bu) ^ __umul24(lo >> 16, 0x85EBu) ^
+                     __umul24(uint32_t(key >> 32) & 0xffffu, 0xC2B3u);
+  return (h ^ (h >> 11)) & mask;
+#else
+  return hashRegionKey(key, mask);
+#endif
+}
+
 /// Find or insert `key`; returns the entry index or kLtabSize when the table is full (caller falls back to global).
 /// `mask` = entries in use - 1 (a power of two <= kLtabSize: small workgroups use a small table so clearing and scanning
 /// it does not dominate their run time).
 template <uint32_t kTab>
 __device__ inline uint32_t ltabFindOrInsert(LdsRegionTableT<kTab> &tab, uint64_t key, uint32_t mask)
 {
-  uint32_t idx = hashRegionKey(key, mask);
+  uint32_t idx = ltabHash(key, mask);
   for (uint32_t probe = 0; probe < 64; ++probe)
   {
     unsigned long long prev = tab.keys[idx];
@@ -326,7 +345,7 @@ __device__ inline uint32_t ltabFindOrInsert(LdsRegionTableT<kTab> &tab, uint64_t
 template <uint32_t kTab>
 __device__ inline uint32_t ltabFind(const LdsRegionTableT<kTab> &tab, uint64_t key, uint32_t mask)
 {
-  uint32_t idx = hashRegionKey(key, mask);
+  uint32_t idx = ltabHash(key, mask);
   for (uint32_t probe = 0; probe < 64; ++probe)
   {
     const unsigned long long k = tab.keys[idx];

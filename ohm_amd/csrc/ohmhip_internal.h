@@ -2,6 +2,7 @@
 #ifndef OHMHIP_INTERNAL_H
 #define OHMHIP_INTERNAL_H
 
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>

@@ -156,10 +156,7 @@ try
   {
     return fail(err);
   }
-  if ((err = hipStreamCreateWithFlags(&m->front_stream, hipStreamNonBlocking)) != 0 ||
-      (err = hipEventCreateWithFlags(&m->ev_batch_done[0], hipEventDisableTiming)) != 0 ||
-      (err = hipEventCreateWithFlags(&m->ev_batch_done[1], hipEventDisableTiming)) != 0 ||
-      (err = hipEventCreateWithFlags(&m->ev_bin_done, hipEventDisableTiming)) != 0)
+  if ((err = hipStreamCreateWithFlags(&m->front_stream, hipStreamNonBlocking)) != 0)
   {
     return fail(err);
   }
@@ -287,6 +284,11 @@ try
   if (const char *env = std::getenv("OHMHIP_DEBUG_FLAGS"))
   {
     m->debug_flags = unsigned(std::atoi(env));
+    m->phase_timing = m->phase_timing || (m->debug_flags & 256u) != 0;  // (the phase timeline needs every stamp)
+  }
+  if (const char *env = std::getenv("OHMHIP_PHASE_TIMING"))
+  {
+    m->phase_timing = std::atoi(env) != 0;
   }
   if (const char *env = std::getenv("OHMHIP_REFILL_MIN_IDLE"))
   {
@@ -455,13 +457,6 @@ try
   {
     (void)hipStreamDestroy(m->front_stream);
   }
-  for (hipEvent_t e : { m->ev_batch_done[0], m->ev_batch_done[1], m->ev_bin_done })
-  {
-    if (e)
-    {
-      (void)hipEventDestroy(e);
-    }
-  }
   delete m;
   return OHMHIP_OK;
 }
@@ -603,7 +598,7 @@ try
     OHMHIP_CHECK(hipMemset(m->d_dbg, 0, sizeof(c)));
   }
   OHMHIP_CHECK(hipStreamSynchronize(m->copy_stream));
-  if ((m->debug_flags & 256u) && m->batch_seq >= 4)
+  if ((m->debug_flags & 256u) && m->phase_timing && m->batch_seq >= 4)
   {
     // Development aid: when the phases of the last three batches started / ended, relative to the first of them
     // (set-up start, set-up + plan end, bin start, bin end, sort end, walk end, batch end).
@@ -639,28 +634,88 @@ try
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
-  hipEvent_t *tev = m->tev[(m->batch_seq - 1 - batches_back) % kTimingRing];
+  const uint32_t ring = uint32_t((m->batch_seq - 1 - batches_back) % kTimingRing);
+  hipEvent_t *tev = m->tev[ring];
+  const uint32_t have = m->tev_mask[ring];
+  auto has = [&](int k) { return (have >> k) & 1u; };
+  ms[0] = ms[1] = ms[2] = ms[3] = 0.0f;
+  if (!has(4))
+  {
+    return OHMHIP_ERR_INTERNAL;
+  }
   OHMHIP_CHECK(hipEventSynchronize(tev[4]));
-  float sort_ms = 0, apply_ms = 0, front_ms = 0, bin_ms = 0;
-  OHMHIP_CHECK(hipEventElapsedTime(&ms[0], tev[0], tev[4]));
-  // The set-up pass of a batch runs on its own stream under the previous batch's last kernels, so back-to-back batches
-  // complete at intervals shorter than first start -> last end; that interval is the device time the batch cost.
+  // Device time the batch cost: first kernel start -> last kernel end where the start was recorded (phase timing), else
+  // plan end -> last kernel end; for batches presented back to back the interval between the previous batch's last
+  // kernel and this one's (a batch's set-up pass runs on a second stream under the previous batch's last kernels, so
+  // batches complete at intervals shorter than first start -> last end).
+  if (has(0))
+  {
+    OHMHIP_CHECK(hipEventElapsedTime(&ms[0], tev[0], tev[4]));
+  }
+  else if (has(5))
+  {
+    OHMHIP_CHECK(hipEventElapsedTime(&ms[0], tev[5], tev[4]));
+  }
   if (uint64_t(batches_back) + 1 < m->batch_seq && batches_back + 1 < kTimingRing)
   {
-    hipEvent_t *prev = m->tev[(m->batch_seq - 2 - batches_back) % kTimingRing];
+    const uint32_t prev_ring = uint32_t((m->batch_seq - 2 - batches_back) % kTimingRing);
     float period = 0;
-    if (hipEventElapsedTime(&period, prev[4], tev[4]) == hipSuccess && period > 0 && period < ms[0])
+    if (((m->tev_mask[prev_ring] >> 4) & 1u) &&
+        hipEventElapsedTime(&period, m->tev[prev_ring][4], tev[4]) == hipSuccess && period > 0 &&
+        (period < ms[0] || !has(0)))
     {
       ms[0] = period;
     }
   }
-  OHMHIP_CHECK(hipEventElapsedTime(&front_ms, tev[0], tev[5]));
-  OHMHIP_CHECK(hipEventElapsedTime(&bin_ms, tev[6], tev[1]));
-  ms[1] = front_ms + bin_ms;
-  OHMHIP_CHECK(hipEventElapsedTime(&ms[2], tev[2], tev[3]));
-  OHMHIP_CHECK(hipEventElapsedTime(&sort_ms, tev[1], tev[2]));
-  OHMHIP_CHECK(hipEventElapsedTime(&apply_ms, tev[3], tev[4]));
-  ms[3] = sort_ms + apply_ms;
+  float sort_ms = 0, apply_ms = 0, front_ms = 0, bin_ms = 0;
+  if (has(0) && has(5) && has(6) && has(1))
+  {
+    OHMHIP_CHECK(hipEventElapsedTime(&front_ms, tev[0], tev[5]));
+    OHMHIP_CHECK(hipEventElapsedTime(&bin_ms, tev[6], tev[1]));
+    ms[1] = front_ms + bin_ms;
+  }
+  const int pre = int(m->tev_pre_walk[ring]);
+  if (has(3) && pre > 0 && has(pre))
+  {
+    OHMHIP_CHECK(hipEventElapsedTime(&ms[2], tev[pre], tev[3]));
+    if (has(1) && pre != 1)
+    {
+      OHMHIP_CHECK(hipEventElapsedTime(&sort_ms, tev[1], tev[pre]));
+    }
+    OHMHIP_CHECK(hipEventElapsedTime(&apply_ms, tev[3], tev[4]));
+    ms[3] = sort_ms + apply_ms;
+  }
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_set_phase_timing(ohmhip_map_t m, int enable)
+try
+{
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);
+  m->phase_timing = enable != 0;
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_batches_launched(ohmhip_map_t m, uint64_t *count)
+try
+{
+  if (!m || !count)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  // (no flush of collected rays: asking must not change what runs; only a launch handed to the map's own thread is
+  // waited for, its status stays with the map for the next settling call)
+  if (m->launch_busy)
+  {
+    m->launch_thread->wait();
+  }
+  *count = m->batch_seq;
   return OHMHIP_OK;
 }
 OHMHIP_ABI_CATCH

@@ -632,6 +632,10 @@ struct GpuKeyOut
   int16_t region[3];
   uint8_t voxel[4];
 };
+// The reference's record, from its own header compiled in place (tests/golden/ref_vectors.npz: gpukey_layout).
+static_assert(sizeof(GpuKeyOut) == 10 && alignof(GpuKeyOut) == 2 && offsetof(GpuKeyOut, region) == 0 &&
+                offsetof(GpuKeyOut, voxel) == 6,
+              "GpuKeyOut must keep the layout of ohm::GpuKey (ohmgpu/GpuKey.h:37-46)");
 
 /// LineKeysQueryGpu / `calculateLines` (ohmgpu/gpu/LineKeys.cl:66-100) with the CPU walk's semantics
 /// (ohm/LineWalk.h:112-129 walkSegmentKeys, flags 0: start and end voxel included): one lane per query line writes the

@@ -9,6 +9,10 @@
 
 #include "ohmhip_internal.h"
 
+#ifndef OHMHIP_STEPS_FAST
+#define OHMHIP_STEPS_FAST 1  // stepsBefore: the count from the quotient alone when it is far from every integer
+#endif
+
 namespace ohmhip
 {
 __device__ inline double dInf()
@@ -171,6 +175,21 @@ __device__ inline int stepsBefore(double init, double delta, double rdelta, int 
   if (delta > 0 && delta < dInf())
   {
     const double x = (ta - init) * rdelta;
+#if OHMHIP_STEPS_FAST
+    // In real arithmetic T_b(i) <= ta  <=>  i - 1 <= x.  The fp64 values the exact predicate compares -- T_b(i) =
+    // fl(init + fl(delta * (i - 1))) against ta -- differ from that by rounding of at most 2^-51 * (i + |init| / delta)
+    // steps, and x itself carries three roundings (2^-51 * |x|): for |x| < 2^20 and |init| <= 4 delta both stay below
+    // 1e-9 steps.  So when x keeps a distance of 1e-5 from every integer the predicate's outcome for every i is the real
+    // one -- no tie, no doubt -- and the count follows without evaluating it (the loops below evaluate it at least twice
+    // per call; the set-up kernels call this twice per ray-region segment).  Everything else takes the exact route.
+    const double whole = floor(x);
+    const double frac = x - whole;
+    if (frac > 1e-5 && frac < 1.0 - 1e-5 && x > -1048576.0 && x < 1048576.0 && fabs(init) <= 4.0 * delta)
+    {
+      const int count = int(whole) + 1;
+      return (x < 0) ? 0 : ((count > total) ? total : count);
+    }
+#endif
     // T_b(i) <= ta  <=>  i - 1 <= x
     n = (x < 0) ? 0 : ((x >= double(total)) ? total : int(x) + 1);
     n = (n > total) ? total : n;

@@ -302,9 +302,9 @@ void scheduleWriteBack(ohmhip_map_t m, uint32_t now)
   }
   hipStream_t cs = m->wb_stream;
   bool ok = true;
-  if (m->batch_done_recorded[m->parity ^ 1u])
+  if (m->batch_done_event[m->parity ^ 1u])
   {
-    ok = hipStreamWaitEvent(cs, m->ev_batch_done[m->parity ^ 1u], 0) == hipSuccess;
+    ok = hipStreamWaitEvent(cs, m->batch_done_event[m->parity ^ 1u], 0) == hipSuccess;
   }
   if (ok)
   {

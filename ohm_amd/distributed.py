@@ -522,8 +522,11 @@ class PartitionedIntegrator:
         # ohmhip_map_integrate_rays_device): three receive buffers used in turn are never written while a batch reads
         # them, so a step does not wait for the previous one -- the next batch is routed (the library routes on a stream
         # of its own) and exchanged while the previous one integrates.
+        # The turn advances per LAUNCH, not per call: a step that receives no rays, or whose rays the map only
+        # collects (batch coalescing), launches nothing, and the two batches launched last may both still be reading
+        # their buffers.  Each buffer remembers the launch count its batch made; it is free once two more were launched.
         self._recv = [None, None, None]
-        self._calls = 0
+        self._recv_batch = [0, 0, 0]
         self._xstream = None
         self.last = {}
 
@@ -585,8 +588,10 @@ class PartitionedIntegrator:
         from . import _lib as L
         gm = self.gpu_map
         n_local = int(element_count) // 2
-        slot = self._calls % 3
-        self._calls += 1
+        launched = gm.batchesLaunched()
+        # (when the previous integrate call returned, every batch but the two launched last had ended)
+        slot = next(i for i in range(3) if self._recv_batch[i] == 0 or self._recv_batch[i] + 2 <= launched)
+        self._recv_batch[slot] = 0
         routed, counts, visits = self.route(d_rays_ptr, n_local, ray_update_flags)
         sent = int(counts.sum())
         if self.comm is not None:
@@ -619,7 +624,11 @@ class PartitionedIntegrator:
                      "rays_received": n_recv, "recv_counts": recv_counts, "visits_local": visits}
         if n_recv == 0:
             return 0
-        return gm.integrateRaysDevice(recv.data_ptr(), 2 * n_recv, ray_update_flags)
+        done = gm.integrateRaysDevice(recv.data_ptr(), 2 * n_recv, ray_update_flags)
+        after = gm.batchesLaunched()
+        # (no launch: the call copied its rays behind the ones waiting and waited for the copy -- the buffer is free)
+        self._recv_batch[slot] = after if after > launched else 0
+        return done
 
 
 def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timings=None, streams_out=None):

@@ -360,6 +360,17 @@ class GpuMap(RayMapper):
         L.check(L.lib.ohmhip_map_batch_timings(self._handle, batches_back, ms), "batch_timings")
         return {"ms_total": ms[0], "ms_setup": ms[1], "ms_walk": ms[2], "ms_apply": ms[3]}
 
+    def setPhaseTiming(self, enable=True):
+        """Record the start markers of the set-up and binning passes too (ms_setup, and ms_total of a batch on its own as
+        first kernel start -> last kernel end): a few microseconds per batch, off by default (include/ohmhip.h)."""
+        L.check(L.lib.ohmhip_map_set_phase_timing(self._handle, 1 if enable else 0), "set_phase_timing")
+
+    def batchesLaunched(self):
+        """Device batches launched so far (calls that only collect their rays launch none)."""
+        n = C.c_uint64(0)
+        L.check(L.lib.ohmhip_map_batches_launched(self._handle, C.byref(n)), "batches_launched")
+        return int(n.value)
+
     def wait(self):
         L.check(L.lib.ohmhip_map_sync(self._handle), "sync")
 

@@ -539,6 +539,17 @@ public:
     ohmhip_map_last_stats(handle_, &st);
     return st;
   }
+  /// Device batches launched so far (a call that only collects its rays, or is rejected, launches none): what a caller
+  /// recycling device ray buffers by the "two batches in flight" rule counts (include/ohmhip.h).
+  uint64_t batchesLaunched() const
+  {
+    uint64_t n = 0;
+    ohmhip_map_batches_launched(handle_, &n);
+    return n;
+  }
+  /// Start markers of the set-up and binning passes for lastBatchStats().ms_setup (a few microseconds per batch; off by
+  /// default, see ohmhip_map_set_phase_timing).
+  void setPhaseTiming(bool enable) { OHMHIP_GPUAPICHECK(ohmhip_map_set_phase_timing(handle_, enable ? 1 : 0)); }
   /// The MapRegionCache face of the reference's GpuCache (ohm/MapRegionCache.h; ohmgpu/GpuCache.h:80): what the core
   /// map and the tests call through gpuCache() -- flush / clear / remove.  There is no separate cache object here (the
   /// whole map is resident), so this is a view of the GpuMap.
@@ -1192,7 +1203,17 @@ public:
     {
       n_in += c;
     }
-    gputil::Buffer &in = recv_[calls_++ % 3];
+    // The turn advances per LAUNCH, not per call: a step that launches nothing -- no rays received, or rays
+    // the map only collects -- leaves the two batches launched last in flight, possibly both still reading their
+    // buffers.  A buffer is free once two more batches were launched after the one that reads it.
+    const uint64_t launched = map_.batchesLaunched();
+    size_t turn = 0;
+    while (turn < 2 && recv_batch_[turn] != 0 && recv_batch_[turn] + 2 > launched)
+    {
+      ++turn;  // (at most two buffers are held by batches in flight: the third is always free)
+    }
+    recv_batch_[turn] = 0;
+    gputil::Buffer &in = recv_[turn];
     const size_t in_bytes = std::max<size_t>(n_in, 1) * 6 * sizeof(double);
     if (!in.isValid())
     {
@@ -1200,7 +1221,7 @@ public:
     }
     else if (in.size() < in_bytes)
     {
-      in.resize(in_bytes + in_bytes / 4);  // (the batch that read it -- three calls ago -- has ended)
+      in.resize(in_bytes + in_bytes / 4);  // (the batch that read it has ended: see above)
     }
     void *d_routed = nullptr, *d_in = nullptr;
     if (routed_.isValid())
@@ -1222,6 +1243,8 @@ public:
     }
     const size_t done = map_.integrateRays(in, 2 * n_in, ray_update_flags);
     last_status_ = map_.lastStatus();
+    const uint64_t after = map_.batchesLaunched();
+    recv_batch_[turn] = after > launched ? after : 0;  // (no launch: the rays were copied, the buffer is free)
     return done;
   }
 
@@ -1236,7 +1259,7 @@ private:
   gputil::Queue exchange_queue_;
   gputil::Buffer routed_, recv_[3];
   std::vector<uint32_t> send_counts_, recv_counts_;
-  size_t calls_ = 0;
+  uint64_t recv_batch_[3] = { 0, 0, 0 };  ///< launch count of the batch reading each receive buffer (0: none)
   size_t rays_received_ = 0;
   int last_status_ = OHMHIP_OK;
 };

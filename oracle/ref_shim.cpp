@@ -12,6 +12,11 @@
 #include <ohm/VoxelOccupancyCompute.h>   // occupancyAdjustHit/Miss/Up/Down
 #include <ohm/VoxelTouchTimeCompute.h>   // encodeVoxelTouchTime
 #include <ohm/VoxelTsdfCompute.h>        // calculateTsdf<Vec3> (templated on the vector type)
+#include <ohm/RayFlag.h>                 // RayFlag bit values
+#include <ohmgpu/GpuKey.h>               // the device key record, host side (its "MapCoord.h" is ohm/'s)
+
+#include <cstddef>
+#include <cstring>
 
 namespace
 {
@@ -64,5 +69,40 @@ int ref_calculate_tsdf(const double sensor[3], const double sample[3], const dou
                            distance) ?
            1 :
            0;
+}
+/// sizeof / alignof / member offsets of the reference's GpuKey (ohmgpu/GpuKey.h:37-46).
+void ref_gpukey_layout(unsigned out[4])
+{
+  out[0] = unsigned(sizeof(ohm::GpuKey));
+  out[1] = unsigned(alignof(ohm::GpuKey));
+  out[2] = unsigned(offsetof(ohm::GpuKey, region));
+  out[3] = unsigned(offsetof(ohm::GpuKey, voxel));
+}
+/// The bytes of a GpuKey holding the given members (the layout a replacement's key records must reproduce).
+void ref_gpukey_bytes(const short region[3], const unsigned char voxel[4], unsigned char *out)
+{
+  ohm::GpuKey key;
+  std::memset(&key, 0, sizeof(key));
+  for (int i = 0; i < 3; ++i)
+  {
+    key.region[i] = region[i];
+  }
+  for (int i = 0; i < 4; ++i)
+  {
+    key.voxel[i] = voxel[i];
+  }
+  std::memcpy(out, &key, sizeof(key));
+}
+/// RayFlag values in declaration order (ohm/RayFlag.h:16-60).
+void ref_ray_flags(unsigned out[12])
+{
+  const unsigned v[12] = { ohm::kRfDefault,         ohm::kRfEndPointAsFree, ohm::kRfStopOnFirstOccupied,
+                           ohm::kRfExcludeOrigin,   ohm::kRfExcludeSample,  ohm::kRfExcludeRay,
+                           ohm::kRfExcludeUnobserved, ohm::kRfExcludeFree,  ohm::kRfExcludeOccupied,
+                           ohm::kRfReverseWalk,     ohm::kRfInternal,       ohm::kRfInternalTimestamps };
+  for (int i = 0; i < 12; ++i)
+  {
+    out[i] = v[i];
+  }
 }
 }

@@ -2,7 +2,7 @@
 
 The outputs come from oracle/_ref/libohmref.so, which oracle/Makefile compiles from the reference's own headers where
 they lie under /root/reference (ohm/MapCoord.h, ohm/VoxelOccupancyCompute.h, ohm/VoxelTsdfCompute.h,
-ohm/VoxelTouchTimeCompute.h); run this script only where that library can be built.  The fixture is data only (seeded
+ohm/VoxelTouchTimeCompute.h, ohm/RayFlag.h, ohmgpu/GpuKey.h); run this script only where that library can be built.  The fixture is data only (seeded
 inputs + the reference's results) and is what tests/test_oracle_golden.py holds the oracle to, bit for bit, on machines
 that have neither the reference checkout nor the library.
 
@@ -105,6 +105,25 @@ def main():
             res[pi, i] = (r, np.float32(w.value).view(np.uint32), np.float32(d.value).view(np.uint32))
     out.update(tsdf_sensor=sensor, tsdf_sample=sample, tsdf_centre=centre, tsdf_w0=w0, tsdf_d0=d0, tsdf_params=params,
                tsdf_out=res)
+    # --- the device key record and the ray flags (ohmgpu/GpuKey.h:37-46, ohm/RayFlag.h:16-60): layout and values
+    layout = (C.c_uint * 4)()
+    ref.ref_gpukey_layout(layout)
+    out["gpukey_layout"] = np.array(list(layout), dtype=np.uint32)  # sizeof, alignof, offsetof(region), offsetof(voxel)
+    rk = ((u(16, 64, 0) - 0.5) * 65535).astype(np.int16).reshape(-1)
+    regions = np.stack([rk, np.roll(rk, 7), np.roll(rk, 19)], axis=1)
+    regions[:4] = [(-32768, 32767, 0), (0, 0, 0), (-1, 1, -1), (32767, -32768, 255)]
+    voxels = (u(16, 64, 1)[:, None] * np.array([255, 254, 253, 1.999]) + np.arange(4)).astype(np.uint8) % 255
+    voxels[:, 3] = voxels[:, 3] & 1
+    raw = np.zeros((64, int(layout[0])), dtype=np.uint8)
+    for i in range(64):
+        buf = (C.c_ubyte * int(layout[0]))()
+        ref.ref_gpukey_bytes((C.c_short * 3)(*[int(v) for v in regions[i]]), (C.c_ubyte * 4)(*[int(v) for v in voxels[i]]),
+                             buf)
+        raw[i] = np.frombuffer(buf, dtype=np.uint8)
+    out.update(gpukey_regions=regions, gpukey_voxels=voxels, gpukey_bytes=raw)
+    flags = (C.c_uint * 12)()
+    ref.ref_ray_flags(flags)
+    out["ray_flags"] = np.array(list(flags), dtype=np.uint32)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -339,6 +339,46 @@ def test_ndt_miss_planar():
         assert abs(p - expect) <= tol, (start, end, p, expect)
 
 
+def _cylinder_samples(n=10000, radius=0.3, seed=1153297050):
+    """The sample cloud of Ndt.MissCylindrical (NdtTests.cpp:343-373), drawn from the reference's own random stream
+    (tests/stdrandom.py): uniform points of the voxel pushed onto a cylinder about the z axis, radius uniform in
+    [radius - noise, radius + noise] with noise = 0.05f."""
+    from stdrandom import MinStdRand0
+    rng = MinStdRand0(seed)
+    noise = float(np.float32(0.05))
+    pts = np.zeros((n, 3))
+    for i in range(n):
+        x, y, z = rng.uniform(-0.99, 0.99), rng.uniform(-0.99, 0.99), rng.uniform(-0.99, 0.99)
+        length_xy = math.sqrt(x * x + y * y)
+        if length_xy > 1e-6:
+            r = rng.uniform(radius - noise, radius + noise)
+            x, y = r * x / length_xy, r * y / length_xy
+        pts[i] = (x, y, z)
+    return pts
+
+
+# (start, end, expected probability, tolerance) as the reference lists them, NdtTests.cpp:375-405
+NDT_MISS_CYLINDRICAL_CASES = [
+    ((0, 0, 5), (0, 0, -5), 0.004, 0.001),          # straight down the axis
+    ((0, 0, -5), (0, 0, 5), 0.004, 0.001),          # the same reversed
+    ((0.3, 0.3, 5), (0.3, 0.3, -5), 0.425, 0.01),   # parallel to the cylinder near its edge: a near hit
+    ((0.45, 0.45, -5), (0.6, 0.6, 5), 0.499, 0.001),  # parallel, outside: a miss
+    ((2, -0.3, 0), (-2, -0.3, 0), 0.312, 0.005),    # across the middle of the cylinder
+    ((2, -0.3, 0.85), (-2, -0.3, 0.85), 0.436, 0.003),  # across its top end
+    ((2, 0.6, 0.85), (-2, 0.6, 0.85), 0.497, 0.001),    # across the voxel, past the cylinder
+]
+
+
+def test_ndt_miss_cylindrical():
+    # Ndt.MissCylindrical (NdtTests.cpp:335-408): the one reference case with curvature about a single axis, on the
+    # reference's own 10 000 samples and to the reference's own tolerances.
+    samples = _cylinder_samples()
+    m, cov, mean, count, value = _build_ndt_voxel(samples, 2.0, (-1.0, -1.0, -1.0), 0.05)
+    for start, end, expect, tol in NDT_MISS_CYLINDRICAL_CASES:
+        p = _miss_probability(m, cov, mean, count, value, start, end, 0.05)
+        assert abs(p - expect) <= tol, (start, end, p, expect)
+
+
 def test_ndt_miss_spherical():
     # Ndt.MissSpherical (NdtTests.cpp:407-470): shell of radius 0.3 +- noise around the origin
     n = 10000

@@ -85,3 +85,19 @@ def test_calculate_tsdf_bit_exact():
             assert ra == rb
             assert np.float32(a[0].value).view(np.uint32) == np.float32(b[0].value).view(np.uint32)
             assert np.float32(a[1].value).view(np.uint32) == np.float32(b[1].value).view(np.uint32)
+
+
+def test_gpukey_layout_and_ray_flags_fixture_is_what_the_reference_header_compiles_to():
+    """The committed fixture (tests/golden/ref_vectors.npz: gpukey_layout, gpukey_bytes, ray_flags) against the live
+    reference library: ohmgpu/GpuKey.h:37-46 and ohm/RayFlag.h:16-60 compiled where they lie."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.npz"))
+    layout = (C.c_uint * 4)()
+    ref.ref_gpukey_layout(layout)
+    assert list(layout) == [int(v) for v in g["gpukey_layout"]]
+    for region, voxel, expect in zip(g["gpukey_regions"], g["gpukey_voxels"], g["gpukey_bytes"]):
+        buf = (C.c_ubyte * int(layout[0]))()
+        ref.ref_gpukey_bytes((C.c_short * 3)(*[int(v) for v in region]), (C.c_ubyte * 4)(*[int(v) for v in voxel]), buf)
+        assert bytes(buf) == expect.tobytes()
+    flags = (C.c_uint * 12)()
+    ref.ref_ray_flags(flags)
+    assert list(flags) == [int(v) for v in g["ray_flags"]]
