@@ -323,8 +323,12 @@ int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
  * way, ohmgpu/GpuLayerCache.cpp:550-584); a copy is discarded if a batch touches its region afterwards
  * (ohmhip_cache_stats::writebacks / writeback_hits / writeback_stale).  What does not combine with it: replica merge (OHMHIP_ERR_UNSUPPORTED either way
  * round) and the zero-copy views (ohmhip_map_region_slot reports OHMHIP_ERR_NOT_FOUND for a stored region).  A batch
- * that alone touches more regions than the limit allows still fails with OHMHIP_ERR_CAPACITY; turning spilling on
- * therefore sets the batch coalescing threshold to 0 (a collected batch touches the regions of all its calls at once). */
+ * that alone touches more regions than the limit allows is integrated as two halves in ray order (and those again, down
+ * to single rays: the reference finalises what it has enqueued when its cache fills in the middle of a batch and carries
+ * on, ohmgpu/GpuMap.cpp:900-996; results are those of the whole batch -- except on maps with a traversal layer, whose
+ * exit range is carried within a call: there, and for a single ray that still does not fit, the call fails with
+ * OHMHIP_ERR_CAPACITY and changes nothing).  Turning spilling on sets the batch coalescing threshold to 0 (a collected
+ * batch touches the regions of all its calls at once). */
 int ohmhip_map_set_spill_to_host(ohmhip_map_t map, int enable);
 /* The background write-back of the spill path (see WRITE-BACK above), opt-in: off by default. */
 int ohmhip_map_set_spill_writeback(ohmhip_map_t map, int enable);
@@ -350,6 +354,13 @@ int ohmhip_map_batch_timings(ohmhip_map_t map, uint32_t batches_back, float ms[4
  * recorded only with phase timing on (this call, OHMHIP_PHASE_TIMING=1): ms[1], and ms[0] of a batch on its own as first
  * kernel start -> last kernel end, need it and read 0 / the shorter span otherwise.  Default: off. */
 int ohmhip_map_set_phase_timing(ohmhip_map_t map, int enable);
+/* OccupancyMap::firstRayTime / setFirstRayTime (ohm/OccupancyMap.h:342-351): the time base the touch-time layer is
+ * encoded against (milliseconds since it, ohm/VoxelTouchTimeCompute.h:24-37).  Like the reference the map takes it from
+ * the first time stamp it is ever given; set it explicitly where that is not the map's to decide -- the ranks of a
+ * partitioned map must share ONE base (the first stamp of the whole job), not each the first stamp that happens to be
+ * routed to it.  A negative value means "not set yet". */
+int ohmhip_map_set_first_ray_time(ohmhip_map_t map, double time);
+int ohmhip_map_first_ray_time(ohmhip_map_t map, double *time);
 /* Device batches the map has launched since it was created.  An integrate call that only collects its rays (batch
  * coalescing) or is rejected launches none: callers that recycle device ray buffers by the "two batches in flight" rule
  * of ohmhip_map_integrate_rays_device count LAUNCHES with this, not calls -- a buffer handed to the call that made the
@@ -506,10 +517,26 @@ int ohmhip_comm_unique_id(unsigned char id[OHMHIP_COMM_ID_BYTES]);  /* ncclGetUn
 int ohmhip_comm_init_rank(ohmhip_comm_t *comm, const unsigned char id[OHMHIP_COMM_ID_BYTES], int world_size, int rank);
 int ohmhip_comm_destroy(ohmhip_comm_t comm);
 /* Partitioned map: the all-to-all of routed rays (see "Partitioned map" above). */
+/* FAILURE AGREEMENT: a rank that cannot take part in the step (its routing failed, it is out of memory ...) still calls
+ * ohmhip_comm_exchange_counts, with OHMHIP_COUNT_FAILED in every send count: the call then returns OHMHIP_ERR_PEER on
+ * EVERY rank (recv_counts zeroed) and no rank enters the payload exchange -- all ranks leave the step together.  A failure
+ * after the exchange (the integration of what arrived) is local: the failing rank's caller has to end the group's run. */
+#define OHMHIP_COUNT_FAILED 0xffffffffu
 int ohmhip_comm_exchange_counts(ohmhip_comm_t comm, const uint32_t *send_counts, uint32_t *recv_counts,
                                 ohmhip_stream_t stream);
 int ohmhip_comm_exchange_rays(ohmhip_comm_t comm, const double *d_send, const uint32_t *send_counts, double *d_recv,
                               const uint32_t *recv_counts, ohmhip_stream_t stream);
+/* The routed rays' SIDE ARRAYS (round 5) -- the time stamps and intensities the reference passes with every batch
+ * (ohmgpu/GpuMap.cpp:416; GpuNdtMap.cpp:433-486: NDT-TM needs the intensities, a touch-time layer the stamps) travel the
+ * same way: ohmhip_gather_rows puts an array into routed order with the index list ohmhip_map_route_rays returns
+ * (d_dst[i] = d_src[d_index[i]], rows of bytes_per_row bytes, device pointers, stream order), and
+ * ohmhip_comm_exchange_side is the all-to-all of ohmhip_comm_exchange_rays for bytes_per_ray bytes per ray with the
+ * same counts.  Both exchange calls validate their arguments before the collective starts: an invalid call returns
+ * OHMHIP_ERR_INVALID_ARG without having taken part in it. */
+int ohmhip_comm_exchange_side(ohmhip_comm_t comm, const void *d_send, const uint32_t *send_counts, void *d_recv,
+                              const uint32_t *recv_counts, uint32_t bytes_per_ray, ohmhip_stream_t stream);
+int ohmhip_gather_rows(const void *d_src, const uint32_t *d_index, size_t count, uint32_t bytes_per_row, void *d_dst,
+                       ohmhip_stream_t stream);
 
 typedef struct ohmhip_merge_stats
 {

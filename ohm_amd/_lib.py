@@ -135,6 +135,10 @@ _sigs = {
     "ohmhip_transform_samples": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_double, _vp, _vp,
                                            C.POINTER(C.c_uint32)]),
     "ohmhip_map_batch_timings": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_float)]),
+    "ohmhip_comm_exchange_side": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp]),
+    "ohmhip_gather_rows": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
+    "ohmhip_map_set_first_ray_time": (C.c_int, [_vp, C.c_double]),
+    "ohmhip_map_first_ray_time": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "ohmhip_map_set_phase_timing": (C.c_int, [_vp, C.c_int]),
     "ohmhip_map_batches_launched": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ohmhip_map_line_keys": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),

@@ -48,6 +48,7 @@ struct BatchRun
   uint32_t event_capacity = 0, n_events = 0;
   float *direct_occ = nullptr;
   uint32_t direct_segments = 0;
+  uint32_t sort_covers = 0;  ///< the per-region sort launched so far orders regions of up to this many samples
   bool batch_end_marked = false;  ///< tev[4] is the stop event of the batch's last kernel already
 
   /// The batch recorded (or bound to a kernel) event k of its ring entry.
@@ -158,14 +159,42 @@ struct BatchRun
     m->bin_done_event = tev[1];
   }
 
-  void launchRegionSort()
+  /// Order the regions' sample lists.  Small regions (nearly all) by 256-thread workgroups, the dense ones by the
+  /// 1024-thread, 66 KiB instantiation -- launched only when some region needs it, and FIRST: it starts the moment the
+  /// binning pass ends, ahead of the next batch's set-up pass (which reaches the device ~15 us later through its event),
+  /// whereas launched second its workgroups queued behind that pass for a CU's LDS and held the walk back by 50-90 us.
+  /// `dense` = the densest region's sample count (the previous batch's when the launch is speculative: binAndOrder adds
+  /// the dense launch once the batch's own summary asks for it).  tev[2], the end of the ordering phase, is the stop event
+  /// of the phase's last launch.
+  void launchRegionSort(uint32_t dense)
   {
-    hipExtLaunchKernelGGL(k_sort_region_hits, dim3(4 * m->walk_workgroups), dim3(kSortThreads), 0, s, nullptr, tev[2],
-                          0, regionTable(m), batchScratch(m),
-                          static_cast<const unsigned long long *>(m->hit_keys_a.ptr),
-                          static_cast<unsigned long long *>(m->hit_keys_b.ptr), m->mc.region_voxels);
+    const unsigned long long *in = static_cast<const unsigned long long *>(m->hit_keys_a.ptr);
+    unsigned long long *out = static_cast<unsigned long long *>(m->hit_keys_b.ptr);
+    const bool need_dense = kSortSmallHits == 0 || dense > kSortSmallHits;
+    if (need_dense)
+    {
+      hipExtLaunchKernelGGL((k_sort_region_hits<kSortRegionHits, kSortThreads>), dim3(2 * m->walk_workgroups),
+                            dim3(kSortThreads), 0, s, nullptr, kSortSmallHits ? nullptr : tev[2], 0, regionTable(m),
+                            batchScratch(m), in, out, m->mc.region_voxels, kSortSmallHits);
+    }
+    if (kSortSmallHits)
+    {
+      hipExtLaunchKernelGGL((k_sort_region_hits<kSortSmallHits ? kSortSmallHits : 64u, kSortSmallThreads>),
+                            dim3(8 * m->walk_workgroups), dim3(kSortSmallThreads), 0, s, nullptr, tev[2], 0,
+                            regionTable(m), batchScratch(m), in, out, m->mc.region_voxels, 0u);
+    }
+    sort_covers = need_dense ? kSortRegionHits : kSortSmallHits;
     mark(2);
     m->tev_pre_walk[ring] = 2;
+  }
+
+  void launchDenseSort()
+  {
+    hipExtLaunchKernelGGL((k_sort_region_hits<kSortRegionHits, kSortThreads>), dim3(2 * m->walk_workgroups),
+                          dim3(kSortThreads), 0, s, nullptr, tev[2], 0, regionTable(m), batchScratch(m),
+                          static_cast<const unsigned long long *>(m->hit_keys_a.ptr),
+                          static_cast<unsigned long long *>(m->hit_keys_b.ptr), m->mc.region_voxels, kSortSmallHits);
+    sort_covers = kSortRegionHits;
   }
 
   int frontHalf()
@@ -184,6 +213,9 @@ struct BatchRun
     }
     if (m->bin_done_event)
     {
+      // (round 5, with the event markers gone: letting the pass start with the previous batch's binning pass instead of
+      // behind it was measured again -- 0.951 against 0.883 ms per C1 batch: the two slow each other down by more than
+      // the ~15 us the event hand-over costs)
       OHMHIP_CHECK(hipStreamWaitEvent(f, m->bin_done_event, 0));
     }
     if (attempt > 0 || !info_clean)
@@ -237,7 +269,7 @@ struct BatchRun
     if (speculated)
     {
       launchBin(true, spec_seg_cap, static_cast<unsigned long long *>(m->hit_keys_a.ptr));
-      launchRegionSort();
+      launchRegionSort(m->spec_max_region_hits);
     }
     OHMHIP_CHECK(hipEventSynchronize(plan_done));
     OHMHIP_CHECK(hipGetLastError());
@@ -368,6 +400,7 @@ struct BatchRun
     // region holds more samples than that kernel's LDS takes (then: ray-order keys + device-wide radix sort).
     bucket_hits = occupancy_mode && info.max_region_hits <= kSortRegionHits;
     m->spec_bucket_ok = bucket_hits;
+    m->spec_max_region_hits = info.max_region_hits;
     if (m->debug_flags & 4096u)
     {
       std::fprintf(stderr, "[ohmhip dbg] batch: %u rays, %u segments, %u chunks, %u regions touched, %u with samples, "
@@ -375,6 +408,10 @@ struct BatchRun
                    info.n_touched, info.n_hit_regions, info.max_region_hits, int(speculated));
     }
     sorted = keys_b;
+    if (speculated && info.max_region_hits > sort_covers)
+    {
+      launchDenseSort();  // (the speculative launch counted on the previous batch's densest region)
+    }
     if (!speculated)
     {
       launchBin(bucket_hits, seg_cap, keys_a);
@@ -389,7 +426,7 @@ struct BatchRun
       {
         if (info.n_hit_regions)
         {
-          launchRegionSort();
+          launchRegionSort(info.max_region_hits);
         }
       }
       else if (occupancy_mode)
@@ -579,6 +616,11 @@ struct BatchRun
   int replayEvents()
   {
     const size_t total = size_t(n_rays) + size_t(n_events);
+    // The device-wide one-sweep radix sort.  Round 5 built two replacements that order the keys without it -- bucket by
+    // voxel row (histogram, scan, scatter), then an LDS bitonic sort per unit of <= 4096 keys, with the replay either
+    // fused into that kernel or run by the kernels below --, both bit exact, neither faster: C2 1.09 ms against 1.05,
+    // C3 11.2 against 10.3 (profiles/r05_event_buckets.txt).  Per-key global atomics of the two bucketing
+    // passes cost what the sort's passes cost, and the fused replay loses the occupancy the long voxel chains need.
     size_t sort_bytes = 0;
     OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(nullptr, sort_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
     OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));

@@ -233,6 +233,7 @@ struct ohmhip_map_s
   uint32_t event_demand = 0;
   uint32_t event_limit = 0;  ///< OHMHIP_EVENT_LIMIT (tests): cap of the NDT / TSDF event list's first sizing
   bool spec_bucket_ok = false;  ///< the previous occupancy batch used the per-region sample sort: bin speculatively
+  uint32_t spec_max_region_hits = 0;  ///< ... and its densest region held this many samples (which sort kernels to launch)
   double segments_per_ray = 10.0;            ///< running estimate (previous batch) used to size the next batch's chunks
   uint32_t bin_rays_per_block = kBinRaysPerBlock;  ///< tunable (OHMHIP_BIN_RAYS): rays per binning workgroup, large batches
   uint32_t min_chunk_segments = 2048;  ///< tunable (OHMHIP_MIN_CHUNK_SEGMENTS): floor of the small-batch chunk size (two rounds of the walk workgroup's 1024 lanes)

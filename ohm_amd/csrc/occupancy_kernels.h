@@ -1386,12 +1386,22 @@ __device__ inline void bitonicFused(unsigned long long *l_keys, uint32_t g, uint
 
 constexpr uint32_t kSortRegionHits = 8192;
 constexpr int kSortThreads = 1024;
+#ifndef OHMHIP_SORT_SMALL
+#define OHMHIP_SORT_SMALL 2048  // regions with at most this many samples are ordered by 256-thread workgroups (0: off)
+#endif
+constexpr uint32_t kSortSmallHits = OHMHIP_SORT_SMALL;
+constexpr int kSortSmallThreads = 256;
 
-__global__ void __launch_bounds__(kSortThreads)
+/// kCap / kThreads: the instantiation's LDS capacity in keys and workgroup size; it orders the regions of the list with
+/// min_hits < samples <= kCap.  The network of a region with ~10^3 samples keeps 128 lanes busy per fused stage: the
+/// 1024-thread, 66 KiB instantiation (two workgroups per CU) spends its time in barriers of mostly idle waves, so regions
+/// of at most kSortSmallHits samples -- nearly all of them -- go to a 256-thread, 17 KiB one that runs eight per CU.
+template <uint32_t kCap, int kThreads>
+__global__ void __launch_bounds__(kThreads)
   k_sort_region_hits(RegionTable rt, BatchScratch bs, const unsigned long long *__restrict__ keys,
-                     unsigned long long *__restrict__ sorted, int region_voxels)
+                     unsigned long long *__restrict__ sorted, int region_voxels, uint32_t min_hits)
 {
-  __shared__ unsigned long long l_keys[kSortRegionHits + kSortRegionHits / 32];
+  __shared__ unsigned long long l_keys[kCap + kCap / 32];
   // Grid-stride over the list (its length lives on the device: the launch may be issued before the host knows it).
   const uint32_t n_regions = bs.info->n_hit_regions;
   for (uint32_t list_index = blockIdx.x; list_index < n_regions; list_index += gridDim.x)
@@ -1404,7 +1414,7 @@ __global__ void __launch_bounds__(kSortThreads)
   }
   const uint32_t begin = bs.hit_begin[slot];
   const uint32_t n = bs.hit_end[slot] - begin;
-  if (n == 0 || n > kSortRegionHits)
+  if (n <= min_hits || n > kCap)
   {
     continue;
   }
@@ -1413,7 +1423,7 @@ __global__ void __launch_bounds__(kSortThreads)
   {
     padded <<= 1;
   }
-  for (uint32_t i = threadIdx.x; i < padded; i += kSortThreads)
+  for (uint32_t i = threadIdx.x; i < padded; i += kThreads)
   {
     l_keys[sortSlot(i)] = (i < n) ? keys[begin + i] : ~0ull;
   }
@@ -1431,7 +1441,7 @@ __global__ void __launch_bounds__(kSortThreads)
       const uint32_t r = min(3u, levels_left);
       const uint32_t s_shift = levels_left - r;  // log2 of the smallest distance s
       const uint32_t group_count = padded >> r;
-      for (uint32_t g = threadIdx.x; g < group_count; g += kSortThreads)
+      for (uint32_t g = threadIdx.x; g < group_count; g += kThreads)
       {
         if (r == 3)
         {
@@ -1450,7 +1460,7 @@ __global__ void __launch_bounds__(kSortThreads)
       j >>= r;
     }
   }
-  for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
+  for (uint32_t i = threadIdx.x; i < n; i += kThreads)
   {
     const unsigned long long key = l_keys[sortSlot(i)];
     sorted[begin + i] = key;

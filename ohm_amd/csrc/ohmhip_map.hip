@@ -702,6 +702,32 @@ try
 }
 OHMHIP_ABI_CATCH
 
+int ohmhip_map_set_first_ray_time(ohmhip_map_t m, double time)
+try
+{
+  if (!m)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);  // batches already presented keep the base they were presented under
+  m->first_ray_time = time;
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_map_first_ray_time(ohmhip_map_t m, double *time)
+try
+{
+  if (!m || !time)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);
+  *time = m->first_ray_time;
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
 int ohmhip_map_batches_launched(ohmhip_map_t m, uint64_t *count)
 try
 {

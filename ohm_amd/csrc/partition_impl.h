@@ -369,6 +369,12 @@ try
   OHMHIP_CHECK(hipMemsetAsync(d_visits, 0, sizeof(unsigned long long), s));
   // A batch the caller filtered (ohmhip_map_integrate_rays_filtered) carries per-ray flags that do not travel with routed
   // rays: the routing applies the map's own ray filter, like the integration of the routed rays will.
+  // (The map's launch thread -- ohmhip_map_set_async_launch -- writes per-batch fields of m->mc while it launches: the
+  // copy is taken once that thread is idle; its status stays with the map for the next settling call.  ADVICE r4.)
+  if (m->launch_busy)
+  {
+    m->launch_thread->wait();
+  }
   MapConst mc = m->mc;
   mc.batch_filter_flags = nullptr;
   hipLaunchKernelGGL(k_route_mask, dim3(blocks), dim3(kRouteThreads), 0, s, mc, d_rays, n, ray_flags,
@@ -415,6 +421,20 @@ try
   std::vector<uint32_t> host(size_t(world) * world);
   OHMHIP_CHECK(hipMemcpyAsync(host.data(), matrix, sizeof(uint32_t) * host.size(), hipMemcpyDeviceToHost, s));
   OHMHIP_CHECK(hipStreamSynchronize(s));
+  // A rank whose local step failed (routing error, no memory ...) reports OHMHIP_COUNT_FAILED for every destination
+  // instead of counts: every rank sees it here, in the same call, and none goes on to the payload exchange (ADVICE r4:
+  // the peers of a failing rank used to block in the next collective).
+  for (size_t i = 0; i < host.size(); ++i)
+  {
+    if (host[i] == OHMHIP_COUNT_FAILED)
+    {
+      for (int src = 0; src < world; ++src)
+      {
+        recv_counts[src] = 0;
+      }
+      return OHMHIP_ERR_PEER;
+    }
+  }
   for (int src = 0; src < world; ++src)
   {
     recv_counts[src] = host[size_t(src) * world + comm->rank];  // what rank `src` addressed to this rank
@@ -423,16 +443,56 @@ try
 }
 OHMHIP_ABI_CATCH
 
-int ohmhip_comm_exchange_rays(ohmhip_comm_t comm, const double *d_send, const uint32_t *send_counts, double *d_recv,
-                              const uint32_t *recv_counts, ohmhip_stream_t stream)
-try
+}  // extern "C"
+
+namespace
 {
-  if (!comm || !send_counts || !recv_counts)
+/// dst row i = src row index[i] (rows of `row_bytes` bytes, 4-byte granularity when the size allows).
+__global__ void __launch_bounds__(256)
+  k_gather_rows(const unsigned char *__restrict__ src, const uint32_t *__restrict__ index, uint32_t count,
+                uint32_t row_bytes, unsigned char *__restrict__ dst)
+{
+  const uint32_t words = (row_bytes % 4u == 0u) ? row_bytes / 4u : 0u;
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  if (words)
+  {
+    const size_t total = size_t(count) * words;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride)
+    {
+      const uint32_t row = uint32_t(i / words), w = uint32_t(i % words);
+      reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[size_t(index[row]) * words + w];
+    }
+    return;
+  }
+  const size_t total = size_t(count) * row_bytes;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride)
+  {
+    const uint32_t row = uint32_t(i / row_bytes), b = uint32_t(i % row_bytes);
+    dst[i] = src[size_t(index[row]) * row_bytes + b];
+  }
+}
+
+/// The all-to-all of one per-ray array (rays: 48 bytes per ray; time stamps: 8; intensities: 4) over ncclSend / ncclRecv
+/// in one group.  Everything that can be wrong with the arguments is found BEFORE the group starts: a rank
+/// that has entered the collective goes through with it.
+int exchangeBytes(ohmhip_comm_t comm, const unsigned char *d_send, const uint32_t *send_counts, unsigned char *d_recv,
+                  const uint32_t *recv_counts, size_t bytes_per_ray, hipStream_t s)
+{
+  if (!comm || !send_counts || !recv_counts || bytes_per_ray == 0)
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
   const int world = comm->world;
-  hipStream_t s = stream ? stream->stream : nullptr;
+  size_t send_total = 0, recv_total = 0;
+  for (int peer = 0; peer < world; ++peer)
+  {
+    send_total += send_counts[peer];
+    recv_total += recv_counts[peer];
+  }
+  if ((send_total && !d_send) || (recv_total && !d_recv) || send_counts[comm->rank] != recv_counts[comm->rank])
+  {
+    return OHMHIP_ERR_INVALID_ARG;  // (the block a rank addresses to itself never leaves the device: same size both ways)
+  }
   size_t send_at = 0, recv_at = 0, self_send = 0, self_recv = 0;
   OHMHIP_CHECK(ncclStatus(ncclGroupStart()));
   int err = OHMHIP_OK;
@@ -447,11 +507,13 @@ try
     {
       if (send_counts[peer])
       {
-        err = ncclStatus(ncclSend(d_send + send_at * 6, size_t(send_counts[peer]) * 6, ncclDouble, peer, comm->comm, s));
+        err = ncclStatus(ncclSend(d_send + send_at * bytes_per_ray, size_t(send_counts[peer]) * bytes_per_ray, ncclUint8,
+                                  peer, comm->comm, s));
       }
       if (err == OHMHIP_OK && recv_counts[peer])
       {
-        err = ncclStatus(ncclRecv(d_recv + recv_at * 6, size_t(recv_counts[peer]) * 6, ncclDouble, peer, comm->comm, s));
+        err = ncclStatus(ncclRecv(d_recv + recv_at * bytes_per_ray, size_t(recv_counts[peer]) * bytes_per_ray, ncclUint8,
+                                  peer, comm->comm, s));
       }
     }
     send_at += send_counts[peer];
@@ -460,17 +522,54 @@ try
   const int end_err = ncclStatus(ncclGroupEnd());
   OHMHIP_CHECK(err);
   OHMHIP_CHECK(end_err);
-  // the rays a rank addressed to itself never leave the device
-  if (send_counts[comm->rank] != recv_counts[comm->rank])
+  if (send_counts[comm->rank])
+  {
+    OHMHIP_CHECK(hipMemcpyAsync(d_recv + self_recv * bytes_per_ray, d_send + self_send * bytes_per_ray,
+                                bytes_per_ray * size_t(send_counts[comm->rank]), hipMemcpyDeviceToDevice, s));
+  }
+  return OHMHIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ohmhip_comm_exchange_rays(ohmhip_comm_t comm, const double *d_send, const uint32_t *send_counts, double *d_recv,
+                              const uint32_t *recv_counts, ohmhip_stream_t stream)
+try
+{
+  return exchangeBytes(comm, reinterpret_cast<const unsigned char *>(d_send), send_counts,
+                       reinterpret_cast<unsigned char *>(d_recv), recv_counts, 6 * sizeof(double),
+                       stream ? stream->stream : nullptr);
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_comm_exchange_side(ohmhip_comm_t comm, const void *d_send, const uint32_t *send_counts, void *d_recv,
+                              const uint32_t *recv_counts, uint32_t bytes_per_ray, ohmhip_stream_t stream)
+try
+{
+  return exchangeBytes(comm, static_cast<const unsigned char *>(d_send), send_counts, static_cast<unsigned char *>(d_recv),
+                       recv_counts, bytes_per_ray, stream ? stream->stream : nullptr);
+}
+OHMHIP_ABI_CATCH
+
+int ohmhip_gather_rows(const void *d_src, const uint32_t *d_index, size_t count, uint32_t bytes_per_row, void *d_dst,
+                       ohmhip_stream_t stream)
+try
+{
+  if (count == 0)
+  {
+    return OHMHIP_OK;
+  }
+  if (!d_src || !d_index || !d_dst || bytes_per_row == 0 || count > 0xffffffffull)
   {
     return OHMHIP_ERR_INVALID_ARG;
   }
-  if (send_counts[comm->rank])
-  {
-    OHMHIP_CHECK(hipMemcpyAsync(d_recv + self_recv * 6, d_send + self_send * 6,
-                                sizeof(double) * 6 * size_t(send_counts[comm->rank]), hipMemcpyDeviceToDevice, s));
-  }
-  return OHMHIP_OK;
+  const size_t units = count * size_t((bytes_per_row % 4u == 0u) ? bytes_per_row / 4u : bytes_per_row);
+  const uint32_t blocks = uint32_t(std::min<size_t>((units + 255) / 256, 65535));
+  hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, stream ? stream->stream : nullptr,
+                     static_cast<const unsigned char *>(d_src), d_index, uint32_t(count), bytes_per_row,
+                     static_cast<unsigned char *>(d_dst));
+  return int(hipGetLastError());
 }
 OHMHIP_ABI_CATCH
 

@@ -85,6 +85,29 @@ int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_cou
   default:
     break;
   }
+  if (err == OHMHIP_ERR_CAPACITY && m->spill_enabled && n_rays >= 2 && !m->layers[OHMHIP_LID_TRAVERSAL])
+  {
+    // The batch alone touches more regions than the residency limit leaves room for (even with everything else moved
+    // to the host store).  The reference meets a full cache in the middle of a batch by finalising what it has
+    // enqueued and carrying on with the rest (ohmgpu/GpuMap.cpp:900-996, enqueueRegions' flush / retry); the
+    // counterpart here: the failed attempt left the map as it was, so the batch is presented again as two halves in
+    // ray order -- the CPU mappers integrate ray by ray, a batch boundary means nothing to them (except for the
+    // traversal layer, whose exit range is carried within a call: such maps keep failing cleanly).
+    const size_t half = n_rays / 2;
+    size_t done_a = 0, done_b = 0;
+    err = integrateRaysDevice(m, d_rays, half * 2, d_intensities, d_timestamps, ray_flags, &done_a, d_filter_flags);
+    if (err == OHMHIP_OK)
+    {
+      err = integrateRaysDevice(m, d_rays + half * 6, (n_rays - half) * 2, d_intensities ? d_intensities + half : nullptr,
+                                d_timestamps ? d_timestamps + half : nullptr, ray_flags, &done_b,
+                                d_filter_flags ? d_filter_flags + half : nullptr);
+    }
+    if (integrated)
+    {
+      *integrated = done_a + done_b;  // (what the first half integrated stays integrated if the second fails)
+    }
+    return err;
+  }
   if (err == OHMHIP_OK && integrated)
   {
     *integrated = size_t(m->stats.rays_integrated) * 2;

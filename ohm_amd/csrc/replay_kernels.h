@@ -93,18 +93,28 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------------------------------------
 // NDT: RayMapperNdt::integrateRays per-voxel semantics (ohm/RayMapperNdt.cpp:135-230 misses, :262-402 sample).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128)
-  k_replay_ndt(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
-               const double *__restrict__ rays, const float *__restrict__ intensities, float *__restrict__ occupancy,
-               uint32_t *__restrict__ mean_layer, float *__restrict__ cov_layer, float *__restrict__ intensity_layer,
-               uint32_t *__restrict__ hit_miss_layer, SecondaryLayers sec, const RayWalk *__restrict__ walks,
-               const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads)
+/// The layers an NDT replay reads and writes.
+struct NdtLayers
 {
-  // One lane per voxel group (k_group_heads), grid-stride.
-  const uint32_t head_count = *n_heads;
-  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < head_count; h += gridDim.x * blockDim.x)
-  {
-  const uint32_t i = heads[h];
+  float *occupancy;
+  uint32_t *mean;
+  float *covariance;
+  float *intensity;    ///< NDT-TM only (null otherwise, together with hit_miss)
+  uint32_t *hit_miss;
+};
+
+/// Replay ONE voxel group -- the events sorted[i .. ) that share sorted[i]'s (slot, voxel), in ray order -- on the
+/// voxel's state.
+__device__ inline void replayNdtGroup(const MapConst &mc, const RegionTable &rt, const unsigned long long *sorted,
+                                      uint32_t i, uint32_t n_events, const double *__restrict__ rays,
+                                      const float *__restrict__ intensities, const NdtLayers &ly,
+                                      const SecondaryLayers &sec, const RayWalk *__restrict__ walks)
+{
+  float *occupancy = ly.occupancy;
+  uint32_t *mean_layer = ly.mean;
+  float *cov_layer = ly.covariance;
+  float *intensity_layer = ly.intensity;
+  uint32_t *hit_miss_layer = ly.hit_miss;
   const unsigned long long key = sorted[i];
   const unsigned long long group = key >> kHitRayBits;
   const uint32_t slot = uint32_t(key >> kHitSlotShift);
@@ -223,29 +233,34 @@ __global__ void __launch_bounds__(128)
     hit_miss_layer[2 * gi] = hm_hit;
     hit_miss_layer[2 * gi + 1] = hm_miss;
   }
-  }  // voxel groups
+}
+
+__global__ void __launch_bounds__(128)
+  k_replay_ndt(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
+               const double *__restrict__ rays, const float *__restrict__ intensities, float *__restrict__ occupancy,
+               uint32_t *__restrict__ mean_layer, float *__restrict__ cov_layer, float *__restrict__ intensity_layer,
+               uint32_t *__restrict__ hit_miss_layer, SecondaryLayers sec, const RayWalk *__restrict__ walks,
+               const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads)
+{
+  // One lane per voxel group (k_group_heads), grid-stride.
+  const NdtLayers ly{ occupancy, mean_layer, cov_layer, intensity_layer, hit_miss_layer };
+  const uint32_t head_count = *n_heads;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < head_count; h += gridDim.x * blockDim.x)
+  {
+    replayNdtGroup(mc, rt, sorted, heads[h], n_events, rays, intensities, ly, sec, walks);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // TSDF: RayMapperTsdf::integrateRays per-voxel semantics (ohm/RayMapperTsdf.cpp:105-160).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128)
-  k_replay_tsdf(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
-                const double *__restrict__ rays, float *__restrict__ tsdf_layer, const uint32_t *__restrict__ heads,
-                const uint32_t *__restrict__ n_heads)
+/// Replay ONE voxel group of TSDF events (see replayNdtGroup).
+__device__ inline void replayTsdfGroup(const MapConst &mc, const RegionTable &rt, const unsigned long long *sorted,
+                                       uint32_t i, uint32_t n_events, const double *__restrict__ rays,
+                                       float *__restrict__ tsdf_layer)
 {
-  // Grid-stride over the compacted voxel-group heads (k_group_heads) or, with heads == nullptr, over all events with
-  // the non-heads skipped (TSDF groups are short: the compaction pass costs more than it saves there).
-  const uint32_t head_count = heads ? *n_heads : n_events;
-  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < head_count; h += gridDim.x * blockDim.x)
-  {
-  const uint32_t i = heads ? heads[h] : h;
   const unsigned long long key = sorted[i];
   const unsigned long long group = key >> kHitRayBits;
-  if (!heads && (key == kHitInvalid || (i > 0 && (sorted[i - 1] >> kHitRayBits) == group)))
-  {
-    continue;
-  }
   const uint32_t slot = uint32_t(key >> kHitSlotShift);
   const uint32_t vi = uint32_t(key >> kHitRayBits) & ((1u << kHitVoxelBits) - 1u);
   const size_t gi = size_t(slot) * size_t(mc.region_voxels) + vi;
@@ -270,7 +285,26 @@ __global__ void __launch_bounds__(128)
   }
   tsdf_layer[2 * gi] = weight;
   tsdf_layer[2 * gi + 1] = distance;
-  }  // voxel groups
+}
+
+__global__ void __launch_bounds__(128)
+  k_replay_tsdf(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
+                const double *__restrict__ rays, float *__restrict__ tsdf_layer, const uint32_t *__restrict__ heads,
+                const uint32_t *__restrict__ n_heads)
+{
+  // Grid-stride over the compacted voxel-group heads (k_group_heads) or, with heads == nullptr, over all events with
+  // the non-heads skipped (TSDF groups are short: the compaction pass costs more than it saves there).
+  const uint32_t head_count = heads ? *n_heads : n_events;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < head_count; h += gridDim.x * blockDim.x)
+  {
+    const uint32_t i = heads ? heads[h] : h;
+    const unsigned long long key = sorted[i];
+    if (!heads && (key == kHitInvalid || (i > 0 && (sorted[i - 1] >> kHitRayBits) == (key >> kHitRayBits))))
+    {
+      continue;
+    }
+    replayTsdfGroup(mc, rt, sorted, i, n_events, rays, tsdf_layer);
+  }
 }
 
 /// TSDF: one block per touched region: voxels which only saw free-space visits this batch (count n, none flagged):

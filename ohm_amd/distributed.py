@@ -495,11 +495,26 @@ def exchange_routed_rays(routed, counts, group=None):
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
     recv_counts = [int(c) for c in recv.tolist()]
+    # (a rank whose local step failed sends -1 to EVERY rank -- PartitionedIntegrator._announce_failure -- so every rank
+    # sees it here, in the same call, and none goes on to the payload exchange)
+    if min(recv_counts) < 0:
+        raise RuntimeError("partitioned step: a peer rank reported a local failure (OHMHIP_ERR_PEER); no rays exchanged")
     out = torch.empty((sum(recv_counts), 6), dtype=routed.dtype, device=routed.device)
     dist.all_to_all_single(out.view(-1), routed.reshape(-1, 6)[:int(sum(int(c) for c in counts))].reshape(-1),
                            [6 * c for c in recv_counts], [6 * int(c) for c in counts], group=group)
     assert len(recv_counts) == world
     return out, recv_counts
+
+
+def exchange_routed_side(block, counts, recv_counts, group=None):
+    """The all-to-all of exchange_routed_rays for a per-ray side array (time stamps: float64, intensities: float32): `block`
+    is a 1-D tensor in routed order, `counts` / `recv_counts` the rays per destination / source the ray exchange used."""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty((int(sum(recv_counts)),), dtype=block.dtype, device=block.device)
+    dist.all_to_all_single(out, block[:int(sum(int(c) for c in counts))].contiguous(), [int(c) for c in recv_counts],
+                           [int(c) for c in counts], group=group)
+    return out
 
 
 class PartitionedIntegrator:
@@ -527,6 +542,11 @@ class PartitionedIntegrator:
         # their buffers.  Each buffer remembers the launch count its batch made; it is free once two more were launched.
         self._recv = [None, None, None]
         self._recv_batch = [0, 0, 0]
+        # side arrays (time stamps, intensities) travel with the rays: routed-order staging and per-slot receive buffers
+        self._index = None
+        self._time_base_set = False
+        self._side_send = {}
+        self._side_recv = [{}, {}, {}]
         self._xstream = None
         self.last = {}
 
@@ -562,15 +582,76 @@ class PartitionedIntegrator:
             self._recv[slot] = t
         return t
 
-    def route(self, d_rays, n_rays, ray_update_flags=0):
-        """Route `n_rays` rays at device pointer `d_rays`; returns (routed tensor, counts, visits)."""
+    def route(self, d_rays, n_rays, ray_update_flags=0, with_index=False):
+        """Route `n_rays` rays at device pointer `d_rays`; returns (routed tensor, counts, visits).  with_index: the
+        index of every routed ray in the input is kept in self._index (device int32 tensor) for the side arrays."""
+        import torch
         routed = self._ensure_routed(2 * n_rays)
         while True:
+            d_index = None
+            if with_index:
+                if self._index is None or self._index.shape[0] < routed.shape[0]:
+                    self._index = torch.empty((routed.shape[0],), dtype=torch.int32, device="cuda")
+                d_index = self._index.data_ptr()
             counts, visits, fits = self.gpu_map.routeRays(d_rays, n_rays, routed.data_ptr(), routed.shape[0],
-                                                          ray_update_flags)
+                                                          ray_update_flags, d_index=d_index)
             if fits:
                 return routed, counts, visits
             routed = self._ensure_routed(int(counts.sum()))
+
+    def _announce_failure(self, counts):
+        """Take part in the step's count exchange with the failure marker (every rank then leaves the step together)."""
+        from . import _lib as L
+        marker = np.full(len(counts), 0xffffffff, dtype=np.uint32)
+        if self.comm is not None:
+            got = np.zeros_like(marker)
+            L.lib.ohmhip_comm_exchange_counts(self.comm._handle, marker.ctypes.data, got.ctypes.data,
+                                              self._exchange_stream())
+        else:
+            import torch
+            import torch.distributed as dist
+            device = "cpu" if dist.get_backend(self.group) == "gloo" else "cuda"
+            send = torch.full((len(counts),), -1, dtype=torch.int64, device=device)
+            dist.all_to_all_single(torch.empty_like(send), send, group=self.group)
+
+    def _agree_on_time_base(self, d_first_stamp):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib as L
+        first = np.array([np.nan], dtype=np.float64)
+        if d_first_stamp is not None:
+            tmp = L._vp()
+            L.check(L.lib.ohmhip_buffer_create(C.byref(tmp), 8, 3), "buffer_create")
+            ptr = L._vp()
+            L.check(L.lib.ohmhip_buffer_ptr(tmp, C.byref(ptr)))
+            idx = torch.zeros((1,), dtype=torch.int32, device="cuda")
+            torch.cuda.current_stream().synchronize()
+            L.check(L.lib.ohmhip_gather_rows(d_first_stamp, idx.data_ptr(), 1, 8, ptr, None), "gather_rows")
+            L.check(L.lib.ohmhip_device_synchronize(), "device_synchronize")
+            L.check(L.lib.ohmhip_buffer_read(tmp, first.ctypes.data, 8, 0, None, None, None), "buffer_read")
+            L.lib.ohmhip_buffer_destroy(tmp)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world > 1:
+            device = "cpu" if dist.get_backend(self.group) == "gloo" else "cuda"
+            mine = torch.tensor(first, dtype=torch.float64, device=device)
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=self.group)
+            stamps = [float(t.item()) for t in every]
+        else:
+            stamps = [float(first[0])]
+        known = [t for t in stamps if t == t]  # (NaN: that rank has no rays in this batch)
+        if known:
+            self.gpu_map.setFirstRayTime(known[0])
+            self._time_base_set = True
+
+    def _side_buffer(self, store, name, rays, dtype):
+        import torch
+        t = store.get(name)
+        if t is None or t.shape[0] < rays or t.dtype != dtype:
+            t = torch.empty((max(int(rays * 1.25) + 1024, 4096),), dtype=dtype, device="cuda")
+            store[name] = t
+        return t
 
     def integrateRays(self, local_rays, ray_update_flags=0):
         """local_rays: (2N, 3) float64 CUDA tensor (origin, sample pairs).  Collective.  Returns the number of points
@@ -581,21 +662,54 @@ class PartitionedIntegrator:
         torch.cuda.current_stream().synchronize()  # the library works on its own HIP streams
         return self.integrateRaysDevice(local.data_ptr(), 2 * local.shape[0], ray_update_flags)
 
-    def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=0):
+    def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=0, d_timestamps=None, d_intensities=None):
         """The same for a raw device pointer to element_count dvec3 (complete when the call is made; free again when the
-        call returns).  The batch the call launches is left in flight: GpuMap.wait() / syncVoxels() settle it."""
+        call returns).  d_timestamps / d_intensities: device pointers to one double / float per local ray; they are put
+        into routed order (ohmhip_gather_rows with the routing's index list), exchanged with the rays and handed to the
+        map with what arrives -- a partitioned NDT-TM map gets its intensities, a touch-time layer its stamps, exactly as
+        one map integrating the ranks' batches one after the other would.  The batch the call launches is left in flight:
+        GpuMap.wait() / syncVoxels() settle it."""
         import torch
         from . import _lib as L
         gm = self.gpu_map
         n_local = int(element_count) // 2
+        sides = [(name, ptr, dtype, size) for name, ptr, dtype, size in
+                 (("timestamps", d_timestamps, torch.float64, 8), ("intensities", d_intensities, torch.float32, 4))
+                 if ptr is not None]
+        if d_timestamps is not None and not self._time_base_set:
+            # One time base for the whole partitioned map (OccupancyMap::firstRayTime, the touch-time layer's zero): the
+            # first stamp of the lowest rank that has rays -- what ONE map integrating rank 0's batch, then rank 1's, ...
+            # would have taken.  Collective (an all-gather of one double per rank).
+            self._agree_on_time_base(d_timestamps if n_local else None)
         launched = gm.batchesLaunched()
         # (when the previous integrate call returned, every batch but the two launched last had ended)
         slot = next(i for i in range(3) if self._recv_batch[i] == 0 or self._recv_batch[i] + 2 <= launched)
         self._recv_batch[slot] = 0
-        routed, counts, visits = self.route(d_rays_ptr, n_local, ray_update_flags)
+        # A rank-local failure before the exchange (routing, buffers) must not leave the peers blocked in the collective:
+        # the rank still takes part in the COUNT exchange, with the failure marker instead of counts, so that every rank
+        # raises from this same call (ADVICE r4; include/ohmhip.h "FAILURE AGREEMENT").
+        local_failure = None
+        try:
+            routed, counts, visits = self.route(d_rays_ptr, n_local, ray_update_flags, with_index=bool(sides))
+        except Exception as exc:  # noqa: BLE001 -- re-raised below, after the peers have been told
+            local_failure = exc
+            world_size = self.partition.world_size
+            routed, counts, visits = self._ensure_routed(1), np.zeros(world_size, dtype=np.uint32), 0
+        if local_failure is not None:
+            self._announce_failure(counts)
+            raise local_failure
         sent = int(counts.sum())
+        # side arrays into routed order (the library's gather kernel on the exchange stream)
+        side_send = {}
+        xs = self._exchange_stream() if (self.comm is not None or sides) else None
+        for name, ptr, dtype, size in sides:
+            buf = self._side_buffer(self._side_send, name, sent, dtype)
+            L.check(L.lib.ohmhip_gather_rows(ptr, self._index.data_ptr(), sent, size, buf.data_ptr(), xs), "gather_rows")
+            side_send[name] = buf
+        if sides:
+            L.check(L.lib.ohmhip_stream_finish(xs), "stream_finish")
+        side_recv = {}
         if self.comm is not None:
-            xs = self._exchange_stream()
             send_counts = np.ascontiguousarray(counts, dtype=np.uint32)
             recv_counts = np.zeros_like(send_counts)
             L.check(L.lib.ohmhip_comm_exchange_counts(self.comm._handle, send_counts.ctypes.data,
@@ -604,12 +718,19 @@ class PartitionedIntegrator:
             recv = self._ensure_recv(slot, n_recv)
             L.check(L.lib.ohmhip_comm_exchange_rays(self.comm._handle, routed.data_ptr(), send_counts.ctypes.data,
                                                     recv.data_ptr(), recv_counts.ctypes.data, xs), "exchange_rays")
+            for name, ptr, dtype, size in sides:
+                got = self._side_buffer(self._side_recv[slot], name, n_recv, dtype)
+                L.check(L.lib.ohmhip_comm_exchange_side(self.comm._handle, side_send[name].data_ptr(),
+                                                        send_counts.ctypes.data, got.data_ptr(),
+                                                        recv_counts.ctypes.data, size, xs), "exchange_side")
+                side_recv[name] = got
             L.check(L.lib.ohmhip_stream_finish(xs), "stream_finish")  # (not the device: batches stay in flight)
             recv_counts = [int(c) for c in recv_counts]
         else:
             import torch.distributed as dist
             block = routed[:sent]
-            if dist.get_backend(self.group) == "gloo":
+            staged = dist.get_backend(self.group) == "gloo"
+            if staged:
                 got, recv_counts = exchange_routed_rays(block.cpu(), counts, self.group)
                 n_recv = got.shape[0]
                 recv = self._ensure_recv(slot, n_recv)
@@ -619,83 +740,145 @@ class PartitionedIntegrator:
                 n_recv = got.shape[0]
                 recv = got
                 self._recv[slot] = got  # stays alive while the batch reads it
+            for name, ptr, dtype, size in sides:
+                src = side_send[name][:sent]
+                arrived = exchange_routed_side(src.cpu() if staged else src, counts, recv_counts, self.group)
+                keep = self._side_buffer(self._side_recv[slot], name, n_recv, dtype)
+                keep[:n_recv].copy_(arrived)
+                side_recv[name] = keep
             torch.cuda.current_stream().synchronize()
         self.last = {"rays_local": n_local, "rays_routed": sent, "rays_kept": int(counts[self.partition.rank]),
                      "rays_received": n_recv, "recv_counts": recv_counts, "visits_local": visits}
         if n_recv == 0:
             return 0
-        done = gm.integrateRaysDevice(recv.data_ptr(), 2 * n_recv, ray_update_flags)
+        done = gm.integrateRaysDevice(recv.data_ptr(), 2 * n_recv, ray_update_flags,
+                                      d_intensities=side_recv["intensities"].data_ptr() if "intensities" in side_recv else None,
+                                      d_timestamps=side_recv["timestamps"].data_ptr() if "timestamps" in side_recv else None)
         after = gm.batchesLaunched()
         # (no launch: the call copied its rays behind the ones waiting and waited for the copy -- the buffer is free)
         self._recv_batch[slot] = after if after > launched else 0
         return done
 
 
-def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timings=None, streams_out=None):
+def integrate_partitioned_in_process(gpu_maps, shards, ray_update_flags=0, timings=None, streams_out=None,
+                                     timestamps=None, intensities=None):
     """The partitioned integration for several GpuMaps living in ONE process (stand-ins for ranks on a single GPU: tests,
     and bench.py's one-GPU C4 leg).  gpu_maps[r] carries rank r's partition (setRegionPartition); shards[r]: rank r's
-    (2N_r, 3) float64 host rays.  Every rank's rays are routed by its own map (the library's kernels), the blocks are
-    re-assembled per destination in (source rank, ray) order -- what the all-to-all delivers -- and integrated.  Returns
-    a dict of counts: rays routed per (source, destination), rays received per rank.  `streams_out` (a list) receives the
-    stream each rank integrated, as (k, 6) host arrays."""
+    (2N_r, 3) float64 host rays; timestamps[r] / intensities[r] (optional): rank r's per-ray float64 / float32 side
+    arrays.  Every rank's rays are routed by its own map (the library's kernels), its side arrays are put into routed
+    order on the device (ohmhip_gather_rows with the routing's index list -- what PartitionedIntegrator does before the
+    exchange), the blocks are re-assembled per destination in (source rank, ray) order -- what the all-to-all delivers --
+    and integrated.  Returns a dict of counts: rays routed per (source, destination), rays received per rank.
+    `streams_out` (a list) receives the stream each rank integrated, as (k, 6) host arrays."""
     import ctypes as C
     import time
     from . import _lib as L
     world = len(gpu_maps)
     blocks = [[None] * world for _ in range(world)]
+    side_blocks = {"timestamps": [[None] * world for _ in range(world)], "intensities": [[None] * world for _ in range(world)]}
+    side_in = {"timestamps": (timestamps, np.float64), "intensities": (intensities, np.float32)}
     matrix = np.zeros((world, world), dtype=np.int64)
     visits = []
+    if timestamps is not None:
+        # one time base for all ranks' maps: the first stamp of the lowest rank with rays (PartitionedIntegrator agrees on
+        # it with an all-gather); only while none is set yet
+        firsts = [float(np.asarray(t).reshape(-1)[0]) for t in timestamps if np.asarray(t).size]
+        for gm in gpu_maps:
+            if firsts and gm.firstRayTime() < 0:
+                gm.setFirstRayTime(firsts[0])
+
+    def device_copy(host):
+        buf, ptr = L._vp(), L._vp()
+        L.check(L.lib.ohmhip_buffer_create(C.byref(buf), max(host.nbytes, 48), 3), "buffer_create")
+        if host.nbytes:
+            L.check(L.lib.ohmhip_buffer_write(buf, host.ctypes.data, host.nbytes, 0, None, None, None), "buffer_write")
+        L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(ptr)))
+        return buf, ptr
+
     for r, (gm, rays) in enumerate(zip(gpu_maps, shards)):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         n = rays.shape[0]
-        src, out = L._vp(), L._vp()
-        L.check(L.lib.ohmhip_buffer_create(C.byref(src), max(rays.nbytes, 48), 3), "buffer_create")
-        L.check(L.lib.ohmhip_buffer_write(src, rays.ctypes.data, rays.nbytes, 0, None, None, None), "buffer_write")
+        src, d_src = device_copy(rays)
+        want_sides = [name for name, (arrays, _) in side_in.items() if arrays is not None]
+        out = idx = None
         cap = max(2 * n, 1024)
         while True:
+            out, d_out = L._vp(), L._vp()
             L.check(L.lib.ohmhip_buffer_create(C.byref(out), 48 * cap, 3), "buffer_create")
-            d_src, d_out = L._vp(), L._vp()
-            L.check(L.lib.ohmhip_buffer_ptr(src, C.byref(d_src)))
             L.check(L.lib.ohmhip_buffer_ptr(out, C.byref(d_out)))
+            d_idx = None
+            if want_sides:
+                idx, d_idx = L._vp(), L._vp()
+                L.check(L.lib.ohmhip_buffer_create(C.byref(idx), 4 * cap, 3), "buffer_create")
+                L.check(L.lib.ohmhip_buffer_ptr(idx, C.byref(d_idx)))
             if timings is not None:
                 gm.routeRays(d_src, n, d_out, cap, ray_update_flags)  # untimed: the map's routing buffers and stream
             t0 = time.perf_counter()
-            counts, v, fits = gm.routeRays(d_src, n, d_out, cap, ray_update_flags)
+            counts, v, fits = gm.routeRays(d_src, n, d_out, cap, ray_update_flags, d_index=d_idx)
             if timings is not None and fits:
                 timings.setdefault("route_ms", []).append(1e3 * (time.perf_counter() - t0))
             if fits:
                 break
             L.lib.ohmhip_buffer_destroy(out)
+            if idx is not None:
+                L.lib.ohmhip_buffer_destroy(idx)
             cap = int(counts.sum()) + 1024
         visits.append(v)
         total = int(counts.sum())
         host = np.zeros((total, 6), dtype=np.float64)
         if total:
             L.check(L.lib.ohmhip_buffer_read(out, host.ctypes.data, host.nbytes, 0, None, None, None), "buffer_read")
+        routed_sides = {}
+        for name in want_sides:
+            arrays, dtype = side_in[name]
+            values = np.ascontiguousarray(arrays[r], dtype=dtype).reshape(-1)
+            assert values.shape[0] == n, "one %s value per ray" % name
+            sbuf, d_side = device_copy(values)
+            gathered = np.zeros(total, dtype=dtype)
+            gbuf, d_gathered = device_copy(gathered)
+            L.check(L.lib.ohmhip_gather_rows(d_side, d_idx, total, values.itemsize, d_gathered, None), "gather_rows")
+            L.check(L.lib.ohmhip_device_synchronize(), "device_synchronize")
+            if total:
+                L.check(L.lib.ohmhip_buffer_read(gbuf, gathered.ctypes.data, gathered.nbytes, 0, None, None, None))
+            routed_sides[name] = gathered
+            L.lib.ohmhip_buffer_destroy(sbuf)
+            L.lib.ohmhip_buffer_destroy(gbuf)
         at = 0
         for d in range(world):
             blocks[r][d] = host[at:at + int(counts[d])]
+            for name in want_sides:
+                side_blocks[name][r][d] = routed_sides[name][at:at + int(counts[d])]
             matrix[r, d] = int(counts[d])
             at += int(counts[d])
         L.lib.ohmhip_buffer_destroy(src)
         L.lib.ohmhip_buffer_destroy(out)
+        if idx is not None:
+            L.lib.ohmhip_buffer_destroy(idx)
     integrated = []
     for d, gm in enumerate(gpu_maps):
         stream = np.concatenate([blocks[r][d] for r in range(world)]) if world else np.zeros((0, 6))
         if streams_out is not None:
             streams_out.append(stream)
         if stream.shape[0]:
-            buf, ptr = L._vp(), L._vp()
-            L.check(L.lib.ohmhip_buffer_create(C.byref(buf), stream.nbytes, 3), "buffer_create")
-            L.check(L.lib.ohmhip_buffer_write(buf, stream.ctypes.data, stream.nbytes, 0, None, None, None))
-            L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(ptr)))
+            buf, ptr = device_copy(stream)
+            extra_bufs, extra_ptrs = [], {}
+            for name, (arrays, dtype) in side_in.items():
+                if arrays is not None:
+                    b, p_ = device_copy(np.ascontiguousarray(np.concatenate([side_blocks[name][r][d] for r in range(world)]),
+                                                             dtype=dtype))
+                    extra_bufs.append(b)
+                    extra_ptrs[name] = p_
             gm.wait()
             t0 = time.perf_counter()
-            integrated.append(gm.integrateRaysDevice(ptr, 2 * stream.shape[0], ray_update_flags))
+            integrated.append(gm.integrateRaysDevice(ptr, 2 * stream.shape[0], ray_update_flags,
+                                                     d_intensities=extra_ptrs.get("intensities"),
+                                                     d_timestamps=extra_ptrs.get("timestamps")))
             gm.wait()
             if timings is not None:
                 timings.setdefault("integrate_ms", []).append(1e3 * (time.perf_counter() - t0))
             L.lib.ohmhip_buffer_destroy(buf)
+            for b in extra_bufs:
+                L.lib.ohmhip_buffer_destroy(b)
         else:
             integrated.append(0)
     return {"routed": matrix, "received": matrix.sum(axis=0), "integrated": integrated, "visits_local": visits}

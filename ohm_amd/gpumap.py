@@ -339,13 +339,15 @@ class GpuMap(RayMapper):
             return 0
         return int(done.value)
 
-    def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=RayFlag.kRfDefault):
-        """Rays already resident in HBM (bench path): d_rays_ptr is a raw device pointer to element_count dvec3.  The
-        array must be complete when the call is made (synchronise the stream that produced it): the map reads it on
-        streams of its own."""
+    def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=RayFlag.kRfDefault, d_intensities=None,
+                            d_timestamps=None):
+        """Rays already resident in HBM (bench path): d_rays_ptr is a raw device pointer to element_count dvec3
+        (d_intensities / d_timestamps: optional device pointers to one float / double per ray).  The arrays must be
+        complete when the call is made (synchronise the stream that produced them): the map reads them on streams of its
+        own."""
         done = C.c_size_t(0)
-        status = L.lib.ohmhip_map_integrate_rays_device(self._handle, d_rays_ptr, element_count, None, None,
-                                                        int(ray_update_flags), C.byref(done))
+        status = L.lib.ohmhip_map_integrate_rays_device(self._handle, d_rays_ptr, element_count, d_intensities,
+                                                        d_timestamps, int(ray_update_flags), C.byref(done))
         L.check(status, "GpuMap.integrateRaysDevice")
         return int(done.value)
 
@@ -359,6 +361,16 @@ class GpuMap(RayMapper):
         ms = (C.c_float * 4)()
         L.check(L.lib.ohmhip_map_batch_timings(self._handle, batches_back, ms), "batch_timings")
         return {"ms_total": ms[0], "ms_setup": ms[1], "ms_walk": ms[2], "ms_apply": ms[3]}
+
+    def setFirstRayTime(self, time):
+        """OccupancyMap::setFirstRayTime (ohm/OccupancyMap.h:346): the base the touch-time layer is encoded against.  The
+        ranks of a partitioned map share one (PartitionedIntegrator sets it from the first stamp of the whole job)."""
+        L.check(L.lib.ohmhip_map_set_first_ray_time(self._handle, float(time)), "set_first_ray_time")
+
+    def firstRayTime(self):
+        t = C.c_double(-1.0)
+        L.check(L.lib.ohmhip_map_first_ray_time(self._handle, C.byref(t)), "first_ray_time")
+        return float(t.value)
 
     def setPhaseTiming(self, enable=True):
         """Record the start markers of the set-up and binning passes too (ms_setup, and ms_total of a batch on its own as

@@ -547,6 +547,15 @@ public:
     ohmhip_map_batches_launched(handle_, &n);
     return n;
   }
+  /// OccupancyMap::setFirstRayTime / firstRayTime (ohm/OccupancyMap.h:342-351): the touch-time layer's time base; the
+  /// ranks of a partitioned map share one.
+  void setFirstRayTime(double time) { OHMHIP_GPUAPICHECK(ohmhip_map_set_first_ray_time(handle_, time)); }
+  double firstRayTime() const
+  {
+    double t = -1.0;
+    ohmhip_map_first_ray_time(handle_, &t);
+    return t;
+  }
   /// Start markers of the set-up and binning passes for lastBatchStats().ms_setup (a few microseconds per batch; off by
   /// default, see ohmhip_map_set_phase_timing).
   void setPhaseTiming(bool enable) { OHMHIP_GPUAPICHECK(ohmhip_map_set_phase_timing(handle_, enable ? 1 : 0)); }

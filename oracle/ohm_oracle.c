@@ -352,6 +352,12 @@ size_t oracle_region_keys(const OracleMap *m, int16_t *keys_xyz, size_t cap)
   return n;
 }
 
+/* OccupancyMap::setFirstRayTime (ohm/OccupancyMap.h:346): the touch-time base, set regardless of the current value. */
+void oracle_map_set_first_ray_time(OracleMap *m, double time)
+{
+  m->first_ray_time = time;
+}
+
 void *oracle_region_layer(OracleMap *m, int rx, int ry, int rz, int layer_id)
 {
   OracleChunk *c = table_find(m, rx, ry, rz);

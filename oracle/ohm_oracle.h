@@ -141,6 +141,7 @@ uint64_t oracle_map_visit_count(const OracleMap *map);
 /* Region enumeration / raw layer access (MapChunk layout: index = x + y*dx + z*dx*dy, ohm/MapChunk.h:33-50). */
 size_t oracle_region_count(const OracleMap *map);
 size_t oracle_region_keys(const OracleMap *map, int16_t *keys_xyz, size_t cap);
+void oracle_map_set_first_ray_time(OracleMap *m, double time);
 void *oracle_region_layer(OracleMap *map, int rx, int ry, int rz, int layer_id);
 size_t oracle_layer_voxel_bytes(int layer_id);
 

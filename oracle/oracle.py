@@ -76,6 +76,7 @@ lib.oracle_region_count.restype = C.c_size_t
 lib.oracle_region_count.argtypes = [_vp]
 lib.oracle_region_keys.restype = C.c_size_t
 lib.oracle_region_keys.argtypes = [_vp, _vp, C.c_size_t]
+lib.oracle_map_set_first_ray_time.argtypes = [_vp, C.c_double]
 lib.oracle_region_layer.restype = _vp
 lib.oracle_region_layer.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int]
 for _n in ("hit", "miss", "up", "down"):
@@ -219,6 +220,21 @@ class OracleMap:
         count = self.region_dim[0] * self.region_dim[1] * self.region_dim[2] * comps
         buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
         return np.frombuffer(buf, dtype=dtype).copy()
+
+    def set_first_ray_time(self, time):
+        """OccupancyMap::setFirstRayTime: the base the touch-time layer is encoded against."""
+        lib.oracle_map_set_first_ray_time(self._h, C.c_double(float(time)))
+
+    def region_layer_view(self, key, name):
+        """The live block itself (no copy): tests that restate a reference case which writes single voxels on the CPU
+        side (Voxel<T>::write in tests/ohmtestgpu) edit the oracle's map through it.  None for an unknown region."""
+        ptr = lib.oracle_region_layer(self._h, int(key[0]), int(key[1]), int(key[2]), LAYER_IDS[name])
+        if not ptr:
+            return None
+        dtype, comps = LAYER_DTYPES[name]
+        count = self.region_dim[0] * self.region_dim[1] * self.region_dim[2] * comps
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype)
 
     def chunks(self, names=None):
         names = names or self.layers

@@ -20,14 +20,21 @@ def ray_destinations(om, part, rays, include_end=False):
     return dests
 
 
-def route_reference(om, part, rays, world):
-    """(routed (k, 6) rays: destination blocks back to back, rays in order inside a block; counts per destination)."""
+def route_reference(om, part, rays, world, with_index=False):
+    """(routed (k, 6) rays: destination blocks back to back, rays in order inside a block; counts per destination[; the
+    index of every routed ray in the input -- what ohmhip_map_route_rays returns in d_routed_index and side arrays are
+    put into routed order with])."""
     rays = np.asarray(rays, dtype=np.float64).reshape(-1, 3)
     dests = ray_destinations(om, part, rays)
     blocks = [[] for _ in range(world)]
+    index = [[] for _ in range(world)]
     for i, ds in enumerate(dests):
         for d in ds:
             blocks[d].append(rays[2 * i:2 * i + 2].reshape(6))
+            index[d].append(i)
     counts = [len(b) for b in blocks]
     flat = [r for b in blocks for r in b]
-    return np.array(flat, dtype=np.float64).reshape(-1, 6), counts
+    routed = np.array(flat, dtype=np.float64).reshape(-1, 6)
+    if with_index:
+        return routed, counts, np.array([i for b in index for i in b], dtype=np.int64)
+    return routed, counts

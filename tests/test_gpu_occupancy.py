@@ -163,6 +163,36 @@ def test_speculative_binning_recovers_from_wrong_guesses(gpu):
     assert_parity(stats)
 
 
+def test_speculated_batches_switch_between_the_small_and_the_dense_region_sort(gpu):
+    # Round 5: regions of up to 2048 samples are ordered by a 256-thread instantiation of the per-region sort, denser
+    # ones (up to 8192) by the 1024-thread one, which is launched only when the densest region asks for it -- decided
+    # from the PREVIOUS batch when the launch is speculative, and added once the batch's own summary is in.  Batches
+    # whose densest region moves across that boundary, in both directions, with misses that have to be ordered against
+    # the samples, must stay bit exact.
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm = GpuMap(map_)
+    gm.setBatchCoalescing(0)
+    om = make_oracle(map_)
+
+    def cluster(n, seed):
+        i = np.arange(n)
+        ends = np.stack([2.0 + 0.9 * synth.uniform01(seed, i, 1), 0.9 * synth.uniform01(seed, i, 2) - 0.45,
+                         0.9 * synth.uniform01(seed, i, 3) - 0.45], axis=1)
+        rays = np.zeros((4 * n, 3), dtype=np.float64)
+        rays[1::4] = ends          # samples inside one region ...
+        rays[3::4] = ends * 2.5    # ... and rays that cross the sample voxels on their way out
+        return rays
+
+    sparse = synth.random_rays(3000, extent=6.0, seed=31)
+    batches = (sparse, sparse, cluster(1500, 5), cluster(1500, 6), sparse, cluster(900, 7), cluster(2500, 8), sparse,
+               cluster(1500, 9))
+    for batch in batches:
+        assert gm.integrateRays(batch) == batch.shape[0]
+        om.integrate_occupancy(batch)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+
+
 def test_out_of_range_coordinates_and_degenerate_batches(gpu):
     # Points whose region coordinate does not fit the int16 key are null keys: the CPU walk visits nothing for such rays
     # (ohm/LineWalk.h:119-122) but the mapper still applies the sample update -- to the end voxel when that is

@@ -174,18 +174,35 @@ def test_stored_regions_answer_the_region_calls(gpu):
     assert len(gm.regionKeys()) == 0 and gm.cacheStats()["regions_spilled"] == 0
 
 
-def test_a_batch_larger_than_the_limit_still_fails_cleanly(gpu):
+def test_a_batch_larger_than_the_limit_is_integrated_in_pieces(gpu):
+    """A batch that alone touches more regions than the limit leaves room for: without spilling it fails and changes
+    nothing; with spilling it is integrated as halves in ray order (the reference finalises what it has enqueued when its
+    cache fills mid-batch and carries on, ohmgpu/GpuMap.cpp:900-996) and the map is the CPU mapper's for the whole batch."""
+    small = sensor_rays((0.0, 0.0, 0.0), 2000, seed=11, max_range=2.5)
+    big = sensor_rays((0.0, 0.0, 0.0), 4000, seed=12, min_range=5.0, max_range=9.0)  # > 20 regions on its own
     map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
     gm = limited_map(map_, 20)
-    gm.setSpillToHost(True)
+    gm.setBatchCoalescing(0)                   # (a collected batch would report its failure at the flush, not here)
     om = make_oracle(map_)
-    small = sensor_rays((0.0, 0.0, 0.0), 2000, seed=11, max_range=2.5)
     assert gm.integrateRays(small) == small.shape[0]
     om.integrate_occupancy(small)
-    big = sensor_rays((0.0, 0.0, 0.0), 4000, seed=12, min_range=5.0, max_range=9.0)  # > 20 regions on its own
-    assert gm.integrateRays(big) == 0
+    assert gm.integrateRays(big) == 0          # no spilling: clean failure
     gm.syncVoxels()
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+    gm.setSpillToHost(True)
+    assert gm.integrateRays(big) == big.shape[0]
+    om.integrate_occupancy(big)
+    assert gm.integrateRays(small) == small.shape[0]
+    om.integrate_occupancy(small)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+    assert gm.cacheStats()["evictions"] > 0
+    # a traversal layer carries its exit range within a call: such a map keeps failing cleanly
+    map_t = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy", "traversal"))
+    gt = limited_map(map_t, 20)
+    gt.setSpillToHost(True)
+    assert gt.integrateRays(small) == small.shape[0]
+    assert gt.integrateRays(big) == 0
 
 
 def test_regions_created_by_name_obey_the_limit(gpu):

@@ -104,18 +104,30 @@ def _worker(rank, world, port, result_dir):
         from oracle.oracle import OracleMap
         origins = [(0.05, 0.05, 0.05), (6.45, 0.05, 0.05)]
         part = D.territories_from_origins(origins, world, rank, 3.2, block_shift=0, margin=8.0)
-        om = OracleMap(0.1)
+        om = OracleMap(0.1, layers=("occupancy", "touch_time"))
         received_total = 0
         for rnd in range(2):
             n = 900 + 300 * rank + 50 * rnd  # ragged
             local = synth.rays_c0(n=n, origin=origins[rank], length=5.0, seed=400 + 10 * rnd + rank)
-            routed, counts = _route(OracleMap(0.1), part, local, world)
+            # the side array of the batch (time stamps; every rank's clock runs on from the previous rank's, so that
+            # "rank 0's batch, then rank 1's" is also the order of the stamps)
+            stamps = 100.0 + 10.0 * rnd + 4.0 * rank + 0.001 * np.arange(n, dtype=np.float64)
+            routed, counts, index = _route(OracleMap(0.1), part, local, world, with_index=True)
             got, recv_counts = D.exchange_routed_rays(torch.from_numpy(routed), counts)
+            got_stamps = D.exchange_routed_side(torch.from_numpy(stamps[index]), counts, recv_counts)
+            if rnd == 0:
+                # one time base for the partitioned map: the first stamp of rank 0's first batch, as ONE map integrating
+                # the ranks' batches in rank order would take it (PartitionedIntegrator._agree_on_time_base)
+                base = torch.tensor([stamps[0]], dtype=torch.float64)
+                dist.broadcast(base, src=0)
+                om.set_first_ray_time(float(base.item()))
             stream = got.numpy().reshape(-1, 3)
             np.save(os.path.join(result_dir, f"local_{rnd}_{rank}.npy"), local)
+            np.save(os.path.join(result_dir, f"stamps_{rnd}_{rank}.npy"), stamps)
             np.save(os.path.join(result_dir, f"stream_{rnd}_{rank}.npy"), stream)
             np.save(os.path.join(result_dir, f"counts_{rnd}_{rank}.npy"), np.array([counts, recv_counts]))
-            om.integrate_occupancy(stream)
+            assert got_stamps.shape[0] == stream.shape[0] // 2
+            om.integrate_occupancy(stream, timestamps=got_stamps.numpy())
             received_total += stream.shape[0] // 2
         chunks = om.chunks()
         keys = np.array(sorted(chunks.keys()), dtype=np.int16).reshape(-1, 3)
@@ -123,6 +135,8 @@ def _worker(rank, world, port, result_dir):
         np.save(os.path.join(result_dir, f"keys_{rank}.npy"), keys[mine])
         np.save(os.path.join(result_dir, f"occ_{rank}.npy"),
                 np.stack([chunks[tuple(int(v) for v in k)]["occupancy"] for k in keys[mine]]))
+        np.save(os.path.join(result_dir, f"touch_{rank}.npy"),
+                np.stack([chunks[tuple(int(v) for v in k)]["touch_time"] for k in keys[mine]]))
     finally:
         dist.destroy_process_group()
 
@@ -131,11 +145,11 @@ def test_two_rank_gloo_route_exchange_integrate_matches_sequential(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     from oracle.oracle import OracleMap
-    seq = OracleMap(0.1)
+    seq = OracleMap(0.1, layers=("occupancy", "touch_time"))
     for rnd in range(2):
         locals_ = [np.load(tmp_path / f"local_{rnd}_{r}.npy") for r in range(world)]
-        for lr in locals_:  # rank order, then ray order
-            seq.integrate_occupancy(lr)
+        for r, lr in enumerate(locals_):  # rank order, then ray order -- the side array (time stamps) with its rays
+            seq.integrate_occupancy(lr, timestamps=np.load(tmp_path / f"stamps_{rnd}_{r}.npy"))
         counts = [np.load(tmp_path / f"counts_{rnd}_{r}.npy") for r in range(world)]
         # what rank s addressed to rank d is what d received from s, and some -- not all -- rays travel
         for s in range(world):
@@ -156,12 +170,15 @@ def test_two_rank_gloo_route_exchange_integrate_matches_sequential(tmp_path):
     seen = set()
     for r in range(world):
         keys, occ = np.load(tmp_path / f"keys_{r}.npy"), np.load(tmp_path / f"occ_{r}.npy")
-        assert len(keys) > 0
-        for k, tile in zip(keys, occ):
+        touch = np.load(tmp_path / f"touch_{r}.npy")
+        assert len(keys) > 0 and int(np.count_nonzero(touch)) > 0
+        for k, tile, stamp_tile in zip(keys, occ, touch):
             key = tuple(int(v) for v in k)
             assert key not in seen
             seen.add(key)
             assert np.array_equal(tile.view(np.uint32), seq_chunks[key]["occupancy"].view(np.uint32)), key
+            # the routed time stamps arrived with their rays: the touch-time layer of the partition is the sequential one
+            assert np.array_equal(stamp_tile, seq_chunks[key]["touch_time"]), key
     assert seen == set(seq_chunks.keys())
 
 
@@ -185,3 +202,34 @@ def test_territories_by_load_balance_one_sensor():
     for r in range(1, 7):
         mine = az[owners[rim] == r]
         assert mine.max() - mine.min() < 2 * np.pi * 0.4
+
+
+def _failure_worker(rank, world, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        outcome = "ok"
+        if rank == 1:
+            # what PartitionedIntegrator does when its own routing raised: take part in the count exchange with the marker
+            class _Failing:
+                comm, group = None, None
+            D.PartitionedIntegrator._announce_failure(_Failing(), np.zeros(world, dtype=np.uint32))
+            outcome = "announced"
+        else:
+            try:
+                D.exchange_routed_rays(torch.zeros((3, 6), dtype=torch.float64), [1, 2])
+            except RuntimeError as exc:
+                outcome = "peer failure: " + str(exc)
+        with open(os.path.join(result_dir, f"outcome_{rank}.txt"), "w") as fh:
+            fh.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_local_failure_ends_the_step_on_every_rank(tmp_path):
+    """a rank whose routing fails still takes part in the step's count exchange, with the failure marker, so
+    its peers raise from the same call instead of blocking in the payload collective (world 2, gloo)."""
+    mp.spawn(_failure_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "outcome_1.txt").read_text() == "announced"
+    assert (tmp_path / "outcome_0.txt").read_text().startswith("peer failure")
