@@ -626,7 +626,9 @@ def main():
             fresh = []
             for _ in range(3):
                 mf = ohm_amd.OccupancyMap(resolution, (32, 32, 32), layers=("occupancy",))
-                gf = ohm_amd.GpuMap(mf, gpu_mem_size=8 << 30)
+                # (expected_element_count: the per-batch buffers are sized at construction, as the reference's GpuMap
+                # constructor sizes its ray / key buffers -- the first call then allocates nothing)
+                gf = ohm_amd.GpuMap(mf, expected_element_count=rays.shape[0], gpu_mem_size=8 << 30)
                 gf.wait()
                 t1 = time.perf_counter()
                 gf.integrateRaysDevice(dptr, rays.shape[0])

@@ -354,6 +354,11 @@ int ohmhip_map_batch_timings(ohmhip_map_t map, uint32_t batches_back, float ms[4
  * recorded only with phase timing on (this call, OHMHIP_PHASE_TIMING=1): ms[1], and ms[0] of a batch on its own as first
  * kernel start -> last kernel end, need it and read 0 / the shorter span otherwise.  Default: off. */
 int ohmhip_map_set_phase_timing(ohmhip_map_t map, int enable);
+/* The per-batch device buffers (ray set-up records, ray-region segments, sample keys, sort scratch) are grown by the
+ * batch that first needs them -- a few hipMalloc calls, each a device synchronisation, inside that call.  The reference's
+ * GpuMap constructor sizes its key / ray buffers for `expected_element_count` up front (ohmgpu/GpuMap.cpp:429-470); this is
+ * the counterpart: size everything a batch of `ray_count` rays needs now.  Optional; batches of any size still work. */
+int ohmhip_map_reserve_rays(ohmhip_map_t map, size_t ray_count);
 /* OccupancyMap::firstRayTime / setFirstRayTime (ohm/OccupancyMap.h:342-351): the time base the touch-time layer is
  * encoded against (milliseconds since it, ohm/VoxelTouchTimeCompute.h:24-37).  Like the reference the map takes it from
  * the first time stamp it is ever given; set it explicitly where that is not the map's to decide -- the ranks of a

@@ -137,6 +137,7 @@ _sigs = {
     "ohmhip_map_batch_timings": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_float)]),
     "ohmhip_comm_exchange_side": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp]),
     "ohmhip_gather_rows": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
+    "ohmhip_map_reserve_rays": (C.c_int, [_vp, C.c_size_t]),
     "ohmhip_map_set_first_ray_time": (C.c_int, [_vp, C.c_double]),
     "ohmhip_map_first_ray_time": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "ohmhip_map_set_phase_timing": (C.c_int, [_vp, C.c_int]),

@@ -702,6 +702,48 @@ try
 }
 OHMHIP_ABI_CATCH
 
+int ohmhip_map_reserve_rays(ohmhip_map_t m, size_t ray_count)
+try
+{
+  if (!m || ray_count >= (size_t(1) << (kHitRayBits - 1)))
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);
+  OHMHIP_CHECK(hipSetDevice(m->device));
+  // What prepare() / sizeBuffers() of a batch of `ray_count` rays would otherwise allocate inside the first call (a
+  // hipMalloc is a device synchronisation and ~0.1 ms each: 0.25 ms of a fresh map's first 10^6-ray batch).
+  hipStream_t s = m->stream;
+  const size_t n = std::max<size_t>(ray_count, 1);
+  const uint32_t blocks = uint32_t((n + 127) / 128);  // (the smallest binning workgroup: the most workgroups)
+  for (int p = 0; p < 2; ++p)
+  {
+    OHMHIP_CHECK(m->walks_buf[p].ensure(sizeof(RayWalk) * n, false, s));
+    OHMHIP_CHECK(m->wg_regions[p].ensure(sizeof(WgRegion) * size_t(std::min<size_t>(blocks, (n + kBinRaysPerBlock - 1) / kBinRaysPerBlock * 8)) * kLtabSize, false, s));
+    OHMHIP_CHECK(m->wg_region_count[p].ensure(sizeof(uint32_t) * size_t(blocks), false, s));
+  }
+  const bool occupancy = m->config.mode == OHMHIP_MODE_OCCUPANCY;
+  const size_t events = std::max<size_t>(size_t(1) << 20, n * 64);  // (visits / 4 at ~256 visits per ray)
+  const size_t keys = occupancy ? n : n + events;
+  OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * keys, false, s));
+  OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * keys, false, s));
+  if (occupancy)
+  {
+    OHMHIP_CHECK(m->interval_counts.ensure(sizeof(uint32_t) * n, true, s));
+    OHMHIP_CHECK(m->events.ensure(sizeof(unsigned long long) * events, false, s));
+  }
+  size_t sort_bytes = 0;
+  OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(nullptr, sort_bytes, static_cast<unsigned long long *>(m->hit_keys_a.ptr),
+                                                    static_cast<unsigned long long *>(m->hit_keys_b.ptr), keys, 0,
+                                                    sortEndBit(m), s));
+  OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
+  // ray-region segments: the running estimate (10 per ray until a batch has been seen) with some head room
+  OHMHIP_CHECK(m->segments.ensure(sizeof(Segment) * size_t(double(n) * std::max(m->segments_per_ray, 10.0) * 1.25), false, s));
+  OHMHIP_CHECK(hipStreamSynchronize(s));
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
 int ohmhip_map_set_first_ray_time(ohmhip_map_t m, double time)
 try
 {

@@ -189,6 +189,10 @@ class GpuMap(RayMapper):
         # gputil::Exception from the ctor on allocation failure (ohmgpu/GpuMap.h:53-54,159-160)
         L.check(status, "GpuMap: ohmhip_map_create")
         self._ok = True
+        if expected_element_count > 2048:
+            # the reference sizes its ray / key buffers for expected_element_count points in the constructor
+            # (ohmgpu/GpuMap.cpp:429-470); the default (2048) is left to the first batch
+            L.check(L.lib.ohmhip_map_reserve_rays(self._handle, int(expected_element_count) // 2), "reserve_rays")
         self._upload_existing()
 
     def _fill_map_values(self, cfg):

@@ -345,7 +345,7 @@ public:
 class GpuMap : public RayMapper
 {
 public:
-  /// @param expected_element_count accepted for source compatibility; batch buffers grow on demand.
+  /// @param expected_element_count points per call the per-batch device buffers are sized for up front (as the reference does, ohmgpu/GpuMap.cpp:429-470); larger batches still work, the buffers then grow on demand.
   /// @param gpu_mem_size device memory budget for the resident map, 0 => default.
   explicit GpuMap(OccupancyMap *map, bool borrowed_map = true, unsigned expected_element_count = 2048,
                   size_t gpu_mem_size = 0)
@@ -727,7 +727,7 @@ public:
 
 protected:
   using ConfigHook = void (*)(ohmhip_map_config &, void *);
-  GpuMap(OccupancyMap *map, bool borrowed_map, unsigned /*expected_element_count*/, size_t gpu_mem_size, int mode,
+  GpuMap(OccupancyMap *map, bool borrowed_map, unsigned expected_element_count, size_t gpu_mem_size, int mode,
          void *hook_data, ConfigHook hook = nullptr)
     : map_(map)
     , borrowed_map_(borrowed_map)
@@ -751,6 +751,11 @@ protected:
     cfg.layers = map->layers();
     // gputil::Exception on allocation failure from the ctor (ohmgpu/GpuMap.h:53-54,159-160).
     OHMHIP_GPUAPICHECK(ohmhip_map_create(&handle_, &cfg));
+    if (expected_element_count > 2048u)
+    {
+      // the reference sizes its ray / key buffers for expected_element_count points here (ohmgpu/GpuMap.cpp:429-470)
+      OHMHIP_GPUAPICHECK(ohmhip_map_reserve_rays(handle_, expected_element_count / 2u));
+    }
     uploadExisting();
   }
 

@@ -1,14 +1,16 @@
 #!/bin/bash
-# Build what can be built of ohm_amd/host/ref_adaptor (INTEGRATION.md Level 2) against the reference checkout the moment
-# glm exists on the box.  Never writes a stand-in for glm: without it the script says so and exits 77
-# (the "skipped" code); tests/test_ref_adaptor_build.py turns that into a pytest skip.
+# Build what can be built of ohm_amd/host/ref_adaptor (INTEGRATION.md Level 2) against the reference checkout, and SAY
+# what was not: the translation units that need no glm -- the gputil backend and the device
+# selection, 3 of 8, plus the reference's own gpuEventList.cpp -- are compiled on every box; the five that include an
+# ohm header which includes glm are compiled where glm exists and listed by name as NOT COMPILED where it does not
+# (exit 77, the "skipped" code; tests/test_ref_adaptor_build.py).  Never writes a stand-in for glm.
 #
 #   scripts/build_ref_adaptor.sh [reference checkout = /root/reference] [output dir = build/ref_adaptor]
 #   GLM_INCLUDE_DIR=<dir containing glm/glm.hpp>   overrides the search
 #   OHM_LIB_DIR=<dir with libohm / libohmutil / liblogutil built with real glm>   also LINKS libohmgpuhip.so
 #
-# Step 1 compiles every adaptor source -- the gputil backend AND the ohm:: half (GpuMap / GpuNdtMap / GpuTsdfMap /
-# GpuCache / OhmGpu / HipMapBinding) -- to object files against the reference's headers where they lie; the four headers
+# Step 1 compiles the adaptor sources -- the gputil backend, OhmGpu, and with glm the ohm:: half (GpuMap / GpuNdtMap /
+# GpuTsdfMap / GpuCache / HipMapBinding) -- to object files against the reference's headers where they lie; the four headers
 # the reference's build generates (OhmConfig.h, OhmGpuConfig.h, gpuConfig.h and the export-macro headers) are produced
 # from its own templates in the output directory, as ref_adaptor/CMakeLists.txt does.  Step 2 (only with OHM_LIB_DIR)
 # links them into libohmgpuhip.so against the reference's core libraries and libohmhip.so.  The full recipe with the
@@ -26,12 +28,7 @@ GLM=""
 for d in "${GLM_INCLUDE_DIR:-}" /usr/include /usr/local/include /opt/rocm/include /usr/include/x86_64-linux-gnu; do
   if [ -n "$d" ] && [ -f "$d/glm/glm.hpp" ]; then GLM="$d"; break; fi
 done
-if [ -z "$GLM" ]; then
-  echo "SKIPPED: glm absent (looked for glm/glm.hpp in \$GLM_INCLUDE_DIR, /usr/include, /usr/local/include, /opt/rocm/include); no stand-in is ever written"
-  exit 77
-fi
-echo "glm: $GLM/glm/glm.hpp"
-set -e
+if [ -n "$GLM" ]; then echo "glm: $GLM/glm/glm.hpp"; else echo "glm: ABSENT (looked for glm/glm.hpp in \$GLM_INCLUDE_DIR, /usr/include, /usr/local/include, /opt/rocm/include); no stand-in is ever written"; fi
 GEN="$OUT/generated"
 mkdir -p "$GEN/ohm" "$GEN/ohmgpu" "$GEN/gputil" "$GEN/ohmutil" "$GEN/logutil" "$OUT/obj"
 # configure_file(): #cmakedefine X -> /* #undef X */ (no optional feature is switched on), @VAR@ -> empty
@@ -50,18 +47,47 @@ export_header "$GEN/ohmgpu/OhmGpuExport.h" ohmgpu_API OHMGPU_EXPORT_H
 export_header "$GEN/gputil/gputilExport.h" gputilAPI GPUTIL_EXPORT_H
 export_header "$GEN/ohmutil/OhmUtilExport.h" ohmutil_API OHMUTIL_EXPORT_H
 export_header "$GEN/logutil/LogUtilExport.h" logutil_API LOGUTIL_EXPORT_H
-INC="-I$GEN -I$GEN/ohm -I$GEN/ohmgpu -I$GEN/gputil -I$GEN/ohmutil -I$GEN/logutil -I$REF -I$REF/ohmutil/3rdparty -I$GLM -I$ROOT/include -I$SRC -I$SRC/gputil_hip"
+INC="-I$GEN -I$GEN/ohm -I$GEN/ohmgpu -I$GEN/gputil -I$GEN/ohmutil -I$GEN/logutil -I$REF -I$REF/ohmutil/3rdparty -I$ROOT/include -I$SRC -I$SRC/gputil_hip"
+if [ -n "$GLM" ]; then INC="$INC -I$GLM"; fi
+# Translation units that need NO glm (the gputil backend, device selection) are compiled on every box; the ones that
+# include an ohm header which includes glm only where glm exists.  Every unit's fate is printed: nothing is "checked"
+# anywhere else.
+NO_GLM_UNITS="OhmGpu.cpp gputil_hip/gputilHip.cpp gputil_hip/gputilHipBuffer.cpp"
+GLM_UNITS="GpuCache.cpp GpuMap.cpp GpuNdtMap.cpp GpuTsdfMap.cpp private/HipMapBinding.cpp"
 OBJS=""
-for f in GpuCache.cpp GpuMap.cpp GpuNdtMap.cpp GpuTsdfMap.cpp OhmGpu.cpp private/HipMapBinding.cpp gputil_hip/gputilHip.cpp gputil_hip/gputilHipBuffer.cpp; do
-  o="$OUT/obj/$(echo "$f" | tr '/' '_' | sed 's/\.cpp$/.o/')"
-  echo "compile $f"
-  g++ -std=c++14 -O1 -fPIC -Wall -Dgputil_EXPORTS -Dohmgpuhip_EXPORTS $INC -c "$SRC/$f" -o "$o"
-  OBJS="$OBJS $o"
+COMPILED=""
+NOT_COMPILED=""
+FAILED=""
+compile_unit() { # source path relative to $SRC (or absolute), object name
+  local src="$1" obj="$OUT/obj/$2"
+  if g++ -std=c++14 -O1 -fPIC -Wall -Dgputil_EXPORTS -Dohmgpuhip_EXPORTS $INC -c "$src" -o "$obj" 2> "$obj.log"; then
+    OBJS="$OBJS $obj"; COMPILED="$COMPILED $2"; echo "compiled      $1"
+  else
+    FAILED="$FAILED $1"; echo "FAILED        $1: $(grep -m1 error "$obj.log" | cut -c1-160)"
+  fi
+}
+for f in $NO_GLM_UNITS; do
+  compile_unit "$SRC/$f" "$(echo "$f" | tr '/' '_' | sed 's/\.cpp$/.o/')"
 done
-echo "compile gputil/gpuEventList.cpp (the reference's own, backend independent)"
-g++ -std=c++14 -O1 -fPIC -Dgputil_EXPORTS $INC -c "$REF/gputil/gpuEventList.cpp" -o "$OUT/obj/gpuEventList.o"
-OBJS="$OBJS $OUT/obj/gpuEventList.o"
-echo "COMPILED: $(echo $OBJS | wc -w) objects under $OUT/obj"
+compile_unit "$REF/gputil/gpuEventList.cpp" gpuEventList.o   # the reference's own, backend independent
+for f in $GLM_UNITS; do
+  if [ -n "$GLM" ]; then
+    compile_unit "$SRC/$f" "$(echo "$f" | tr '/' '_' | sed 's/\.cpp$/.o/')"
+  else
+    first=$(g++ -std=c++14 -fsyntax-only $INC "$SRC/$f" 2>&1 | grep -m1 'fatal error' | sed -E 's/.*fatal error: //' | cut -c1-80)
+    NOT_COMPILED="$NOT_COMPILED $f"; echo "NOT COMPILED  $f  (stops at: $first)"
+  fi
+done
+echo "COMPILED: $(echo $COMPILED | wc -w) objects under $OUT/obj:$COMPILED"
+if [ -n "$FAILED" ]; then
+  echo "FAILED:$FAILED"
+  exit 1
+fi
+if [ -n "$NOT_COMPILED" ]; then
+  echo "NOT COMPILED (need glm, have never been through a compiler on this box):$NOT_COMPILED"
+  echo "SKIPPED: glm absent -- $(echo $NOT_COMPILED | wc -w) of 8 adaptor translation units not compiled"
+  exit 77
+fi
 if [ -n "${OHM_LIB_DIR:-}" ]; then
   g++ -shared -o "$OUT/libohmgpuhip.so" $OBJS -L"$OHM_LIB_DIR" -lohm -lohmutil -llogutil -L"$ROOT/ohm_amd/lib" -lohmhip \
       -Wl,-rpath,"$ROOT/ohm_amd/lib" -Wl,-rpath,"$OHM_LIB_DIR"

@@ -7,7 +7,8 @@ buf = L._vp(); L.check(L.lib.ohmhip_buffer_create(C.byref(buf), rays.nbytes, 3))
 p = L._vp(); L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(p)))
 for rep in range(2):
     m = ohm_amd.OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
-    g = ohm_amd.GpuMap(m, gpu_mem_size=8 << 30)
+    g = ohm_amd.GpuMap(m, expected_element_count=(rays.shape[0] if rep else 2048), gpu_mem_size=8 << 30)
+    g.setPhaseTiming(True)
     g.wait()
     for k in range(3):
         t0 = time.perf_counter(); g.integrateRaysDevice(p, rays.shape[0]); g.wait(); dt = time.perf_counter() - t0

@@ -446,3 +446,179 @@ def test_touch_time(gpu, ndt):
         encoded = int(map_.chunks[tuple(region)]["touch_time"][vi])
         assert encoded * 0.001 + 1000.0 == stamps[-1]      # decodeVoxelTouchTime(map.firstRayTime(), data)
     gm.close()
+
+
+def test_incident_with_occupancy(gpu):
+    """Incident.WithOccupancy (GpuIncidentsTests.cpp:128-134): the same ten batches through GpuMap, ONE RAY PER CALL (the
+    reference needs that because its GPU update is order dependent; here it is simply 10 000 more calls): packed normals
+    bit for bit the CPU mapper's."""
+    res = float(np.float32(0.1))
+    map_ = OccupancyMap(res, (32, 32, 32), layers=("occupancy", "mean", "incident_normal"))
+    map_.setOrigin((-0.5 * res,) * 3)
+    gm = GpuMap(map_, True, 2)
+    gm.setBatchCoalescing(0)          # every call its own device batch, as the reference runs it
+    om = make_oracle(map_)
+    rng = MinStdRand0(1153297050)
+    for it in range(10):
+        rays = _rays_about_the_origin(rng, 1000, res)
+        calls = range(1000) if it < 2 else range(0, 1000, 50)   # (two iterations ray by ray, the rest in calls of 50)
+        step = 1 if it < 2 else 50
+        for r in calls:
+            part = rays[2 * r:2 * (r + step)]
+            assert gm.integrateRays(part) == part.shape[0]
+        gm.syncVoxels()
+        om.integrate_occupancy(rays)
+        assert_parity(compare_maps(om.chunks(), map_.chunks, list(map_.layers), exact_float=True))
+        region, local = om.voxel_key((0.0, 0.0, 0.0))
+        region = tuple(int(v) for v in region)
+        vi = local[0] + 32 * (local[1] + 32 * local[2])
+        assert int(map_.chunks[region]["incident_normal"][vi]) != 0
+        map_.chunks[region]["incident_normal"][vi] = 0
+        map_.chunks[region]["mean"].reshape(-1, 2)[vi] = 0
+        om.region_layer_view(region, "incident_normal")[vi] = 0
+        om.region_layer_view(region, "mean").reshape(-1, 2)[vi] = 0
+        gm.gpuCache().clear()
+        gm.uploadRegions()
+    gm.close()
+
+
+# ---- GpuTraversalTests.cpp (ohmtestcommon/TraversalTest.cpp) ------------------------------------------------------------
+def _traversal_rays(into):
+    axes = [(-1, 0, 0), (0, -1, 0), (0, 0, -1), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    d2 = [(-1, -1, 0), (1, -1, 0), (-1, 1, 0), (1, 1, 0), (-1, 0, -1), (1, 0, -1), (-1, 0, 1), (1, 0, 1), (0, -1, -1),
+          (0, 1, -1), (0, -1, 1), (0, 1, 1)]
+    d3 = [(-1, -1, -1), (1, -1, -1), (-1, 1, -1), (1, 1, -1), (-1, -1, 1), (1, -1, 1), (-1, 1, 1), (1, 1, 1)]
+    if into:     # TraversalTest.cpp:32-49: every ray ends at the origin; expected half a voxel crossing per ray
+        return [(s, (0, 0, 0)) for s in axes + d2 + d3], [1] * 6 + [2] * 12 + [3] * 8
+    # TraversalTest.cpp:96-147: every ray passes through the origin; a full crossing per ray
+    through = [((-1, 0, 0), (1, 0, 0)), ((0, -1, 0), (0, 1, 0)), ((0, 0, -1), (0, 0, 1)),
+               ((-1, -1, 0), (1, 1, 0)), ((1, -1, 0), (-1, 1, 0)), ((-1, 1, 0), (1, -1, 0)), ((1, 1, 0), (-1, -1, 0)),
+               ((-1, 0, -1), (1, 0, 1)), ((1, 0, -1), (-1, 0, 1)), ((-1, 0, 1), (1, 0, -1)), ((1, 0, 1), (-1, 0, -1)),
+               ((0, -1, -1), (0, 1, 1)), ((0, 1, -1), (0, -1, 1)), ((0, -1, 1), (0, 1, -1)), ((0, 1, 1), (0, -1, -1)),
+               ((-1, -1, -1), (1, 1, 1)), ((1, -1, -1), (-1, 1, 1)), ((-1, 1, -1), (1, -1, 1)), ((1, 1, -1), (-1, -1, 1)),
+               ((-1, -1, 1), (1, 1, -1)), ((1, -1, 1), (-1, 1, -1)), ((-1, 1, 1), (1, -1, -1)), ((1, 1, 1), (-1, -1, -1))]
+    return through, [1] * 3 + [2] * 12 + [3] * 8
+
+
+@pytest.mark.parametrize("name,into,mapper,mean", [
+    ("Through", False, "occupancy", True), ("ThroughNoMean", False, "occupancy", False), ("ThroughNdt", False, "ndt", True),
+    ("ThroughNdtTm", False, "ndt-tm", True), ("Into", True, "occupancy", True), ("IntoNoMean", True, "occupancy", False),
+    ("IntoNdt", True, "ndt", True), ("IntoNdtTm", True, "ndt-tm", True)])
+def test_traversal(gpu, name, into, mapper, mean):
+    """Traversal.Through / ThroughNoMean / ThroughNdt / ThroughNdtTm / Into / IntoNoMean / IntoNdt / IntoNdtTm
+    (GpuTraversalTests.cpp:21-89; ohmtestcommon/TraversalTest.cpp:22-188): rays through / into the voxel at the origin,
+    one call per ray; after every ray the voxel's traversal is the running sum of (half) voxel crossings to the reference's
+    1e-3 -- and the whole layer is the CPU mapper's to 1e-5."""
+    res = float(np.float32(0.1))
+    layers = ("occupancy", "mean", "traversal") if mean else ("occupancy", "traversal")
+    map_ = OccupancyMap(res, (32, 32, 32), layers=layers)
+    map_.setOrigin((-0.5 * res,) * 3)
+    if mapper == "occupancy":
+        gm = GpuMap(map_, True, 2)
+    else:
+        gm = GpuNdtMap(map_, True, 2, 0, ohm_amd.NdtMode.kTraversability if mapper == "ndt-tm" else ohm_amd.NdtMode.kOccupancy)
+    om = make_oracle(map_)
+    if mapper != "occupancy":
+        _ndt_parameters(om, gm, ndt_tm=(mapper == "ndt-tm"))
+    rays, dims = _traversal_rays(into)
+    expected = np.float32(0.0)
+    for (start, end), dim in zip(rays, dims):
+        ray = np.array([start, end], dtype=np.float64)
+        assert gm.integrateRays(ray) == 2
+        gm.syncVoxels()
+        (om.integrate_occupancy if mapper == "occupancy" else om.integrate_ndt)(ray)
+        rate = math.sqrt(dim * res * res) * (0.5 if into else 1.0)
+        expected = np.float32(expected + np.float32(rate))
+        region, local = om.voxel_key((0.0, 0.0, 0.0))
+        vi = local[0] + 32 * (local[1] + 32 * local[2])
+        got = float(map_.chunks[tuple(int(v) for v in region)]["traversal"][vi])
+        assert abs(got - float(expected)) <= 1e-3, (name, start, end, got, float(expected))
+    cpu = om.chunks()
+    for key, blocks in cpu.items():
+        assert np.allclose(map_.chunks[key]["traversal"], blocks["traversal"], rtol=1e-5, atol=1e-6), (name, key)
+    others = [n for n in map_.layers if n != "traversal"]
+    assert_parity(compare_maps(cpu, map_.chunks, others, rel=1e-5, exact_float=(mapper == "occupancy")))
+    gm.close()
+
+
+# ---- GpuRayPatternTests.cpp ----------------------------------------------------------------------------------------------
+CLEARING_FLAGS = RayFlag.kRfEndPointAsFree | RayFlag.kRfStopOnFirstOccupied | RayFlag.kRfExcludeFree | \
+    RayFlag.kRfExcludeUnobserved   # ClearingPattern::kDefaultRayFlags, ohm/ClearingPattern.h:44-45
+
+
+def _seed_region(map_, om, values):
+    """CPU-side voxel writes (Voxel<float>::write in the reference's tests): region (0, 0, 0) of the host map and of the
+    oracle holds `values` {local (x, y, z): log-odds}, everything else unobserved."""
+    tile = np.full(32 * 32 * 32, np.inf, dtype=np.float32)
+    for (x, y, z), v in values.items():
+        tile[x + 32 * (y + 32 * z)] = np.float32(v)
+    map_.chunks[(0, 0, 0)] = {"occupancy": tile.copy()}
+    if om.region_layer_view((0, 0, 0), "occupancy") is None:
+        c = np.array(om.voxel_centre((0, 0, 0), (16, 16, 16)))
+        om.integrate_occupancy(np.array([c, c]), flags=int(RayFlag.kRfExcludeSample | RayFlag.kRfExcludeRay))
+        if om.region_layer_view((0, 0, 0), "occupancy") is None:   # (nothing was touched: touch one voxel for real)
+            om.integrate_occupancy(np.array([c, c]))
+    om.region_layer_view((0, 0, 0), "occupancy")[:] = tile
+
+
+def test_ray_pattern_clearing(gpu):
+    """RayPattern.Clearing (GpuRayPatternTests.cpp:28-85): a line of 20 occupied voxels along x, hit probability 0.51, miss
+    probability 0 (one miss erases one hit); a one-ray clearing pattern along the line, applied 20 times with the clearing
+    flags: every application stops at the first occupied voxel and frees exactly that one."""
+    map_ = OccupancyMap(0.1, (32, 32, 32))
+    map_.setHitProbability(0.51)
+    map_.setMissProbability(0.0)
+    om = make_oracle(map_)
+    hit = np.float32(map_.hit_value)
+    _seed_region(map_, om, {(x, 0, 0): hit for x in range(20)})
+    gm = GpuMap(map_, True, 2)                    # uploads the CPU-built line
+    start = np.array(om.voxel_centre((0, 0, 0), (0, 0, 0)))
+    ray = np.array([start, start + np.array([0.1 * 20, 0.0, 0.0])])   # the y line rotated onto x, translated to the voxel
+    for i in range(20):
+        occ = map_.chunks[(0, 0, 0)]["occupancy"]
+        assert occ[i] >= map_.occupancy_threshold_value                     # still occupied ...
+        assert gm.integrateRays(ray, ray_update_flags=CLEARING_FLAGS) == 2
+        gm.syncVoxels()
+        om.integrate_occupancy(ray, flags=int(CLEARING_FLAGS))
+        occ = map_.chunks[(0, 0, 0)]["occupancy"]
+        assert np.isfinite(occ[i]) and occ[i] < map_.occupancy_threshold_value   # ... and now it is not
+        assert np.all(occ[i + 1:20] == hit)                                 # the ray stopped there
+        assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+    gm.close()
+
+
+def test_ray_pattern_exclude(gpu):
+    """RayPattern.Exclude (GpuRayPatternTests.cpp:87-93; ohmtestcommon/RayPatternTestUtil.h:34-153): voxels { unobserved,
+    free, occupied, occupied } along x at 1 m, one ray through them under five flag sets; the reference's expected values
+    to its 1e-3, and the CPU mapper's map bit for bit."""
+    inf = float("inf")
+    for case in range(5):
+        map_ = OccupancyMap(1.0, (32, 32, 32))
+        map_.setMissValue(-1.1 * map_.hit_value)
+        map_.setOrigin((0.5, 0.5, 0.5))
+        map_.saturate_at_min_value = map_.saturate_at_max_value = False
+        map_.min_voxel_value, map_.max_voxel_value = np.float32(-3.4028234663852886e38), np.float32(3.4028234663852886e38)
+        hit, miss = float(np.float32(map_.hit_value)), float(np.float32(map_.miss_value))
+        om = make_oracle(map_)
+        keys = [om.voxel_key((float(i), 0.0, 0.0)) for i in range(4)]
+        assert all(tuple(k[0]) == (0, 0, 0) for k in keys)
+        seed = {tuple(keys[1][1]): miss, tuple(keys[2][1]): hit, tuple(keys[3][1]): hit}   # voxel 0 stays unobserved
+        _seed_region(map_, om, seed)
+        default = CLEARING_FLAGS
+        flags, expected = [
+            (default, (inf, miss, hit + miss, hit)),
+            (default & ~RayFlag.kRfStopOnFirstOccupied, (inf, miss, hit + miss, hit + miss)),
+            (RayFlag.kRfEndPointAsFree | RayFlag.kRfExcludeUnobserved, (inf, 2.0 * miss, hit + miss, hit + miss)),
+            (RayFlag.kRfEndPointAsFree | RayFlag.kRfExcludeFree, (miss, miss, hit + miss, hit + miss)),
+            (RayFlag.kRfEndPointAsFree | RayFlag.kRfExcludeOccupied, (miss, 2.0 * miss, hit, hit))][case]
+        gm = GpuMap(map_, True, 2)
+        ray = np.array([(0.0, 0.0, 0.0), (10.0, 0.0, 0.0)])
+        assert gm.integrateRays(ray, ray_update_flags=flags) == 2
+        gm.syncVoxels()
+        om.integrate_occupancy(ray, flags=int(flags))
+        occ = map_.chunks[(0, 0, 0)]["occupancy"]
+        for (region, local), want in zip(keys, expected):
+            got = float(occ[local[0] + 32 * (local[1] + 32 * local[2])])
+            assert (got == want) if math.isinf(want) else abs(got - want) <= 1e-3, (case, local, got, want)
+        assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+        gm.close()
