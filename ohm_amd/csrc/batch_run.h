@@ -36,6 +36,9 @@ struct BatchRun
   uint32_t batch_chunk_segments = 0;
   int mode = 0;
   bool stop_mode = false, occupancy_mode = false, ndt_mode = false, tsdf_mode = false;
+  /// Occupancy map without mean / secondary layers: the walk kernel replays the samples of every region it holds in one
+  /// chunk itself, and the apply kernels run over k_plan's lists of the regions that are left.
+  bool occ_inline = false;
   int ray_shift = 0;
   SecondaryLayers sec;
   // per attempt
@@ -112,6 +115,8 @@ struct BatchRun
     sec.incident = tsdf_mode ? nullptr : static_cast<uint32_t *>(m->layers[OHMHIP_LID_INCIDENT]);
     sec.timestamps = d_timestamps;
     sec.time_base = m->first_ray_time;
+    occ_inline = occupancy_mode && !m->layers[OHMHIP_LID_MEAN] && !sec.traversal && !sec.touch_time && !sec.incident &&
+                 !m->layers[OHMHIP_LID_INTENSITY] && !m->layers[OHMHIP_LID_HIT_MISS];
 
     for (int p = 0; p < 2; ++p)
     {
@@ -244,7 +249,7 @@ struct BatchRun
     // recorded behind that copy.)
     hipExtLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, f, nullptr, tev[5], 0, regionTable(m), batchScratch(m),
                           batchChunks(m), m->chunk_capacity, batch_chunk_segments, m->h_info_dev,
-                          m->d_info + next_info_index, batchEventCount(m));
+                          m->d_info + next_info_index, batchEventCount(m), occ_inline ? uint32_t(kLdsHits) : 0u);
     mark(5);
     m->info_clean = true;
     hipEvent_t plan_done = tev[5];
@@ -490,10 +495,7 @@ struct BatchRun
         // layer has its sums already.
         wa.rewalk = (walk_attempt > 0 && (direct_occ || tsdf_mode)) ? 1 : 0;
         wa.flag_all = ((tsdf_mode && m->mc.tsdf_dropoff > 0) || stop_mode) ? 1 : 0;
-        wa.inline_hits = (occupancy_mode && !m->layers[OHMHIP_LID_MEAN] && !sec.traversal && !sec.touch_time &&
-                          !sec.incident && !m->layers[OHMHIP_LID_INTENSITY] && !m->layers[OHMHIP_LID_HIT_MISS]) ?
-                           1 :
-                           0;
+        wa.inline_hits = occ_inline ? 1 : 0;
         // Traversal layer: its own fp64 pass over the chunk list after the count walk (traversal_kernels.h).
         const bool traversal_pass = sec.traversal != nullptr && walk_attempt == 0;
         // The lean instantiation applies unless ray origins are excluded (a first voxel that is not visited).  (An end
@@ -596,7 +598,32 @@ struct BatchRun
     uint32_t *mean_layer = static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]);
     uint32_t *intervals = static_cast<uint32_t *>(m->interval_counts.ptr);
     const RayWalk *walks = static_cast<const RayWalk *>(batchWalks(m).ptr);
-    // (one launch with a workgroup per region that receives samples, and the count application shared by eight
+    if (occ_inline)
+    {
+      // The walk applied every region it held in one chunk: the apply kernels run over k_plan's lists of the others
+      // (C1: ~80 of 1243 regions; 46 -> ~20 us), the bookkeeping of all touched regions is k_batch_cleanup's.
+      const uint32_t blocks_per_region = std::max<uint32_t>((info.max_region_hits + 255u) / 256u, 1u);
+      const uint32_t hit_blocks = info.n_apply_hits * blocks_per_region;
+      if (hit_blocks + info.n_apply_counts)
+      {
+        hipLaunchKernelGGL(k_apply_lists, dim3(hit_blocks + info.n_apply_counts * kApplyListParts), dim3(256), 0, s, m->mc,
+                           regionTable(m), batchScratch(m), ray_flags, sorted, intervals, m->d_miss_counts, m->d_hit_mask,
+                           d_rays, occ, hit_blocks, blocks_per_region);
+      }
+      if (info.n_touched)
+      {
+        hipExtLaunchKernelGGL(k_batch_cleanup, dim3(std::min<uint32_t>(info.n_touched, 4096u)), dim3(256), 0, s, nullptr,
+                              tev[4], 0, m->mc, regionTable(m), batchScratch(m), info.n_touched, m->d_hit_mask);
+      }
+      else
+      {
+        OHMHIP_CHECK(hipEventRecord(tev[4], s));
+      }
+      batch_end_marked = true;
+      return OHMHIP_OK;
+    }
+    // (maps with a mean / secondary layer: every region's samples and every touched region go through the two kernels.
+    // One launch with a workgroup per region that receives samples, and the count application shared by eight
     // workgroups per region, were both measured slower in round 5 -- 1.01 and 0.93 against 0.91 ms per C1 batch: short-lived
     // workgroups that leave after three dependent loads cost more than the idle lanes they replace)
     hipExtLaunchKernelGGL(k_apply_hits, dim3(ray_blocks), dim3(256), 0, s, nullptr, info.n_touched ? nullptr : tev[4], 0,

@@ -64,6 +64,8 @@ struct BatchScratch
   uint32_t *touched;       ///< [hash_capacity] list of touched hash indices
   uint32_t *hit_count;     ///< [hash_capacity] samples per region (k_ray_setup -> k_plan, which zeroes it again)
   uint32_t *sort_list;     ///< [hash_capacity] regions receiving samples, most samples first (k_plan -> sort)
+  uint32_t *apply_counts_list;  ///< [hash_capacity] regions cut into several chunks: k_apply_counts_list applies their counts
+  uint32_t *apply_hits_list;    ///< [hash_capacity] regions whose samples the walk does not replay itself: k_apply_hits_list
   uint32_t *hit_begin;     ///< [slot_capacity] first sample of the region in the sorted list
   uint32_t *hit_end;       ///< [slot_capacity]
   uint32_t *dirty;         ///< [slot_capacity]
@@ -813,7 +815,7 @@ __device__ inline void touchRegionUse(uint32_t *use, uint32_t slot, uint32_t sta
 __global__ void __launch_bounds__(1024)
   k_plan(RegionTable rt, BatchScratch bs, Chunk *__restrict__ chunks, uint32_t chunk_capacity,
          uint32_t chunk_segments, BatchInfo *__restrict__ host_info, BatchInfo *__restrict__ next_info,
-         uint32_t *__restrict__ event_count)
+         uint32_t *__restrict__ event_count, uint32_t inline_max_hits)
 {
   constexpr uint32_t kSizeClasses = 32;  // chunk size classes for the largest-first order (class = 32 * size / max)
   constexpr int kRounds = 4;             // touched regions held in registers between the two passes: 4 x 1024
@@ -829,6 +831,7 @@ __global__ void __launch_bounds__(1024)
   __shared__ uint32_t s_hclass[33];  // regions per sample-count class (class = bits of count - 1)
   __shared__ uint32_t s_big_n;
   __shared__ uint32_t s_big[kBigQueue][4];  // hash index, slot, segment offset, segment count
+  __shared__ uint32_t s_n_apply_counts, s_n_apply_hits;
   const uint32_t n = bs.info->n_touched;
   const uint32_t tid = threadIdx.x;
   if (tid == 0)
@@ -838,6 +841,8 @@ __global__ void __launch_bounds__(1024)
     s_hit_base = 0;
     s_hit_max = 0;
     s_big_n = 0;
+    s_n_apply_counts = 0;
+    s_n_apply_hits = 0;
   }
   if (tid <= kSizeClasses)
   {
@@ -881,6 +886,17 @@ __global__ void __launch_bounds__(1024)
       {
         atomicMax(&s_hit_max, hits);
         atomicAdd(&s_hclass[hitClass(hits)], 1u);
+      }
+      // What the walk kernel leaves to the apply kernels (inline_max_hits: the most samples the walk replays for a
+      // region it holds in one chunk; 0: it replays none): the counts of regions cut into several chunks, and the samples
+      // of regions that are not held by exactly one chunk or are too dense.
+      if (nchk > 1)
+      {
+        bs.apply_counts_list[atomicAdd(&s_n_apply_counts, 1u)] = h;
+      }
+      if (hits && (nchk != 1 || hits > inline_max_hits))
+      {
+        bs.apply_hits_list[atomicAdd(&s_n_apply_hits, 1u)] = h;
       }
     }
     // Inclusive scan of (segments, chunks, samples) over the 1024 threads: shuffles inside a wave, wave totals
@@ -1081,6 +1097,8 @@ __global__ void __launch_bounds__(1024)
     out.n_hits = s_hit_base;
     out.max_region_hits = s_hit_max;
     out.n_hit_regions = s_hclass[32];
+    out.n_apply_counts = s_n_apply_counts;
+    out.n_apply_hits = s_n_apply_hits;
     *bs.info = out;
     // Housekeeping that would otherwise be separate copy / fill launches on the batch's critical path: the host's copy
     // of the summary goes straight to pinned memory, the next batch's summary and the walk's counters start at zero.
@@ -3088,6 +3106,127 @@ __global__ void __launch_bounds__(1024)
 {
   applyCounts(blockIdx.x, mc, rt, bs, ray_flags, miss_counts, hit_mask, occupancy, clear_mask, hit_miss_counts,
               direct_chunk_segments, skip_masked, 0, traversal, traversal_acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The apply phase of occupancy-only maps (round 5).  The walk kernel applies every region it holds in ONE chunk itself --
+// counts and samples, straight from LDS -- so in the steady state of C1 the two kernels above found work in ~80 of
+// 1243 regions and spent their 46 us on workgroups and lanes that looked at a region or a sample and left.  k_plan now
+// lists the regions that DO need them (BatchScratch::apply_counts_list / apply_hits_list): the kernels below run over
+// those lists only, and the per-region bookkeeping every touched region needs moves to k_batch_cleanup.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kApplyListParts = 16;  ///< workgroups sharing one listed region's count application (whole mask words each)
+
+/// One launch for both lists (256-thread workgroups; the first hit_blocks of them replay samples, the others apply
+/// counts): a listed region's samples and its plain counts touch DIFFERENT voxels -- the count part skips every voxel
+/// whose sample-mask bit is set, those counts are the sample replay's (which applies and clears them) -- so the two run
+/// side by side instead of one behind the other (22 + 17 us as two launches: both are chains of dependent loads).
+///   sample part: workgroup (r, p) replays samples [256 p, 256 p + 256) of listed region r -- one lane per sample, the
+///     head of a voxel's run replays the run (applyHits); blocks_per_region covers the batch's densest region
+///   count part: workgroup (r, p) applies 1 / kApplyListParts of listed region r's counts (whole mask words)
+__global__ void __launch_bounds__(256)
+  k_apply_lists(MapConst mc, RegionTable rt, BatchScratch bs, unsigned ray_flags,
+                const unsigned long long *__restrict__ sorted, uint32_t *__restrict__ interval_counts,
+                uint32_t *__restrict__ miss_counts, const uint32_t *__restrict__ hit_mask,
+                const double *__restrict__ rays, float *__restrict__ occupancy, uint32_t hit_blocks,
+                uint32_t blocks_per_region)
+{
+  if (blockIdx.x < hit_blocks)
+  {
+    const uint32_t slot = rt.vals[bs.apply_hits_list[blockIdx.x / blocks_per_region]];
+    if (slot >= rt.slot_capacity)
+    {
+      return;
+    }
+    const uint32_t begin = bs.hit_begin[slot] & ~kSamplesApplied;
+    const uint32_t i = begin + (blockIdx.x % blocks_per_region) * 256u + threadIdx.x;
+    if (i < bs.hit_end[slot])
+    {
+      SecondaryLayers none{};
+      applyHits(i, mc, rt, bs, ray_flags, sorted, interval_counts, miss_counts, rays, occupancy, nullptr, none, nullptr);
+    }
+    return;
+  }
+  const uint32_t block = blockIdx.x - hit_blocks;
+  const uint32_t h = bs.apply_counts_list[block / kApplyListParts];
+  const uint32_t part = block % kApplyListParts;
+  const uint32_t slot = rt.vals[h];
+  if (slot >= rt.slot_capacity)
+  {
+    return;
+  }
+  const size_t base = size_t(slot) * size_t(mc.region_voxels);
+  const uint32_t words = uint32_t(mc.region_voxels + 31) >> 5;
+  const uint32_t *mask = hit_mask + size_t(slot) * words;
+  const uint32_t v_lo = uint32_t(uint64_t(words) * part / kApplyListParts) * 32u;
+  const uint32_t v_hi = min(uint32_t(uint64_t(words) * (part + 1u) / kApplyListParts) * 32u, uint32_t(mc.region_voxels));
+  if (mc.region_voxels % 4 == 0)
+  {
+    uint4 *counts4 = reinterpret_cast<uint4 *>(miss_counts + base);
+    float4 *occ4 = reinterpret_cast<float4 *>(occupancy + base);
+    for (uint32_t q = v_lo / 4u + threadIdx.x; q < v_hi / 4u; q += blockDim.x)
+    {
+      uint4 n = counts4[q];
+      if (n.x | n.y | n.z | n.w)
+      {
+        const uint32_t bits = (mask[(4u * q) >> 5] >> ((4u * q) & 31u)) & 15u;
+        n.x = (bits & 1u) ? 0u : n.x;
+        n.y = (bits & 2u) ? 0u : n.y;
+        n.z = (bits & 4u) ? 0u : n.z;
+        n.w = (bits & 8u) ? 0u : n.w;
+        const float4 before = occ4[q];
+        float4 o = before;
+        o.x = n.x ? occMissN(mc, ray_flags, o.x, n.x) : o.x;
+        o.y = n.y ? occMissN(mc, ray_flags, o.y, n.y) : o.y;
+        o.z = n.z ? occMissN(mc, ray_flags, o.z, n.z) : o.z;
+        o.w = n.w ? occMissN(mc, ray_flags, o.w, n.w) : o.w;
+        // (only the voxels that are this part's: a masked voxel's log-odds and count may be under the sample replay's
+        // hands right now)
+        float *o1 = occupancy + base + 4 * q;
+        uint32_t *c1 = miss_counts + base + 4 * q;
+        if (n.x) { if (o.x != before.x) { o1[0] = o.x; } c1[0] = 0; }
+        if (n.y) { if (o.y != before.y) { o1[1] = o.y; } c1[1] = 0; }
+        if (n.z) { if (o.z != before.z) { o1[2] = o.z; } c1[2] = 0; }
+        if (n.w) { if (o.w != before.w) { o1[3] = o.w; } c1[3] = 0; }
+      }
+    }
+    return;
+  }
+  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x)
+  {
+    const uint32_t n = miss_counts[base + vi];
+    if (n && !((mask[vi >> 5] >> (vi & 31u)) & 1u))
+    {
+      occupancy[base + vi] = occMissN(mc, ray_flags, occupancy[base + vi], n);
+      miss_counts[base + vi] = 0;
+    }
+  }
+}
+
+/// Every touched region back to its idle state: the sample mask cleared, the per-batch scratch reset (what applyCounts
+/// does for a region when k_apply_counts runs over all of them).
+__global__ void __launch_bounds__(256)
+  k_batch_cleanup(MapConst mc, RegionTable rt, BatchScratch bs, uint32_t n_touched, uint32_t *__restrict__ hit_mask)
+{
+  const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
+  for (uint32_t r = blockIdx.x; r < n_touched; r += gridDim.x)
+  {
+    const uint32_t h = bs.touched[r];
+    const uint32_t slot = rt.vals[h];
+    if (slot < rt.slot_capacity)
+    {
+      for (uint32_t w = threadIdx.x; w < mask_words; w += blockDim.x)
+      {
+        hit_mask[size_t(slot) * mask_words + w] = 0;
+      }
+    }
+    if (threadIdx.x == 0)
+    {
+      bs.seg_count[h] = 0;
+      bs.seg_cursor[h] = 0;
+      bs.touched_flag[h] = 0;
+    }
+  }
 }
 
 /// dst[i] &= mask

@@ -190,6 +190,11 @@ struct BatchInfo
   uint32_t n_hits;
   uint32_t max_region_hits;  ///< most samples any one region receives in the batch
   uint32_t n_hit_regions;    ///< regions receiving samples (length of the sort list)
+  /// Occupancy maps whose walk kernel applies single-chunk regions itself (counts and samples): how many regions are
+  /// left for the apply kernels -- regions cut into several chunks (their counts), and regions with samples that are cut
+  /// into several chunks, have no chunk at all, or hold more samples than the walk stages (their samples).
+  uint32_t n_apply_counts;
+  uint32_t n_apply_hits;
 };
 
 #ifdef OHMHIP_MAX_CHUNK_SEGMENTS

@@ -32,7 +32,11 @@ BatchScratch batchScratch(ohmhip_map_t m)
   bs.touched_flag = m->d_touched_flag + h;
   bs.touched = m->d_touched + h;
   bs.hit_count = m->d_hit_count + h;
-  bs.sort_list = m->d_sort_list + h;
+  // (three lists per parity in one allocation: regions receiving samples, regions whose counts / whose samples the apply
+  // kernels still have to process -- k_plan)
+  bs.sort_list = m->d_sort_list + 3 * h;
+  bs.apply_counts_list = bs.sort_list + m->hash_capacity;
+  bs.apply_hits_list = bs.sort_list + 2 * size_t(m->hash_capacity);
   bs.voxel_first_hit = m->d_voxel_first_hit;
   bs.hit_begin = m->d_hit_begin + c;
   bs.hit_end = m->d_hit_end + c;
@@ -236,7 +240,7 @@ int allocPool(ohmhip_map_t m, uint32_t capacity, uint32_t keep)
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_count), sizeof(uint32_t) * 2 * hash_cap));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_cursor), sizeof(uint32_t) * 2 * hash_cap));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_hit_count), sizeof(uint32_t) * 2 * hash_cap));
-    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_sort_list), sizeof(uint32_t) * 2 * hash_cap));
+    OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_sort_list), sizeof(uint32_t) * 6 * hash_cap));  // (3 lists x 2 parities)
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_seg_offset), sizeof(uint32_t) * 2 * hash_cap));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_touched_flag), sizeof(uint32_t) * 2 * hash_cap));
     OHMHIP_CHECK(zalloc(reinterpret_cast<void **>(&n_touched), sizeof(uint32_t) * 2 * hash_cap));
@@ -361,11 +365,12 @@ int rollbackTable(ohmhip_map_t m)
   OHMHIP_CHECK(hipMemsetAsync(m->d_keys, 0, sizeof(unsigned long long) * hash_words, s));
   OHMHIP_CHECK(hipMemsetAsync(m->d_vals, 0, sizeof(uint32_t) * hash_words, s));
   uint32_t *per_hash[] = { m->d_seg_count,  m->d_seg_cursor,   m->d_hit_count, m->d_seg_offset,
-                           m->d_touched_flag, m->d_touched,    m->d_sort_list };
+                           m->d_touched_flag, m->d_touched };
   for (uint32_t *p : per_hash)
   {
     OHMHIP_CHECK(hipMemsetAsync(p, 0, sizeof(uint32_t) * 2 * hash_words, s));  // (both parities)
   }
+  OHMHIP_CHECK(hipMemsetAsync(m->d_sort_list, 0, sizeof(uint32_t) * 6 * hash_words, s));  // (3 lists x 2 parities)
   const uint32_t keep = m->slots_committed;
   if (m->slot_capacity > keep)
   {
