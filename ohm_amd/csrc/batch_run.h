@@ -737,9 +737,11 @@ struct BatchRun
                          uint32_t(total), d_rays, static_cast<float *>(m->layers[OHMHIP_LID_TSDF]), heads, n_heads);
       if (info.n_touched)
       {
-        hipLaunchKernelGGL(k_apply_counts_tsdf, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
+        hipLaunchKernelGGL(k_apply_counts_tsdf, dim3(info.n_touched * kTsdfApplyParts), dim3(256), 0, s, m->mc, regionTable(m),
                            batchScratch(m), m->d_miss_counts, m->d_hit_mask,
                            static_cast<float *>(m->layers[OHMHIP_LID_TSDF]), direct_segments);
+        hipLaunchKernelGGL(k_batch_reset, dim3((info.n_touched + 255u) / 256u), dim3(256), 0, s, batchScratch(m),
+                           info.n_touched);
       }
     }
     return OHMHIP_OK;
