@@ -2317,6 +2317,13 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     uint32_t ray = 0;
     uint32_t skip = 0;      // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
     uint32_t end_last = 0;  // kSpecial only: the segment's last voxel is the ray's end voxel
+#ifdef OHMHIP_ABL_RANK
+    // Timing-only stand-in for the "rank" formulation of a step (profiles/r05_rank_probe.txt): the voxel of crossing k
+    // of one axis from two reciprocal multiplies and floors in fp32, no dependence on the previous step's compare.
+    // The constants are made up from the segment record (results are WRONG; lengths and the tile traffic are real).
+    float rk_k = 0.0f, rk_fa = 0.0f, rk_da = 0.0f, rk_ib = 0.0f, rk_cb = 0.0f, rk_ic = 0.0f, rk_cc = 0.0f;
+    float rk_sa = 0.0f, rk_sb = 0.0f, rk_sc = 0.0f, rk_base = 0.0f, rk_unc = 0.0f;
+#endif
     uint32_t qcount = 0;     // wave-uniform
     bool exhausted = false;  // wave-uniform
     uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0, dbg_slow = 0;  // wave-uniform (kTrace)
@@ -2385,6 +2392,20 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
             end_last = (rb.w & kSegEnd) ? 1u : 0u;
           }
           left = refill_only ? 0 : left;
+#ifdef OHMHIP_ABL_RANK
+          rk_k = 0.0f;
+          rk_fa = float(f0) * 0x1p-27f;
+          rk_da = float(d0) * 0x1p-27f;
+          rk_ib = __builtin_amdgcn_rcpf(float(d1 | 1u) * 0x1p-27f);
+          rk_cb = 1.0f - float(f1) * 0x1p-27f * rk_ib;
+          rk_ic = __builtin_amdgcn_rcpf(float(d2 | 1u) * 0x1p-27f);
+          rk_cc = 1.0f - float(f2) * 0x1p-27f * rk_ic;
+          rk_sa = float(sx);
+          rk_sb = float(sy);
+          rk_sc = float(sz);
+          rk_base = float(va);
+          rk_unc = 0.0f;
+#endif
         }
         if (!prefetched)
         {
@@ -2439,6 +2460,36 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           dbg_active += uint32_t(__popcll(__ballot(visit)));
         }
 
+#ifdef OHMHIP_ABL_RANK
+        {
+          const float t_cross = __builtin_fmaf(rk_k, rk_da, rk_fa);
+          const float xb = __builtin_fmaf(t_cross, rk_ib, rk_cb);
+          const float xc = __builtin_fmaf(t_cross, rk_ic, rk_cc);
+          const float fb = __builtin_floorf(xb);
+          const float fc = __builtin_floorf(xc);
+          rk_unc = __builtin_fmaxf(rk_unc, __builtin_fmaxf(__builtin_fabsf(xb - fb - 0.5f), __builtin_fabsf(xc - fc - 0.5f)));
+          const float nb = __builtin_amdgcn_fmed3f(fb, 0.0f, 31.0f);
+          const float nc = __builtin_amdgcn_fmed3f(fc, 0.0f, 31.0f);
+          const float idxf = __builtin_fmaf(nb, rk_sb, __builtin_fmaf(nc, rk_sc, __builtin_fmaf(rk_k, rk_sa, rk_base)));
+          // (optimistic: the uncertainty test once per trip)
+          const unsigned long long slow = (u == kWalkUnroll - 1) ? __ballot(left > 1 && rk_unc > 0.49999f) : 0ull;
+          if (__builtin_expect(slow != 0, 0))
+          {
+            int axis = 1;
+            if ((slow >> lane) & 1ull)
+            {
+              uint32_t r = ray;
+              asm volatile("" : "+v"(r));
+              axis = exactNextAxis(mc, args.walks[r], region_x, region_y, region_z, va >> 1);
+              rk_unc = 0.0f;
+            }
+            rk_k += float(axis);
+          }
+          va = uint32_t(int(idxf)) & 0xfffeu;
+          rk_k += 1.0f;
+          left -= 1;
+        }
+#else
         int stride;
         {
           // ---- one walk step from the fixed-point predictor (see Segment), taken by every lane.  The smallest
@@ -2496,6 +2547,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         }
         va += uint32_t(stride);
         left -= 1;
+#endif
       }
 
       // ---- deferred ordering of misses on masked voxels.  The returned tile words are consumed after the trip's last
