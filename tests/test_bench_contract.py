@@ -1,5 +1,6 @@
-"""CPU: the committed default bench line (profiles/r03_bench_default.json, produced by `python bench.py` on an MI355X)
-carries every field the bench contract names, with consistent arithmetic."""
+"""CPU: the committed default bench line (profiles/r05_bench_default.json, produced by `python bench.py` on an MI355X in
+the same gpurun call as profiles/r05_profile_final.txt and profiles/r05_traffic.json: scripts/profile_r05.sh) carries every
+field the bench contract names, with consistent arithmetic."""
 import json
 import os
 
@@ -7,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r03_bench_default.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as fh:
         line = json.load(fh)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -20,19 +21,29 @@ def test_committed_bench_line_has_the_contract_fields():
     roof = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_lower"):
         assert key in roof, key
-    with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r05_traffic.json")) as fh:
         traffic = json.load(fh)
     walk = traffic["kernels"]["k_region_walk"]
     assert roof["traffic"] == walk["bytes_upper"] and roof["traffic_lower"] == walk["bytes_lower"]
     assert roof["pipeline_traffic"] == traffic["batch_bytes_upper"]
     assert roof["pipeline_traffic_lower"] == traffic["batch_bytes_lower"]
     assert 2000.0 < roof["peak_measured_copy"] < roof["peak"]  # a device-to-device copy, GB/s read + write
-    # north_star: the dominant kernel at >= 0.40 of the HBM roofline
-    assert roof["frac"] >= 0.40
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
-    # achieved = algorithmic bytes per launch / the kernel's average duration (HIP events)
-    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * roof["achieved"]
+    # Basis since round 5: `achieved` / `frac` charge the algorithmic bytes to the whole batch interval
+    # on the device (every kernel of integrateRays) -- the same basis the C2 / C3 blocks use; the dominant kernel alone is
+    # kernel_achieved / kernel_frac.
+    step_s = line["ms_per_step"] * 1e-3
+    assert abs(roof["pipeline_ms"] * 1e-3 - step_s) / step_s < 0.02
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["pipeline_ms"] * 1e-3) / 1e9) < 1e-3 * roof["achieved"]
+    assert roof["frac"] == roof["pipeline_frac"] and 0.30 <= roof["frac"] < roof["kernel_frac"]
+    # the dominant kernel: algorithmic bytes per launch / the kernel's average duration (HIP stop events)
+    assert abs(roof["kernel_achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * roof["kernel_achieved"]
+    assert abs(roof["kernel_frac"] - roof["kernel_achieved"] / roof["peak"]) < 1e-9 and roof["kernel_frac"] >= 0.40
+    assert roof["kernel_ms"] < roof["pipeline_ms"]
+    # the two other C1 workloads the review asks for, top level: a fresh map's first pass and the moving sensor
+    for key in ("first_pass", "moving_sensor"):
+        assert line[key]["ms_per_step"] > line["ms_per_step"] and 0.0 < line[key]["pipeline_frac"] < roof["frac"], key
     visits = line["config"]["voxel_visits_per_step"]
     assert roof["algorithmic_bytes_per_launch"] == 44 * rays + 8 * visits
     cpu = line["cpu_baseline"]
@@ -53,17 +64,17 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_traffic_file_matches_the_profile_it_cites():
-    with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r05_traffic.json")) as fh:
         traffic = json.load(fh)
     walk = traffic["kernels"]["k_region_walk"]
     assert abs(walk["bytes_upper"] - (2.0 * walk["fetch_size_kb"] + walk["write_size_kb"]) * 1024.0) < 1024.0
     assert abs(walk["bytes_lower"] - (walk["fetch_size_kb"] + walk["write_size_kb"]) * 1024.0) < 1024.0
     total = sum(k["bytes_upper"] * k["launches_per_batch"] for k in traffic["kernels"].values())
     assert abs(total - traffic["batch_bytes_upper"]) < 1e-6 * total
-    summary = open(os.path.join(ROOT, "profiles", "r03_profile_final.txt")).read()
+    summary = open(os.path.join(ROOT, "profiles", "r05_profile_final.txt")).read()
     assert "k_region_walk" in summary and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary
     # the profile's average duration of the dominant kernel agrees with the bench line's HIP-event figure
-    with open(os.path.join(ROOT, "profiles", "r03_bench_default.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as fh:
         line = json.load(fh)
     row = [ln for ln in summary.splitlines() if ln.strip().startswith("k_region_walk")][0].split()
     avg_us = float(row[3])
