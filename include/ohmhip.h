@@ -372,6 +372,12 @@ int ohmhip_map_first_ray_time(ohmhip_map_t map, double *time);
  * count L is free once the count has reached L + 2 and a later integrate call has returned (or after ohmhip_map_sync).
  * Does not flush collected rays. */
 int ohmhip_map_batches_launched(ohmhip_map_t map, uint64_t *count);
+/* Maps whose regions are cut into tiles (LARGE REGIONS above): rays, among those that passed the filter, with an end in
+ * a region the reference still addresses (|region| <= 32767) but whose tile coordinates leave the key's 16-bit fields.
+ * Such a ray is not walked and, when it is the sample that lies out there, its sample is dropped -- the one place results
+ * differ from the CPU mappers run with the same region size; this count (since the map was created, rejected batches
+ * excluded) lets a caller see that it happened.  Always 0 for regions of up to 32768 voxels.  Flushes collected rays. */
+int ohmhip_map_rays_beyond_tiles(ohmhip_map_t map, uint64_t *count);
 
 /* Region table (replaces GpuLayerCache::lookup, ohmgpu/GpuLayerCache.cpp:104-119). keys = int16 xyz triples. */
 int ohmhip_map_region_count(ohmhip_map_t map, size_t *count);

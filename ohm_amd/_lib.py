@@ -142,6 +142,7 @@ _sigs = {
     "ohmhip_map_first_ray_time": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "ohmhip_map_set_phase_timing": (C.c_int, [_vp, C.c_int]),
     "ohmhip_map_batches_launched": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "ohmhip_map_rays_beyond_tiles": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ohmhip_map_line_keys": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, _vp, _vp]),
     "ohmhip_map_device_layer_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "ohmhip_map_region_slot": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),

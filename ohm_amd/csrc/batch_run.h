@@ -765,6 +765,7 @@ struct BatchRun
     m->segments_per_ray = std::max(1.0, double(info.n_segments) / double(std::max<uint32_t>(n_rays, 1u)));
     m->stats.regions_touched = info.n_touched;
     m->stats.regions_resident = info.n_slots;
+    m->rays_beyond_tiles += info.n_beyond_tiles;
     m->stats_pending = true;
     ++m->batch_seq;
     return OHMHIP_OK;

@@ -290,6 +290,7 @@ struct ohmhip_map_s
   ohmhip_batch_stats stats = {};
   bool stats_pending = false;
   uint64_t cache_hits = 0, cache_misses = 0, cache_full = 0;  ///< ohmhip_map_cache_stats
+  uint64_t rays_beyond_tiles = 0;  ///< ohmhip_map_rays_beyond_tiles (tiled maps: rays cut for key-range reasons)
   uint64_t memory_limit = 0;                                   ///< ohmhip_map_set_memory_limit
   /// Spill to host (ohmhip_map_set_spill_to_host): regions evicted from the pool when the memory limit is reached, by
   /// packed key.  A spilled region is still part of the map: it is listed, read and synced from here, and moves back

@@ -704,6 +704,10 @@ __global__ void __launch_bounds__(kBinThreads) __attribute__((amdgpu_waves_per_e
     }
     walks[ray] = rw;
     my_ok += (rw.flags & kRwPassed) ? 1u : 0u;
+    if (rw.flags & kRwBeyondTiles)
+    {
+      atomicAdd(&bs.info->n_beyond_tiles, 1u);  // (rare by construction: no LDS stage, no register kept for it)
+    }
     if (!(rw.flags & kRwValid))
     {
       continue;

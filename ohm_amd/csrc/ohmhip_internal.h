@@ -128,7 +128,10 @@ enum : unsigned
   kRwApplySample = 1u << 5,   ///< sample voxel receives the hit update
   kRwExcludeStart = 1u << 6,  ///< kRfExcludeOrigin
   kRwWalk = 1u << 7,          ///< ray part is walked (not kRfExcludeRay)
-  kRwPassed = 1u << 8         ///< the ray passed the ray filter (counted as integrated, like the reference's upload count)
+  kRwPassed = 1u << 8,        ///< the ray passed the ray filter (counted as integrated, like the reference's upload count)
+  /// Tiled maps only: an end of the ray lies in a region the reference addresses but whose TILE coordinates leave the
+  /// packed key's 16-bit fields (include/ohmhip.h, "LARGE REGIONS"); counted in BatchInfo::n_beyond_tiles.
+  kRwBeyondTiles = 1u << 9
 };
 
 /// One (ray, region) unit of line-walk work: "visit `count` voxels of ray `ray` starting at voxel `vi` of the region".
@@ -195,6 +198,7 @@ struct BatchInfo
   /// into several chunks, have no chunk at all, or hold more samples than the walk stages (their samples).
   uint32_t n_apply_counts;
   uint32_t n_apply_hits;
+  uint32_t n_beyond_tiles;  ///< rays with kRwBeyondTiles (tiled maps: dropped or cut short for key-range reasons)
 };
 
 #ifdef OHMHIP_MAX_CHUNK_SEGMENTS

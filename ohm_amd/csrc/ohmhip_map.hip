@@ -770,6 +770,19 @@ try
 }
 OHMHIP_ABI_CATCH
 
+int ohmhip_map_rays_beyond_tiles(ohmhip_map_t m, uint64_t *count)
+try
+{
+  if (!m || !count)
+  {
+    return OHMHIP_ERR_INVALID_ARG;
+  }
+  OHMHIP_SETTLE(m);
+  *count = m->rays_beyond_tiles;
+  return OHMHIP_OK;
+}
+OHMHIP_ABI_CATCH
+
 int ohmhip_map_batches_launched(ohmhip_map_t m, uint64_t *count)
 try
 {

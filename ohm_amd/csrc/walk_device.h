@@ -53,9 +53,13 @@ __device__ inline int pointToRegionVoxel(double coord, double voxel_resolution, 
 /// reference then hands out Key::kNull).  See keyIsNull() for the one addressable key that still reads as null.
 /// @param[out] region Region coordinate per axis.
 /// @param[out] local Local voxel coordinate per axis.
-__device__ inline bool voxelKey(const MapConst &mc, const double p[3], int region[3], int local[3])
+/// @param[out] beyond_tiles Optional: set when the point is addressable in the reference's sense and only the tile
+///   coordinates of a map cut into tiles leave the key's range.
+__device__ inline bool voxelKey(const MapConst &mc, const double p[3], int region[3], int local[3],
+                                bool *beyond_tiles = nullptr)
 {
   bool ok = true;
+  bool tiles_ok = true;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
   {
@@ -70,11 +74,15 @@ __device__ inline bool voxelKey(const MapConst &mc, const double p[3], int regio
     ok = ok && 0 <= q && q < mc.kdim[a];
     // (regions cut into tiles: the tile coordinate coord * tile_split + j has to fit the 16-bit field of the packed
     // key too -- include/ohmhip.h, "LARGE REGIONS")
-    ok = ok && coord * mc.tile_split[a] >= -32768 && coord * mc.tile_split[a] + (mc.tile_split[a] - 1) <= 32767;
+    tiles_ok = tiles_ok && coord * mc.tile_split[a] >= -32768 && coord * mc.tile_split[a] + (mc.tile_split[a] - 1) <= 32767;
     region[a] = coord;
     local[a] = q;
   }
-  return ok;
+  if (beyond_tiles)
+  {
+    *beyond_tiles = ok && !tiles_ok;
+  }
+  return ok && tiles_ok;
 }
 
 /// Key::isNull() is "all three region coordinates == int16 lowest" (ohm/Key.h:206): that one corner region reads as
@@ -284,8 +292,9 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
   rw.flags = kRwPassed;
 
   int r0[3], l0[3], r1[3], l1[3];
-  const bool addressable0 = voxelKey(mc, start, r0, l0);
-  const bool addressable1 = voxelKey(mc, end, r1, l1);
+  bool beyond0 = false, beyond1 = false;
+  const bool addressable0 = voxelKey(mc, start, r0, l0, &beyond0);
+  const bool addressable1 = voxelKey(mc, end, r1, l1, &beyond1);
   const bool ok0 = !keyIsNull(addressable0, r0);
   const bool ok1 = !keyIsNull(addressable1, r1);
   if (!ok0 || !ok1)
@@ -308,6 +317,8 @@ __device__ inline void setupRay(const MapConst &mc, double start[3], double end[
       }
       rw.flags = kRwPassed | kRwValid | kRwApplySample;
     }
+    // (the caller can see that rays were cut for key-range reasons: ohmhip_map_rays_beyond_tiles)
+    rw.flags |= (beyond0 || beyond1) ? unsigned(kRwBeyondTiles) : 0u;
     return;
   }
 

@@ -167,6 +167,7 @@ class GpuMap(RayMapper):
         self._borrowed = borrowed_map
         self._handle = L._vp()
         self._ok = False
+        self._block_addr = {}  # layer name -> {region key: (block, address)}: syncVoxels' destination pointers
         self._ray_segment_length = 0.0
         self._configure_layers()
         cfg = L.MapConfig()
@@ -387,6 +388,13 @@ class GpuMap(RayMapper):
         L.check(L.lib.ohmhip_map_batches_launched(self._handle, C.byref(n)), "batches_launched")
         return int(n.value)
 
+    def raysBeyondTiles(self):
+        """Maps with regions above 32768 voxels: rays cut because a tile coordinate left the key range although the
+        reference addresses the region (include/ohmhip.h: ohmhip_map_rays_beyond_tiles).  0 for ordinary regions."""
+        n = C.c_uint64(0)
+        L.check(L.lib.ohmhip_map_rays_beyond_tiles(self._handle, C.byref(n)), "rays_beyond_tiles")
+        return int(n.value)
+
     def wait(self):
         L.check(L.lib.ohmhip_map_sync(self._handle), "sync")
 
@@ -451,19 +459,29 @@ class GpuMap(RayMapper):
         keys = self.regionKeys(dirty_only=True)
         names = layer_names if layer_names is not None else self._map.layers
         rv = self._map.regionVoxelVolume()
+        key_tuples = [tuple(k) for k in keys.tolist()]
+        chunks = self._map.chunks
         for name in names:
             lid, dtype, comps = LAYERS[name]
-            blocks = []
-            for k in keys:
-                chunk = self._map.chunks.setdefault((int(k[0]), int(k[1]), int(k[2])), {})
-                if name not in chunk:
-                    chunk[name] = np.empty(rv * comps, dtype=dtype)  # fully overwritten by the copy below
-                blocks.append(chunk[name])
-            if not blocks:
+            # (block addresses are remembered per chunk: `ndarray.ctypes` costs a microsecond per block, which at C1's
+            # 1243 regions is a third of the copy itself)
+            cache = self._block_addr.setdefault(name, {})
+            ptrs = np.empty(len(key_tuples), dtype=np.uint64)
+            for i, k in enumerate(key_tuples):
+                chunk = chunks.get(k)
+                if chunk is None:
+                    chunk = chunks[k] = {}
+                block = chunk.get(name)
+                if block is None:
+                    block = chunk[name] = np.empty(rv * comps, dtype=dtype)  # fully overwritten by the copy below
+                cached = cache.get(k)
+                if cached is None or cached[0] is not block:
+                    cached = cache[k] = (block, block.ctypes.data)
+                ptrs[i] = cached[1]
+            if not len(key_tuples):
                 continue
-            ptrs = (C.c_void_p * len(blocks))(*[b.ctypes.data for b in blocks])
-            L.check(L.lib.ohmhip_map_read_regions(self._handle, lid, keys.ctypes.data, len(blocks), ptrs),
-                    "syncVoxels")
+            L.check(L.lib.ohmhip_map_read_regions(self._handle, lid, keys.ctypes.data, len(key_tuples),
+                                                  ptrs.ctypes.data_as(C.POINTER(C.c_void_p))), "syncVoxels")
         if layer_names is None:
             L.check(L.lib.ohmhip_map_clear_dirty(self._handle), "clear_dirty")
         self.wait()

@@ -547,6 +547,14 @@ public:
     ohmhip_map_batches_launched(handle_, &n);
     return n;
   }
+  /// Regions above 32768 voxels only: rays cut because a tile coordinate left the key range although the reference
+  /// addresses the region (include/ohmhip.h: ohmhip_map_rays_beyond_tiles).
+  uint64_t raysBeyondTiles() const
+  {
+    uint64_t n = 0;
+    ohmhip_map_rays_beyond_tiles(handle_, &n);
+    return n;
+  }
   /// OccupancyMap::setFirstRayTime / firstRayTime (ohm/OccupancyMap.h:342-351): the touch-time layer's time base; the
   /// ranks of a partitioned map share one.
   void setFirstRayTime(double time) { OHMHIP_GPUAPICHECK(ohmhip_map_set_first_ray_time(handle_, time)); }

@@ -5,10 +5,13 @@ from ohm_amd import _lib as L, synth
 rays = synth.rays_c1(n=1_000_000)
 buf = L._vp(); L.check(L.lib.ohmhip_buffer_create(C.byref(buf), rays.nbytes, 3)); L.check(L.lib.ohmhip_buffer_write(buf, rays.ctypes.data, rays.nbytes, 0, None, None, None))
 p = L._vp(); L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(p)))
+only = int(sys.argv[1]) if len(sys.argv) > 1 else -1  # one variant only (traces)
 for rep in range(2):
+    if only >= 0 and rep != only:
+        continue
     m = ohm_amd.OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
     g = ohm_amd.GpuMap(m, expected_element_count=(rays.shape[0] if rep else 2048), gpu_mem_size=8 << 30)
-    g.setPhaseTiming(True)
+    g.setPhaseTiming(only < 0)
     g.wait()
     for k in range(3):
         t0 = time.perf_counter(); g.integrateRaysDevice(p, rays.shape[0]); g.wait(); dt = time.perf_counter() - t0

@@ -177,3 +177,55 @@ def test_spill_to_host_with_large_regions(gpu):
     gm.syncVoxels()
     gm.close()
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
+
+
+def test_tile_key_range_boundary_is_pinned_and_counted(gpu):
+    """include/ohmhip.h "LARGE REGIONS": tile coordinates share the packed key's 16-bit fields, so a 64^3 region (8 z
+    slabs) is addressable for region z in [-4096, 4095] only, where the reference addresses +-32767
+    (ohm/MapRegion.cpp:32-69).  Pinned here: the last addressable region behaves like any other (parity with the oracle,
+    nothing counted), a ray one region further is neither walked nor sampled, and ohmhip_map_rays_beyond_tiles counts it
+    (such rays must not vanish silently)."""
+    dims = (64, 64, 64)
+    edge = 6.4
+    map_ = OccupancyMap(0.1, dims, layers=("occupancy", "mean"))
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    z_in = 4095 * edge          # centre of the last addressable region along z
+    z_out = 4096 * edge         # one region further: region 4096 x 8 tiles = 32768 > int16
+    inside = np.array([[0.05, 0.05, z_in + 0.05], [0.35, 0.05, z_in + 0.25]])
+    assert gm.integrateRays(inside) == 2
+    om.integrate_occupancy(inside)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
+    assert (0, 0, 4095) in map_.chunks and gm.raysBeyondTiles() == 0
+    # the same at the negative end: region -4096 is the last one there
+    low = np.array([[0.05, 0.05, -4096 * edge + 0.05], [0.35, 0.05, -4096 * edge + 0.25]])
+    assert gm.integrateRays(low) == 2
+    om.integrate_occupancy(low)
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
+    assert (0, 0, -4096) in map_.chunks and gm.raysBeyondTiles() == 0
+    regions_before = len(gm.regionKeys())
+    # entirely beyond: passes the filter (counted as integrated, like the reference's upload count), changes nothing
+    beyond = np.array([[0.05, 0.05, z_out + 0.05], [0.35, 0.05, z_out + 0.25]])
+    assert gm.integrateRays(beyond) == 2
+    assert gm.raysBeyondTiles() == 1
+    # crossing the limit: start in region 4095, sample in region 4096 -> not walked, sample dropped
+    crossing = np.array([[0.05, 0.05, z_in + 3.15], [0.05, 0.05, z_in + 3.35]])
+    assert gm.integrateRays(crossing) == 2
+    assert gm.raysBeyondTiles() == 2
+    below = np.array([[0.05, 0.05, -4097 * edge + 0.05], [0.35, 0.05, -4097 * edge + 0.25]])
+    assert gm.integrateRays(below) == 2
+    assert gm.raysBeyondTiles() == 3
+    gm.syncVoxels()
+    assert len(gm.regionKeys()) == regions_before
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy", "mean"], exact_float=True))
+    gm.close()
+    # ordinary regions: the reference's own range applies, nothing is ever counted
+    m32 = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    g32 = GpuMap(m32)
+    far = np.array([[0.05, 0.05, 32767 * 3.2 + 0.05], [0.35, 0.05, 32767 * 3.2 + 0.25]])
+    assert g32.integrateRays(far) == 2
+    g32.syncVoxels()
+    assert (0, 0, 32767) in m32.chunks and g32.raysBeyondTiles() == 0
+    g32.close()
