@@ -94,9 +94,24 @@ def main():
             pin4 = D.PartitionedIntegrator(gm4, part, comm=comm3)
             steps = [torch.from_numpy(synth.rays_c1(n=90000 + 7000 * k, seed=50 + k, first=40000 * k)).cuda()
                      for k in range(7)]
-            for t in steps:
+            # (the receive ring advances per LAUNCHED batch.  Steps 2 and 5 are small -- their rays are only
+            # collected, no batch is launched -- and must leave the ring where it is: the buffers of the two batches
+            # still in flight stay untouched, and the small step's own buffer is free when its call returns.)
+            small = {2: torch.from_numpy(synth.rays_c1(n=3000, seed=70)).cuda(),
+                     5: torch.from_numpy(synth.rays_c1(n=2500, seed=71)).cuda()}
+            order = []
+            for k, t in enumerate(steps):
+                if k in small:
+                    launched = gm4.batchesLaunched()
+                    in_use = [v for v in pin4._recv_batch if v]
+                    assert pin4.integrateRays(small[k]) == small[k].shape[0]
+                    assert gm4.batchesLaunched() == launched and [v for v in pin4._recv_batch if v] == in_use
+                    order.append(small[k])
+                launched = gm4.batchesLaunched()
                 assert pin4.integrateRays(t) == t.shape[0]
-            for t in steps:
+                assert gm4.batchesLaunched() > launched
+                order.append(t)
+            for t in order:
                 gm5.integrateRays(t.cpu().numpy())
             gm4.syncVoxels()
             gm5.syncVoxels()
