@@ -366,6 +366,19 @@ struct BatchRun
     uint64_t want_events =
       std::max<uint64_t>({ uint64_t(1) << 20, info.visits / 4, uint64_t(m->event_demand) * 5 / 4 });
     want_events = std::min<uint64_t>(want_events, 0xfffffff0ull - n_rays);
+    if (occupancy_mode)
+    {
+      // The visit count is a bound, not an estimate: an occupancy walk resolves deferred misses in LDS and only regions
+      // too dense for that use the list (C1: none).  A list that already holds 16 events per ray -- what
+      // ohmhip_map_reserve_rays sets aside -- is therefore grown on a measured demand only, not on the bound: growing it
+      // is a hipMalloc in the middle of a fresh map's first batch (0.14 ms of idle device, round 5), and a batch that
+      // does overflow it falls back to resolving in place for that one batch.
+      const uint64_t have = m->events.bytes / sizeof(unsigned long long);
+      if (have >= std::max<uint64_t>(uint64_t(1) << 20, 16ull * n_rays))
+      {
+        want_events = std::max<uint64_t>(std::min(want_events, have), uint64_t(m->event_demand) * 5 / 4);
+      }
+    }
     if (m->event_limit)
     {
       want_events = std::min<uint64_t>(want_events, m->event_limit);  // (test knob: forces the overflow path)
@@ -790,13 +803,37 @@ int integrateBatch(ohmhip_map_t m, const double *d_rays, const float *d_intensit
         continue;
       }
     }
+    // (OHMHIP_DEBUG_FLAGS & 8192: host time of each step of the launch sequence, microseconds)
+    const bool host_times = (m->debug_flags & 8192u) != 0;
+    auto t_host = std::chrono::steady_clock::now();
+    double step_us[6] = { 0, 0, 0, 0, 0, 0 };
+    auto lap = [&](int k) {
+      if (host_times)
+      {
+        const auto now = std::chrono::steady_clock::now();
+        step_us[k] = std::chrono::duration<double, std::micro>(now - t_host).count();
+        t_host = now;
+      }
+    };
     OHMHIP_CHECK(run.commitRegions());
+    lap(0);
     scheduleWriteBack(m, uint32_t(m->batch_seq + 1u));  // (spill to host: keep the next eviction's victims clean)
     OHMHIP_CHECK(run.sizeBuffers());
+    lap(1);
     OHMHIP_CHECK(run.binAndOrder());
+    lap(2);
     OHMHIP_CHECK(run.walk());
+    lap(3);
     OHMHIP_CHECK(run.occupancy_mode ? run.applyOccupancy() : run.replayEvents());
-    return run.finish();
+    lap(4);
+    const int finish_err = run.finish();
+    lap(5);
+    if (host_times)
+    {
+      std::fprintf(stderr, "[ohmhip host] batch %llu: commit %.0f size %.0f bin+order %.0f walk %.0f apply %.0f finish %.0f us\n",
+                   (unsigned long long)m->batch_seq, step_us[0], step_us[1], step_us[2], step_us[3], step_us[4], step_us[5]);
+    }
+    return finish_err;
   }
   return OHMHIP_ERR_CAPACITY;
 }

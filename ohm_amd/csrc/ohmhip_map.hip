@@ -294,6 +294,27 @@ try
   {
     m->refill_min_idle = std::max(1, std::min(64, std::atoi(env)));
   }
+  {
+    // The walk kernel spills ~150 bytes per lane, k_ray_setup 24: the first dispatch that needs more private memory
+    // than its hardware queue has set aside stalls in the command processor until the runtime has grown the queue's
+    // scratch -- 0.13 ms of idle device between the sample sort and the walk of a fresh map's FIRST batch (kernel trace,
+    // round 5; every map brings its own streams).  Paid here instead: one empty launch of the hungriest instantiation
+    // on each of the map's streams (no chunk to fetch: the workgroup leaves at once).
+    WalkArgs wa{};
+    wa.mc = m->mc;
+    wa.bs = batchScratch(m);
+    wa.n_chunks = 0;
+    wa.chunk_cursor = batchEventCount(m) + 1;
+    for (hipStream_t stream : { m->stream, m->front_stream })
+    {
+      hipLaunchKernelGGL((k_region_walk<true, false>), dim3(1), dim3(kWalkThreads), lds_bytes, stream, wa);
+      if ((err = hipMemsetAsync(batchEventCount(m), 0, 2 * sizeof(uint32_t), stream)) != 0 ||
+          (err = hipStreamSynchronize(stream)) != 0)
+      {
+        return fail(err);
+      }
+    }
+  }
   *map = m;
   return OHMHIP_OK;
 }
@@ -737,7 +758,7 @@ try
                                                     static_cast<unsigned long long *>(m->hit_keys_b.ptr), keys, 0,
                                                     sortEndBit(m), s));
   OHMHIP_CHECK(m->sort_temp.ensure(sort_bytes, false, s));
-  // ray-region segments: the running estimate (10 per ray until a batch has been seen) with some head room
+  // ray-region segments: the running estimate (10 per ray until a batch has been seen: C1 has 9.3) with some head room
   OHMHIP_CHECK(m->segments.ensure(sizeof(Segment) * size_t(double(n) * std::max(m->segments_per_ray, 10.0) * 1.25), false, s));
   OHMHIP_CHECK(hipStreamSynchronize(s));
   return OHMHIP_OK;

@@ -7,7 +7,7 @@ buf = L._vp(); L.check(L.lib.ohmhip_buffer_create(C.byref(buf), rays.nbytes, 3))
 p = L._vp(); L.check(L.lib.ohmhip_buffer_ptr(buf, C.byref(p)))
 only = int(sys.argv[1]) if len(sys.argv) > 1 else -1  # one variant only (traces)
 for rep in range(2):
-    if only >= 0 and rep != only:
+    if only in (0, 1) and rep != only:
         continue
     m = ohm_amd.OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
     g = ohm_amd.GpuMap(m, expected_element_count=(rays.shape[0] if rep else 2048), gpu_mem_size=8 << 30)

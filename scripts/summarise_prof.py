@@ -34,6 +34,8 @@ for f in find("*counter_collection.csv"):
     launches = defaultdict(set)
     with open(f) as fh:
         for row in csv.DictReader(fh):
+            if row.get("Grid_Size") and row.get("Grid_Size") == row.get("Workgroup_Size") and "k_region_walk" in row.get("Kernel_Name", ""):
+                continue  # the one-workgroup launches of map creation (queue scratch warm-up), not batches
             k = short(row.get("Kernel_Name", "?"))
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"] or 0)
             launches[k].add(row.get("Dispatch_Id"))

@@ -28,6 +28,8 @@ def counters(pattern, counter):
             for row in csv.DictReader(fh):
                 if row["Counter_Name"] != counter:
                     continue
+                if row.get("Grid_Size") and row.get("Grid_Size") == row.get("Workgroup_Size") and "k_region_walk" in row.get("Kernel_Name", ""):
+                    continue  # the one-workgroup launches of map creation (queue scratch warm-up), not batches
                 k = short(row.get("Kernel_Name", "?"))
                 agg[k] += float(row["Counter_Value"] or 0)
                 launches[k].add(row.get("Dispatch_Id"))
