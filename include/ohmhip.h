@@ -326,8 +326,11 @@ int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
  * that alone touches more regions than the limit allows is integrated as two halves in ray order (and those again, down
  * to single rays: the reference finalises what it has enqueued when its cache fills in the middle of a batch and carries
  * on, ohmgpu/GpuMap.cpp:900-996; results are those of the whole batch -- except on maps with a traversal layer, whose
- * exit range is carried within a call: there, and for a single ray that still does not fit, the call fails with
- * OHMHIP_ERR_CAPACITY and changes nothing).  Turning spilling on sets the batch coalescing threshold to 0 (a collected
+ * exit range is carried within a call: there the call fails with OHMHIP_ERR_CAPACITY and changes nothing.  When a LATER
+ * half -- in the end a single ray -- still does not fit, the call returns OHMHIP_ERR_CAPACITY with the halves before it
+ * applied: `*integrated` then counts the leading elements that were integrated and must not be presented again; the
+ * host mirrors put that count into the exception they raise).  Only this cause splits a batch: a full hash, a refused
+ * allocation or the end of the slot field fail at once and change nothing.  Turning spilling on sets the batch coalescing threshold to 0 (a collected
  * batch touches the regions of all its calls at once). */
 int ohmhip_map_set_spill_to_host(ohmhip_map_t map, int enable);
 /* The background write-back of the spill path (see WRITE-BACK above), opt-in: off by default. */
@@ -337,9 +340,10 @@ int ohmhip_map_sync(ohmhip_map_t map);
 int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);
 
 /* Device phase times of one of the last 32 batches (batches_back = 0: the latest): ms[0] the device time the batch cost
- * -- first kernel start -> last kernel end, or, for batches presented back to back, the interval between the previous
- * batch's last kernel and this one's (a batch's set-up pass runs on a second stream under the previous batch's last
- * kernels) --, ms[1] ray setup + binning (the set-up pass is timed from the moment it may start: queued behind a running
+ * -- first kernel start -> last kernel end, or, for batches that overlapped (this batch's plan had ended before the
+ * previous batch's last kernel did), the interval between the previous batch's last kernel and this one's (a batch's
+ * set-up pass runs on a second stream under the previous batch's last kernels); a batch presented after the device went
+ * idle keeps its own span, host idle time between batches is never counted --, ms[1] ray setup + binning (the set-up pass is timed from the moment it may start: queued behind a running
  * walk kernel it mostly waits for CUs), ms[2] the region walk kernel, ms[3] sample ordering + ordered apply.
  * hipEvents on the map's streams (the gputil::Event / Queue::mark() bookkeeping of ohmgpu/GpuMap.cpp:1036-1191 serves
  * the same purpose); waits for that batch only.  Lets a caller time a run of batches without synchronising after each. */
@@ -357,7 +361,9 @@ int ohmhip_map_set_phase_timing(ohmhip_map_t map, int enable);
 /* The per-batch device buffers (ray set-up records, ray-region segments, sample keys, sort scratch) are grown by the
  * batch that first needs them -- a few hipMalloc calls, each a device synchronisation, inside that call.  The reference's
  * GpuMap constructor sizes its key / ray buffers for `expected_element_count` up front (ohmgpu/GpuMap.cpp:429-470); this is
- * the counterpart: size everything a batch of `ray_count` rays needs now.  Optional; batches of any size still work. */
+ * the counterpart: size everything a batch of `ray_count` rays needs now (the deferred-event list: 16 per ray, at most
+ * 2^27 events).  Optional; batches of any size still work, and the host mirrors treat a failing reservation as "grow on
+ * demand", not as an error. */
 int ohmhip_map_reserve_rays(ohmhip_map_t map, size_t ray_count);
 /* OccupancyMap::firstRayTime / setFirstRayTime (ohm/OccupancyMap.h:342-351): the time base the touch-time layer is
  * encoded against (milliseconds since it, ohm/VoxelTouchTimeCompute.h:24-37).  Like the reference the map takes it from

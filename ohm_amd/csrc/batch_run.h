@@ -314,6 +314,8 @@ struct BatchRun
         const uint64_t allowed =
           m->memory_limit ? std::min<uint64_t>(m->memory_limit / per_region, kMaxRegionSlots) : m->slot_capacity;
         const uint64_t wanted = uint64_t(info.n_slots);  // committed + the batch's new regions
+        // (the one cause integrateRaysDevice answers by presenting the batch in halves: the batch ALONE does not fit)
+        m->batch_exceeds_limit = wanted > allowed && wanted - allowed > m->slots_committed;
         if (wanted > allowed && wanted - allowed <= m->slots_committed)
         {
           const int evict_err = evictColdRegions(m, uint32_t(wanted - allowed));
@@ -616,12 +618,15 @@ struct BatchRun
       // The walk applied every region it held in one chunk: the apply kernels run over k_plan's lists of the others
       // (C1: ~80 of 1243 regions; 46 -> ~20 us), the bookkeeping of all touched regions is k_batch_cleanup's.
       const uint32_t blocks_per_region = std::max<uint32_t>((info.max_region_hits + 255u) / 256u, 1u);
-      const uint32_t hit_blocks = info.n_apply_hits * blocks_per_region;
+      // (64 bits, and capped: with kRfExcludeRay every sample region is listed, and a skewed multi-million-ray batch then
+      // asks for listed regions x tiles of the densest one -- the sample part strides over the pairs instead)
+      const unsigned long long hit_tiles = (unsigned long long)info.n_apply_hits * blocks_per_region;
+      const uint32_t hit_blocks = uint32_t(std::min<unsigned long long>(hit_tiles, 1ull << 20));
       if (hit_blocks + info.n_apply_counts)
       {
         hipLaunchKernelGGL(k_apply_lists, dim3(hit_blocks + info.n_apply_counts * kApplyListParts), dim3(256), 0, s, m->mc,
                            regionTable(m), batchScratch(m), ray_flags, sorted, intervals, m->d_miss_counts, m->d_hit_mask,
-                           d_rays, occ, hit_blocks, blocks_per_region);
+                           d_rays, occ, hit_blocks, blocks_per_region, hit_tiles);
       }
       if (info.n_touched)
       {

@@ -344,6 +344,9 @@ struct ohmhip_map_s
   uint64_t writebacks = 0, writeback_hits = 0, writeback_stale = 0;
   uint32_t writeback_workgroups = 32;  ///< grid of the background copy kernel (OHMHIP_WRITEBACK_WGS): the CUs it may hold
   bool spill_enabled = false;
+  /// The last batch failed with OHMHIP_ERR_CAPACITY because it alone touches more regions than the residency limit
+  /// holds (not: hash full, device memory, slot field) -- the cause integrateRaysDevice answers by splitting the batch.
+  bool batch_exceeds_limit = false;
   uint64_t evictions = 0, readmissions = 0;
   double wb_host_ms = 0;  ///< OHMHIP_DEBUG_FLAGS & 512: host time spent scheduling write-backs
   double spill_ms[6] = { 0, 0, 0, 0, 0, 0 };  ///< OHMHIP_DEBUG_FLAGS & 512: evict select / copy / compact, readmit copy, failed attempts, store growth

@@ -3185,21 +3185,28 @@ __global__ void __launch_bounds__(256)
                 const unsigned long long *__restrict__ sorted, uint32_t *__restrict__ interval_counts,
                 uint32_t *__restrict__ miss_counts, const uint32_t *__restrict__ hit_mask,
                 const double *__restrict__ rays, float *__restrict__ occupancy, uint32_t hit_blocks,
-                uint32_t blocks_per_region)
+                uint32_t blocks_per_region, unsigned long long hit_tiles)
 {
   if (blockIdx.x < hit_blocks)
   {
-    const uint32_t slot = rt.vals[bs.apply_hits_list[blockIdx.x / blocks_per_region]];
-    if (slot >= rt.slot_capacity)
+    // (region, 256-sample tile) pairs, strided over the sample part's workgroups: hit_blocks == hit_tiles except for
+    // skewed multi-million-ray batches, whose product of listed regions and tiles of the densest one is capped by the
+    // host (the product used to be the grid, in 32 bits).
+    for (unsigned long long tile = blockIdx.x; tile < hit_tiles; tile += hit_blocks)
     {
-      return;
-    }
-    const uint32_t begin = bs.hit_begin[slot] & ~kSamplesApplied;
-    const uint32_t i = begin + (blockIdx.x % blocks_per_region) * 256u + threadIdx.x;
-    if (i < bs.hit_end[slot])
-    {
-      SecondaryLayers none{};
-      applyHits(i, mc, rt, bs, ray_flags, sorted, interval_counts, miss_counts, rays, occupancy, nullptr, none, nullptr);
+      const uint32_t slot = rt.vals[bs.apply_hits_list[uint32_t(tile / blocks_per_region)]];
+      if (slot >= rt.slot_capacity)
+      {
+        continue;
+      }
+      const uint32_t begin = bs.hit_begin[slot] & ~kSamplesApplied;
+      const uint32_t i = begin + uint32_t(tile % blocks_per_region) * 256u + threadIdx.x;
+      if (i < bs.hit_end[slot])
+      {
+        SecondaryLayers none{};
+        applyHits(i, mc, rt, bs, ray_flags, sorted, interval_counts, miss_counts, rays, occupancy, nullptr, none,
+                  nullptr);
+      }
     }
     return;
   }

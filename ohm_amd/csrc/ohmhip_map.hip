@@ -680,8 +680,12 @@ try
   if (uint64_t(batches_back) + 1 < m->batch_seq && batches_back + 1 < kTimingRing)
   {
     const uint32_t prev_ring = uint32_t((m->batch_seq - 2 - batches_back) % kTimingRing);
-    float period = 0;
-    if (((m->tev_mask[prev_ring] >> 4) & 1u) &&
+    // Only for batches that really overlapped: this batch's plan had ended before the previous batch's last kernel did.
+    // A batch presented after the device went idle (one batch per sensor frame, a host wait in between) keeps its own
+    // span -- the gap to the previous batch is host idle time, not device time.
+    float period = 0, lead = 0;
+    if (((m->tev_mask[prev_ring] >> 4) & 1u) && has(5) &&
+        hipEventElapsedTime(&lead, m->tev[prev_ring][4], tev[5]) == hipSuccess && lead <= 0 &&
         hipEventElapsedTime(&period, m->tev[prev_ring][4], tev[4]) == hipSuccess && period > 0 &&
         (period < ms[0] || !has(0)))
     {
@@ -744,7 +748,10 @@ try
     OHMHIP_CHECK(m->wg_region_count[p].ensure(sizeof(uint32_t) * size_t(blocks), false, s));
   }
   const bool occupancy = m->config.mode == OHMHIP_MODE_OCCUPANCY;
-  const size_t events = std::max<size_t>(size_t(1) << 20, n * 64);  // (visits / 4 at ~256 visits per ray)
+  // 16 events per ray -- the threshold above which sizeBuffers() grows the list on measured demand only -- and never more
+  // than 2^27 (1 GiB of keys): a generous expected_element_count must not allocate gigabytes outside the memory limit
+  // (ADVICE r5); a batch that needs more grows the list on demand as before.
+  const size_t events = std::min<size_t>(std::max<size_t>(size_t(1) << 20, n * 16), size_t(1) << 27);
   const size_t keys = occupancy ? n : n + events;
   OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * keys, false, s));
   OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * keys, false, s));

@@ -54,6 +54,7 @@ int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_cou
     m->first_ray_time = first;
   }
   int err = OHMHIP_ERR_UNSUPPORTED;
+  m->batch_exceeds_limit = false;
   switch (m->config.mode)
   {
   case OHMHIP_MODE_OCCUPANCY:
@@ -85,8 +86,11 @@ int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_cou
   default:
     break;
   }
-  if (err == OHMHIP_ERR_CAPACITY && m->spill_enabled && n_rays >= 2 && !m->layers[OHMHIP_LID_TRAVERSAL])
+  if (err == OHMHIP_ERR_CAPACITY && m->spill_enabled && m->batch_exceeds_limit && n_rays >= 2 &&
+      !m->layers[OHMHIP_LID_TRAVERSAL])
   {
+    // (only this cause: a full hash, a refused hipMalloc or the slot field's end would cost log2(n) futile attempts,
+    // each with a roll-back and a device synchronisation -- ADVICE r5)
     // The batch alone touches more regions than the residency limit leaves room for (even with everything else moved
     // to the host store).  The reference meets a full cache in the middle of a batch by finalising what it has
     // enqueued and carrying on with the rest (ohmgpu/GpuMap.cpp:900-996, enqueueRegions' flush / retry); the
@@ -96,15 +100,27 @@ int integrateRaysDevice(ohmhip_map_t m, const double *d_rays, size_t element_cou
     const size_t half = n_rays / 2;
     size_t done_a = 0, done_b = 0;
     err = integrateRaysDevice(m, d_rays, half * 2, d_intensities, d_timestamps, ray_flags, &done_a, d_filter_flags);
+    const ohmhip_batch_stats stats_a = m->stats;
     if (err == OHMHIP_OK)
     {
       err = integrateRaysDevice(m, d_rays + half * 6, (n_rays - half) * 2, d_intensities ? d_intensities + half : nullptr,
                                 d_timestamps ? d_timestamps + half : nullptr, ray_flags, &done_b,
                                 d_filter_flags ? d_filter_flags + half : nullptr);
+      if (err == OHMHIP_OK)
+      {
+        // the call's statistics cover both halves
+        m->stats.rays_in += stats_a.rays_in;
+        m->stats.rays_integrated += stats_a.rays_integrated;
+        m->stats.voxel_visits += stats_a.voxel_visits;
+        m->stats.ray_region_segments += stats_a.ray_region_segments;
+        m->stats.regions_touched = std::max(m->stats.regions_touched, stats_a.regions_touched);
+      }
     }
     if (integrated)
     {
-      *integrated = done_a + done_b;  // (what the first half integrated stays integrated if the second fails)
+      // What the first half integrated STAYS integrated if the second fails (include/ohmhip.h): the count says how many
+      // leading elements of the caller's arrays must not be presented again.
+      *integrated = done_a + done_b;
     }
     return err;
   }

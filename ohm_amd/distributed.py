@@ -631,18 +631,26 @@ class PartitionedIntegrator:
             L.check(L.lib.ohmhip_device_synchronize(), "device_synchronize")
             L.check(L.lib.ohmhip_buffer_read(tmp, first.ctypes.data, 8, 0, None, None, None), "buffer_read")
             L.lib.ohmhip_buffer_destroy(tmp)
+        # A base a map already holds (set by the caller, or taken from an earlier un-partitioned batch) is never overwritten
+        # (ADVICE r5): it travels in the same all-gather, and where any rank holds one the lowest such rank's base is what
+        # the ranks WITHOUT one adopt -- like integrate_partitioned_in_process, which only sets a base that is < 0.
+        held = self.gpu_map.firstRayTime()
+        pair = np.array([first[0], held if held >= 0 else np.nan], dtype=np.float64)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world > 1:
             device = "cpu" if dist.get_backend(self.group) == "gloo" else "cuda"
-            mine = torch.tensor(first, dtype=torch.float64, device=device)
+            mine = torch.tensor(pair, dtype=torch.float64, device=device)
             every = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(every, mine, group=self.group)
-            stamps = [float(t.item()) for t in every]
+            pairs = [(float(t[0].item()), float(t[1].item())) for t in every]
         else:
-            stamps = [float(first[0])]
-        known = [t for t in stamps if t == t]  # (NaN: that rank has no rays in this batch)
-        if known:
-            self.gpu_map.setFirstRayTime(known[0])
+            pairs = [(float(pair[0]), float(pair[1]))]
+        bases = [b for _, b in pairs if b == b]
+        known = [t for t, _ in pairs if t == t]  # (NaN: that rank has no rays in this batch)
+        agreed = bases[0] if bases else (known[0] if known else None)
+        if agreed is not None:
+            if held < 0:
+                self.gpu_map.setFirstRayTime(agreed)
             self._time_base_set = True
 
     def _side_buffer(self, store, name, rays, dtype):
@@ -679,7 +687,8 @@ class PartitionedIntegrator:
         if d_timestamps is not None and not self._time_base_set:
             # One time base for the whole partitioned map (OccupancyMap::firstRayTime, the touch-time layer's zero): the
             # first stamp of the lowest rank that has rays -- what ONE map integrating rank 0's batch, then rank 1's, ...
-            # would have taken.  Collective (an all-gather of one double per rank).
+            # would have taken.  Collective (an all-gather of two doubles per rank): EVERY rank must pass the side arrays
+            # consistently -- a rank that omits timestamps while its peers pass them does not enter this collective.
             self._agree_on_time_base(d_timestamps if n_local else None)
         launched = gm.batchesLaunched()
         # (when the previous integrate call returned, every batch but the two launched last had ended)

@@ -193,7 +193,8 @@ class GpuMap(RayMapper):
         if expected_element_count > 2048:
             # the reference sizes its ray / key buffers for expected_element_count points in the constructor
             # (ohmgpu/GpuMap.cpp:429-470); the default (2048) is left to the first batch
-            L.check(L.lib.ohmhip_map_reserve_rays(self._handle, int(expected_element_count) // 2), "reserve_rays")
+            # best effort: a reservation the device cannot hold is not an error, the batches grow their buffers on demand
+            L.lib.ohmhip_map_reserve_rays(self._handle, int(expected_element_count) // 2)
         self._upload_existing()
 
     def _fill_map_values(self, cfg):
@@ -341,8 +342,14 @@ class GpuMap(RayMapper):
             raise L.OhmHipError(status, "GpuMap.integrateRays")
         if status != L.OK:
             self._last_error = status
+            self._last_partial = int(done.value)  # leading elements a split batch did integrate (include/ohmhip.h)
             return 0
         return int(done.value)
+
+    def lastPartialCount(self):
+        """After a failed integrateRays: how many leading elements of that call WERE integrated (non-zero only when a
+        batch over the residency limit was split and a later part still did not fit); do not present those again."""
+        return getattr(self, "_last_partial", 0)
 
     def integrateRaysDevice(self, d_rays_ptr, element_count, ray_update_flags=RayFlag.kRfDefault, d_intensities=None,
                             d_timestamps=None):
@@ -353,7 +360,9 @@ class GpuMap(RayMapper):
         done = C.c_size_t(0)
         status = L.lib.ohmhip_map_integrate_rays_device(self._handle, d_rays_ptr, element_count, d_intensities,
                                                         d_timestamps, int(ray_update_flags), C.byref(done))
-        L.check(status, "GpuMap.integrateRaysDevice")
+        if status != L.OK:
+            self._last_partial = int(done.value)
+            raise L.OhmHipError(status, "GpuMap.integrateRaysDevice (%d leading elements integrated)" % done.value)
         return int(done.value)
 
     def stats(self):

@@ -446,6 +446,7 @@ public:
     }
     last_status_ = ohmhip_map_integrate_rays(handle_, reinterpret_cast<const double *>(rays), element_count,
                                              intensities, timestamps, ray_update_flags, &integrated);
+    last_partial_ = (last_status_ == OHMHIP_OK) ? 0 : integrated;
     return (last_status_ == OHMHIP_OK) ? integrated : 0;
   }
   /// glm-compatible overload: any 3-double point type.
@@ -481,6 +482,9 @@ public:
     return (last_status_ == OHMHIP_OK) ? integrated : 0;
   }
   int lastStatus() const { return last_status_; }
+  /// After a failed integrateRays: the leading elements of that call that WERE integrated (non-zero only when a batch over
+  /// the residency limit was split and a later part still did not fit, include/ohmhip.h); do not present those again.
+  size_t lastPartialCount() const { return last_partial_; }
 
   /// ohmgpu/GpuMap.cpp:308-324 -> GpuLayerCache::syncToMainMemory: fence, then copy regions modified on the device
   /// into the host chunks (every enabled layer).
@@ -762,7 +766,8 @@ protected:
     if (expected_element_count > 2048u)
     {
       // the reference sizes its ray / key buffers for expected_element_count points here (ohmgpu/GpuMap.cpp:429-470)
-      OHMHIP_GPUAPICHECK(ohmhip_map_reserve_rays(handle_, expected_element_count / 2u));
+      // (best effort: a reservation the device cannot hold is not an error, the batches grow their buffers on demand)
+      (void)ohmhip_map_reserve_rays(handle_, expected_element_count / 2u);
     }
     uploadExisting();
   }
@@ -860,6 +865,7 @@ protected:
   double ray_segment_length_ = 0;
   bool grouped_rays_ = false;
   int last_status_ = OHMHIP_OK;
+  size_t last_partial_ = 0;
   unsigned partition_world_ = 1;
   RayFilterFunction ray_filter_;
   ohmhip_map_config cfg_;

@@ -320,3 +320,22 @@ def test_async_launch_failure_keeps_the_following_calls_intact(gpu):
     for r in (small, rays_b, rays_c):                           # A left nothing; B ran with C
         om.integrate_occupancy(r)
     assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+
+
+def test_batch_timings_do_not_count_host_idle_time(gpu):
+    """with phase timing off ms_total of a batch was replaced by the gap between the previous batch's end and
+    this batch's end whenever a previous batch sat in the ring -- a batch presented after a host pause (one per sensor
+    frame) then reported the pause.  The period is only used for batches that really overlapped."""
+    import time
+    map_ = OccupancyMap(0.1, layers=("occupancy",))
+    gm = GpuMap(map_)
+    gm.setBatchCoalescing(0)
+    rays = synth.rays_c1(n=20000, max_range=10.0, seed=3)
+    for _ in range(3):
+        assert gm.integrateRays(rays) == rays.shape[0]
+    gm.wait()
+    time.sleep(0.25)
+    assert gm.integrateRays(rays) == rays.shape[0]
+    gm.wait()
+    ms = gm.batchTimings(0)["ms_total"]
+    assert 0.0 < ms < 50.0, ms  # (the pause was 250 ms; the batch itself takes a fraction of a millisecond)
