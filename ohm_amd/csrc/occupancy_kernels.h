@@ -2761,6 +2761,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           }
         }
       }
+      if (stamp && chunk_index < kTraceChunks)
+      {
+        args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 25 + half] = wall_clock64();
+      }
       }  // halves
       if (inline_hits)
       {
@@ -2785,6 +2789,10 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           const uint32_t w = l_counts[tileWord(vi >> 1)];
           x = occMissN(mc, args.ray_flags, x, (w >> ((vi & 1u) * 16u)) & kTileCountMask);
           g_occ[vi] = x;
+        }
+        if (stamp && chunk_index < kTraceChunks)
+        {
+          args.dbg_counters[16 + size_t(chunk_index) * kTraceWords + 27] = wall_clock64();
         }
         if (threadIdx.x == 0)
         {

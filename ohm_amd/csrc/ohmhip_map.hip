@@ -607,7 +607,7 @@ try
             continue;
           }
           std::fprintf(f, "%zu", b);
-          for (int k = 0; k < 25; ++k)
+          for (int k = 0; k < 28; ++k)
           {
             std::fprintf(f, " %llu", rec[k]);
           }

@@ -37,6 +37,21 @@ for lo, hi in [(0, 256), (256, 1024), (1024, 2048), (2048, 3072), (3072, 1 << 30
         print(f"n_seg ({lo},{hi}]: chunks {m.sum():5d} segs {n_seg[m].sum():9d} mean us {tot[m].mean() / 100:8.2f} "
               f"loop {(ends.max(axis=1) - loop_start)[m].mean() / 100:8.2f} epi {(fin - epi_start)[m].mean() / 100:7.2f} "
               f"single {single[m].mean():.2f}")
+if rows.shape[1] >= 29:
+    # finer epilogue stamps (kTrace builds since round 6): end of each direct-apply half, end of the sample replay
+    h0 = rows[:, 26].astype(np.int64); h1 = rows[:, 27].astype(np.int64); ih = rows[:, 28].astype(np.int64)
+    ok = single & (h0 > 0) & (h1 > 0)
+    if ok.any():
+        has_ih = ok & (ih > 0)
+        print("direct-apply epilogue of single-chunk regions (thread 0's wave), mean us: half0 %.2f  half1 %.2f  sample replay %.2f (%d regions)  rest %.2f" %
+              ((h0 - epi_start)[ok].mean() / 100.0, (h1 - h0)[ok].mean() / 100.0,
+               ((ih - h1)[has_ih].mean() / 100.0) if has_ih.any() else 0.0, has_ih.sum(),
+               (fin - np.where(ih > 0, ih, h1))[ok].mean() / 100.0))
+        for lo, hi in [(0, 256), (256, 1024), (1024, 3072), (3072, 1 << 30)]:
+            m = ok & (n_seg > lo) & (n_seg <= hi)
+            if m.any():
+                mi = m & (ih > 0)
+                print("   n_seg (%d,%d]: half0 %.2f half1 %.2f replay %.2f" % (lo, hi, (h0 - epi_start)[m].mean() / 100.0, (h1 - h0)[m].mean() / 100.0, ((ih - h1)[mi].mean() / 100.0) if mi.any() else 0.0))
 xcc = ((hw >> np.uint64(32)) & np.uint64(0xf)).astype(np.int64)
 cu = ((hw >> np.uint64(8)) & np.uint64(0xf)).astype(np.int64)
 se = ((hw >> np.uint64(13)) & np.uint64(0x7)).astype(np.int64)
