@@ -53,10 +53,10 @@ void GpuCache::reinitialise()
   // The host layout changed (OccupancyMap::updateLayout): bring the host up to date, then rebuild the device map for
   // the new layer set from the host copy.
   HipMapBinding &binding = imp_->binding;
-  if (binding.hip)
+  if (binding.core.valid())
   {
     binding.download({}, true);
-    binding.create(binding.kind, nullptr, nullptr);  // the next batch pushes the NDT / TSDF parameters again
+    binding.create(binding.core.kind(), nullptr, nullptr);  // the next batch pushes the NDT / TSDF parameters again
   }
 }
 
@@ -69,28 +69,18 @@ void GpuCache::clear()
 {
   // Drop residency without download (used after CPU-side edits, e.g. tests/ohmtestgpu/GpuNdtTests.cpp:151-152): the
   // host copy is authoritative afterwards, so everything the host holds is uploaded again before the next batch.
-  HipMapBinding &binding = imp_->binding;
-  if (binding.hip)
-  {
-    ohmhip_map_clear(binding.hip);
-    binding.synced_stamp = 0;
-  }
+  imp_->binding.core.clearResidency();
 }
 
 void GpuCache::removeLayers()
 {
-  imp_->binding.destroy();
+  imp_->binding.core.destroy();
 }
 
 void GpuCache::remove(const glm::i16vec3 &region_key)
 {
-  HipMapBinding &binding = imp_->binding;
-  if (binding.hip)
-  {
-    const int16_t key[3] = { region_key.x, region_key.y, region_key.z };
-    size_t removed = 0;
-    ohmhip_map_remove_regions(binding.hip, key, 1, &removed);
-  }
+  const int16_t key[3] = { region_key.x, region_key.y, region_key.z };
+  imp_->binding.core.removeRegion(key);
 }
 
 bool GpuCache::syncLayerTo(MapChunk &dst_chunk, unsigned dst_layer, const MapChunk &src_chunk, unsigned src_layer)
@@ -118,12 +108,7 @@ size_t GpuCache::targetGpuAllocSize() const
 
 unsigned GpuCache::layerCount() const
 {
-  unsigned count = 0;
-  for (int id = 0; id < OHMHIP_LID_COUNT; ++id)
-  {
-    count += (imp_->binding.config.layers & OHMHIP_LAYER_BIT(id)) ? 1u : 0u;
-  }
-  return count;
+  return imp_->binding.core.layerCount();
 }
 
 GpuLayerCache *GpuCache::createCache(unsigned id, const GpuLayerCacheParams &params)

@@ -23,9 +23,6 @@
 #include <logutil/Logger.h>
 
 #include <algorithm>
-#include <array>
-#include <cmath>
-#include <limits>
 
 namespace ohm
 {
@@ -58,14 +55,11 @@ void sync(OccupancyMap &map)
 void sync(OccupancyMap &map, unsigned layer_index)
 {
   // `layer_index` is a GpuCacheId in the reference (ohmgpu/GpuCache.h:32-44).
-  static const int kCacheToLayer[] = { OHMHIP_LID_OCCUPANCY, -1 /* clearance: not on this path */, OHMHIP_LID_MEAN,
-                                       OHMHIP_LID_COVARIANCE, OHMHIP_LID_INTENSITY, OHMHIP_LID_HIT_MISS,
-                                       OHMHIP_LID_TRAVERSAL, OHMHIP_LID_TOUCH_TIME, OHMHIP_LID_INCIDENT,
-                                       OHMHIP_LID_TSDF };
   HipMapBinding *binding = hipBinding(map);
-  if (binding && layer_index < sizeof(kCacheToLayer) / sizeof(kCacheToLayer[0]) && kCacheToLayer[layer_index] >= 0)
+  const int layer_id = ohmhip_adaptor::cacheIdToLayer(layer_index);
+  if (binding && layer_id >= 0)
   {
-    binding->download({ kCacheToLayer[layer_index] }, false);
+    binding->download({ layer_id }, false);
   }
 }
 
@@ -77,46 +71,23 @@ GpuCache *gpuCache(OccupancyMap &map)
 void walkRegions(const OccupancyMap &map, const glm::dvec3 &start_point, const glm::dvec3 &end_point,
                  const RegionWalkFunction &on_visit)
 {
-  // The regions a segment touches, in order: the boundary crossings of the three axes are merged by their parameter
-  // along the segment.  (The device enumerates regions itself -- k_ray_setup -- so nothing in this backend calls this;
-  // it is kept because it is part of the header.)
-  glm::i16vec3 key = map.regionKey(start_point);
-  const glm::i16vec3 end_key = map.regionKey(end_point);
-  const glm::dvec3 extent = map.regionSpatialResolution();
-  const glm::dvec3 delta = end_point - start_point;
-  std::array<double, 3> next{};  // parameter in [0, 1] of the next boundary crossing per axis
-  std::array<double, 3> pitch{};
-  std::array<int, 3> step{};
-  for (int a = 0; a < 3; ++a)
+  // (The device enumerates regions itself -- k_ray_setup -- so nothing in this backend calls this; it is kept because it
+  // is part of the header.  The merge of the three axes' boundary crossings is the core's.)
+  struct Visit
   {
-    const int remaining = int(end_key[a]) - int(key[a]);
-    step[a] = (remaining > 0) - (remaining < 0);
-    if (step[a] == 0 || delta[a] == 0)
-    {
-      next[a] = pitch[a] = std::numeric_limits<double>::infinity();
-      step[a] = 0;
-      continue;
-    }
-    const double centre = map.regionSpatialCentre(key)[a];
-    const double face = centre + 0.5 * double(step[a]) * extent[a];
-    next[a] = (face - start_point[a]) / delta[a];
-    pitch[a] = extent[a] / std::abs(delta[a]);
-  }
-  on_visit(key, start_point, end_point);
-  int guard = 3 * 65536;
-  while (key != end_key && guard-- > 0)
-  {
-    int axis = 0;
-    axis = (next[1] < next[axis]) ? 1 : axis;
-    axis = (next[2] < next[axis]) ? 2 : axis;
-    if (step[axis] == 0)
-    {
-      break;
-    }
-    key[axis] = int16_t(key[axis] + step[axis]);
-    next[axis] = (key[axis] == end_key[axis]) ? std::numeric_limits<double>::infinity() : next[axis] + pitch[axis];
-    on_visit(key, start_point, end_point);
-  }
+    const RegionWalkFunction &fn;
+    const glm::dvec3 &start, &end;
+  } visit{ on_visit, start_point, end_point };
+  const glm::i16vec3 k0 = map.regionKey(start_point), k1 = map.regionKey(end_point);
+  const glm::dvec3 extent = map.regionSpatialResolution(), centre = map.regionSpatialCentre(k0);
+  const int16_t key0[3] = { k0.x, k0.y, k0.z }, key1[3] = { k1.x, k1.y, k1.z };
+  ohmhip_adaptor::walkRegionKeys(
+    &start_point.x, &end_point.x, key0, key1, &extent.x, &centre.x,
+    [](const int16_t key[3], void *user) {
+      const Visit &v = *static_cast<const Visit *>(user);
+      v.fn(glm::i16vec3(key[0], key[1], key[2]), v.start, v.end);
+    },
+    &visit);
 }
 }  // namespace gpumap
 
@@ -138,10 +109,7 @@ GpuMap::~GpuMap()
     // ohmgpu/GpuMap.cpp:290-305).
     if (HipMapBinding *binding = hipBinding(*imp_->map))
     {
-      if (binding->hip)
-      {
-        ohmhip_map_sync(binding->hip);
-      }
+      binding->core.sync();
     }
   }
   delete imp_;
@@ -292,14 +260,14 @@ void GpuMap::setMap(OccupancyMap *map, bool borrowed_map, unsigned expected_elem
   {
     return;
   }
-  if (!binding->hip)
+  if (!binding->core.valid())
   {
     imp_->gpu_ok = binding->create(imp_->kind, imp_->ndt(), imp_->tsdf());
   }
   else
   {
     // A second mapper over a map that is on the device already must integrate the same way (one device map per host map).
-    imp_->gpu_ok = binding->kind == imp_->kind;
+    imp_->gpu_ok = binding->core.kind() == imp_->kind;
     if (!imp_->gpu_ok)
     {
       logutil::error("GpuMap: the map is already bound to a GPU mapper of another kind\n");
@@ -324,73 +292,31 @@ void GpuMap::releaseGpuProgram() {}
 size_t GpuMap::integrateRays(const glm::dvec3 *rays, size_t element_count, const float *intensities,
                              const double *timestamps, unsigned region_update_flags, const RayFilterFunction &filter)
 {
-  if (!imp_->map || !imp_->gpu_ok || !rays || element_count < 2)
-  {
-    return 0u;
-  }
-  HipMapBinding *binding = hipBinding(*imp_->map);
-  if (!binding || !binding->hip)
-  {
-    return 0u;
-  }
+  HipMapBinding *binding = (imp_->map && imp_->gpu_ok && rays) ? hipBinding(*imp_->map) : nullptr;
   // A layout change since the last batch (layers added on the host) rebuilds the device map through
   // GpuCache::reinitialise(); parameters and CPU-side edits travel before the rays.
-  if (!binding->pushConfig(imp_->ndt(), imp_->tsdf()) || !binding->uploadHostEdits())
+  if (!binding || !binding->pushConfig(imp_->ndt(), imp_->tsdf()) || !binding->uploadHostEdits())
   {
     return 0u;
   }
   imp_->map->touch();
-  const size_t ray_count = element_count / 2;
-  size_t done = 0;
-  int status = OHMHIP_OK;
-  if (!filter)
-  {
-    status = ohmhip_map_integrate_rays(binding->hip, &rays[0].x, 2 * ray_count, intensities, timestamps,
-                                       region_update_flags, &done);
-  }
-  else
-  {
-    // Host filter pass (ohmgpu/GpuMap.cpp:736-746): rejected rays are dropped, accepted ones go on with their possibly
-    // moved end points and the RayFilterFlag bits the filter set.
-    imp_->kept_rays.clear();
-    imp_->kept_intensities.clear();
-    imp_->kept_timestamps.clear();
-    imp_->kept_flags.clear();
-    for (size_t i = 0; i < ray_count; ++i)
+  // The host filter pass (ohmgpu/GpuMap.cpp:736-746) is the core's; the RayFilterFunction rides behind a plain pointer.
+  const ohmhip_adaptor::RayFilterC trampoline = [](double start[3], double end[3], unsigned *flags, void *user) {
+    glm::dvec3 s(start[0], start[1], start[2]), e(end[0], end[1], end[2]);
+    const bool keep = (*static_cast<const RayFilterFunction *>(user))(&s, &e, flags);
+    for (int a = 0; a < 3; ++a)
     {
-      glm::dvec3 start = rays[2 * i];
-      glm::dvec3 end = rays[2 * i + 1];
-      unsigned filter_flags = 0;
-      if (!filter(&start, &end, &filter_flags))
-      {
-        continue;
-      }
-      const double pair[6] = { start.x, start.y, start.z, end.x, end.y, end.z };
-      imp_->kept_rays.insert(imp_->kept_rays.end(), pair, pair + 6);
-      imp_->kept_flags.push_back(static_cast<unsigned char>(filter_flags));
-      if (intensities)
-      {
-        imp_->kept_intensities.push_back(intensities[i]);
-      }
-      if (timestamps)
-      {
-        imp_->kept_timestamps.push_back(timestamps[i]);
-      }
+      start[a] = s[a];
+      end[a] = e[a];
     }
-    const size_t kept = imp_->kept_flags.size();
-    if (kept == 0)
-    {
-      return 0u;
-    }
-    status = ohmhip_map_integrate_rays_filtered(
-      binding->hip, imp_->kept_rays.data(), 2 * kept, intensities ? imp_->kept_intensities.data() : nullptr,
-      timestamps ? imp_->kept_timestamps.data() : nullptr, region_update_flags, imp_->kept_flags.data(), &done);
-  }
-  binding->last_status = status;
-  if (status != OHMHIP_OK)
+    return keep;
+  };
+  const size_t done = binding->core.integrate(&rays[0].x, element_count, intensities, timestamps, region_update_flags,
+                                              filter ? trampoline : nullptr,
+                                              const_cast<RayFilterFunction *>(&filter));
+  if (binding->core.lastStatus() != OHMHIP_OK)
   {
-    logutil::error("GpuMap::integrateRays: ", ohmhip_error_string(status), "\n");
-    return 0u;
+    logutil::error("GpuMap::integrateRays: ", ohmhip_error_string(binding->core.lastStatus()), "\n");
   }
   return done;
 }
@@ -400,10 +326,7 @@ void GpuMap::waitOnPreviousOperation(int buffer_index)
   (void)buffer_index;
   if (HipMapBinding *binding = imp_->map ? hipBinding(*imp_->map) : nullptr)
   {
-    if (binding->hip)
-    {
-      ohmhip_map_sync(binding->hip);
-    }
+    binding->core.sync();
   }
 }
 

@@ -1,19 +1,14 @@
-// HipMapBinding.cpp -- device map <-> ohm::OccupancyMap plumbing shared by the adaptor classes (see the header).
+// HipMapBinding.cpp -- see the header: ohm / glm types in, plain values and pointers out; the logic is HipBindingCore's.
 #include "HipMapBinding.h"
 
 #include <ohm/DefaultLayer.h>
 #include <ohm/MapChunk.h>
-#include <ohm/MapLayer.h>
 #include <ohm/MapLayout.h>
 #include <ohm/NdtMap.h>
 #include <ohm/OccupancyMap.h>
 #include <ohm/VoxelBlock.h>
 #include <ohm/VoxelBuffer.h>
 
-#include <logutil/Logger.h>
-
-#include <algorithm>
-#include <cstring>
 #include <mutex>
 #include <unordered_map>
 
@@ -24,65 +19,55 @@ namespace
 std::mutex g_registry_mutex;
 std::unordered_map<const OccupancyMap *, HipMapBinding *> g_registry;
 
-/// Host layer name of a device layer id (ohm/DefaultLayer.h:17-44).
-const char *layerName(int layer_id)
+ohmhip_adaptor::MapValues mapValues(const OccupancyMap &map)
 {
-  switch (layer_id)
+  ohmhip_adaptor::MapValues v;
+  v.resolution = map.resolution();
+  const glm::u8vec3 dim = map.regionVoxelDimensions();
+  const glm::dvec3 origin = map.origin();
+  for (int a = 0; a < 3; ++a)
   {
-  case OHMHIP_LID_OCCUPANCY:
-    return default_layer::occupancyLayerName();
-  case OHMHIP_LID_MEAN:
-    return default_layer::meanLayerName();
-  case OHMHIP_LID_COVARIANCE:
-    return default_layer::covarianceLayerName();
-  case OHMHIP_LID_TRAVERSAL:
-    return default_layer::traversalLayerName();
-  case OHMHIP_LID_TOUCH_TIME:
-    return default_layer::touchTimeLayerName();
-  case OHMHIP_LID_INCIDENT:
-    return default_layer::incidentNormalLayerName();
-  case OHMHIP_LID_INTENSITY:
-    return default_layer::intensityLayerName();
-  case OHMHIP_LID_HIT_MISS:
-    return default_layer::hitMissCountLayerName();
-  case OHMHIP_LID_TSDF:
-    return default_layer::tsdfLayerName();
-  default:
-    return nullptr;
+    v.region_dim[a] = dim[a];
+    v.origin[a] = origin[a];
   }
+  v.hit_value = map.hitValue();
+  v.miss_value = map.missValue();
+  v.threshold_value = map.occupancyThresholdValue();
+  v.min_value = map.minVoxelValue();
+  v.max_value = map.maxVoxelValue();
+  v.saturate_at_min = map.saturateAtMinValue();
+  v.saturate_at_max = map.saturateAtMaxValue();
+  return v;
 }
 
-/// Device layers a map kind integrates into, given what the host layout offers.
-unsigned deviceLayers(const OccupancyMap &map, HipMapKind kind)
+ohmhip_adaptor::NdtValues ndtValues(const NdtMap *ndt)
 {
-  const MapLayout &layout = map.layout();
-  auto has = [&layout](int id) { return layout.layerIndex(layerName(id)) >= 0; };
-  unsigned bits = 0;
-  if (kind == HipMapKind::kTsdf)
+  ohmhip_adaptor::NdtValues v;
+  if (ndt)
   {
-    return has(OHMHIP_LID_TSDF) ? OHMHIP_LAYER_BIT(OHMHIP_LID_TSDF) : 0u;
+    v.present = true;
+    v.sensor_noise = ndt->sensorNoise();
+    v.sample_threshold = const_cast<NdtMap *>(ndt)->ndtSampleThreshold();  // (not const in the reference)
+    v.adaptation_rate = ndt->adaptationRate();
+    v.reinit_threshold = ndt->reinitialiseCovarianceThreshold();
+    v.reinit_count = ndt->reinitialiseCovariancePointCount();
+    v.initial_intensity_cov = ndt->initialIntensityCovariance();
   }
-  const int ids[] = { OHMHIP_LID_OCCUPANCY, OHMHIP_LID_MEAN, OHMHIP_LID_TRAVERSAL, OHMHIP_LID_TOUCH_TIME,
-                      OHMHIP_LID_INCIDENT };
-  for (int id : ids)
-  {
-    bits |= has(id) ? OHMHIP_LAYER_BIT(id) : 0u;
-  }
-  if (kind != HipMapKind::kOccupancy)
-  {
-    bits |= has(OHMHIP_LID_COVARIANCE) ? OHMHIP_LAYER_BIT(OHMHIP_LID_COVARIANCE) : 0u;
-  }
-  if (kind == HipMapKind::kNdtTraversability)
-  {
-    bits |= has(OHMHIP_LID_INTENSITY) ? OHMHIP_LAYER_BIT(OHMHIP_LID_INTENSITY) : 0u;
-    bits |= has(OHMHIP_LID_HIT_MISS) ? OHMHIP_LAYER_BIT(OHMHIP_LID_HIT_MISS) : 0u;
-  }
-  return bits;
+  return v;
 }
 
-bool sameValues(const ohmhip_map_config &a, const ohmhip_map_config &b)
+ohmhip_adaptor::TsdfValues tsdfValues(const TsdfOptions *tsdf)
 {
-  return std::memcmp(&a, &b, sizeof(a)) == 0;
+  ohmhip_adaptor::TsdfValues v;
+  if (tsdf)
+  {
+    v.present = true;
+    v.max_weight = tsdf->max_weight;
+    v.default_truncation_distance = tsdf->default_truncation_distance;
+    v.dropoff_epsilon = tsdf->dropoff_epsilon;
+    v.sparsity_compensation_factor = tsdf->sparsity_compensation_factor;
+  }
+  return v;
 }
 }  // namespace
 
@@ -91,11 +76,6 @@ HipMapBinding *hipBinding(const OccupancyMap &map)
   std::lock_guard<std::mutex> guard(g_registry_mutex);
   const auto it = g_registry.find(&map);
   return (it != g_registry.end()) ? it->second : nullptr;
-}
-
-HipMapBinding *hipBinding(OccupancyMap &map)
-{
-  return hipBinding(static_cast<const OccupancyMap &>(map));
 }
 
 void registerHipBinding(OccupancyMap &map, HipMapBinding *binding)
@@ -110,150 +90,51 @@ void unregisterHipBinding(OccupancyMap &map)
   g_registry.erase(&map);
 }
 
-void fillConfig(ohmhip_map_config &cfg, const OccupancyMap &map, HipMapKind kind, const NdtMap *ndt,
-                const TsdfOptions *tsdf)
-{
-  cfg.resolution = map.resolution();
-  const glm::u8vec3 dim = map.regionVoxelDimensions();
-  cfg.region_dim[0] = dim.x;
-  cfg.region_dim[1] = dim.y;
-  cfg.region_dim[2] = dim.z;
-  const glm::dvec3 origin = map.origin();
-  cfg.origin[0] = origin.x;
-  cfg.origin[1] = origin.y;
-  cfg.origin[2] = origin.z;
-  cfg.hit_value = map.hitValue();
-  cfg.miss_value = map.missValue();
-  cfg.threshold_value = map.occupancyThresholdValue();
-  cfg.min_value = map.minVoxelValue();
-  cfg.max_value = map.maxVoxelValue();
-  cfg.saturate_at_min = map.saturateAtMinValue() ? 1 : 0;
-  cfg.saturate_at_max = map.saturateAtMaxValue() ? 1 : 0;
-  // The map's own RayFilterFunction is host code: GpuMap runs it per ray (GpuMap.cpp in this directory) and hands the
-  // survivors over with their flags, so the device applies no filter of its own.
-  cfg.ray_filter = OHMHIP_FILTER_NONE;
-  cfg.ray_filter_range = 0;
-  switch (kind)
-  {
-  case HipMapKind::kOccupancy:
-    cfg.mode = OHMHIP_MODE_OCCUPANCY;
-    break;
-  case HipMapKind::kNdtOccupancy:
-    cfg.mode = OHMHIP_MODE_NDT_OM;
-    break;
-  case HipMapKind::kNdtTraversability:
-    cfg.mode = OHMHIP_MODE_NDT_TM;
-    break;
-  case HipMapKind::kTsdf:
-    cfg.mode = OHMHIP_MODE_TSDF;
-    break;
-  }
-  if (ndt)
-  {
-    cfg.ndt_sensor_noise = ndt->sensorNoise();
-    cfg.ndt_sample_threshold = const_cast<NdtMap *>(ndt)->ndtSampleThreshold();  // (not const in the reference)
-    cfg.ndt_adaptation_rate = ndt->adaptationRate();
-    cfg.ndt_reinit_threshold = ndt->reinitialiseCovarianceThreshold();
-    cfg.ndt_reinit_count = ndt->reinitialiseCovariancePointCount();
-    cfg.ndt_initial_intensity_cov = ndt->initialIntensityCovariance();
-  }
-  if (tsdf)
-  {
-    cfg.tsdf_max_weight = tsdf->max_weight;
-    cfg.tsdf_trunc = tsdf->default_truncation_distance;
-    cfg.tsdf_dropoff = tsdf->dropoff_epsilon;
-    cfg.tsdf_sparsity = tsdf->sparsity_compensation_factor;
-  }
-}
-
-HipMapBinding::~HipMapBinding()
-{
-  destroy();
-}
-
-void HipMapBinding::destroy()
-{
-  if (hip)
-  {
-    ohmhip_map_destroy(hip);
-    hip = nullptr;
-  }
-}
-
 int HipMapBinding::hostLayer(int layer_id) const
 {
-  const char *name = layerName(layer_id);
+  const char *name = ohmhip_adaptor::hostLayerName(layer_id);
   return (map && name) ? map->layout().layerIndex(name) : -1;
 }
 
-bool HipMapBinding::create(HipMapKind new_kind, const NdtMap *ndt, const TsdfOptions *tsdf)
+bool HipMapBinding::create(HipMapKind kind, const NdtMap *ndt, const TsdfOptions *tsdf)
 {
-  destroy();
-  kind = new_kind;
-  ohmhip_map_config_default(&config);
-  fillConfig(config, *map, kind, ndt, tsdf);
-  config.layers = deviceLayers(*map, kind);
-  config.gpu_mem_size = gpu_mem_size;
-  last_status = ohmhip_map_create(&hip, &config);
-  if (last_status != OHMHIP_OK)
+  unsigned host_layers = 0;
+  for (int id = 0; id < OHMHIP_LID_COUNT; ++id)
   {
-    logutil::error("ohmhip_map_create failed: ", ohmhip_error_string(last_status), "\n");
-    hip = nullptr;
-    return false;
+    host_layers |= (hostLayer(id) >= 0) ? OHMHIP_LAYER_BIT(id) : 0u;
   }
   // Everything the host map already holds goes up (a GpuMap over a CPU-built map, GpuMapTest PopulateMultiple etc.).
-  synced_stamp = 0;
-  return uploadHostEdits();
+  return core.create(kind, mapValues(*map), host_layers, gpu_mem_size, ndtValues(ndt), tsdfValues(tsdf)) &&
+         uploadHostEdits();
 }
 
 bool HipMapBinding::pushConfig(const NdtMap *ndt, const TsdfOptions *tsdf)
 {
-  ohmhip_map_config current = config;
-  fillConfig(current, *map, kind, ndt, tsdf);
-  if (sameValues(current, config))
-  {
-    return true;
-  }
-  last_status = ohmhip_map_update_config(hip, &current);
-  if (last_status != OHMHIP_OK)
-  {
-    return false;
-  }
-  config = current;
-  return true;
+  return core.pushConfig(mapValues(*map), ndtValues(ndt), tsdfValues(tsdf));
 }
 
 bool HipMapBinding::uploadHostEdits()
 {
-  if (!hip)
+  if (!core.valid())
   {
     return false;
   }
   std::vector<std::pair<uint64_t, glm::i16vec3>> regions;
-  map->collectDirtyRegions(synced_stamp, regions);
-  if (regions.empty())
-  {
-    synced_stamp = map->stamp();
-    return true;
-  }
+  map->collectDirtyRegions(core.syncedStamp(), regions);
   std::vector<int16_t> keys;
-  keys.reserve(regions.size() * 3);
   std::vector<MapChunk *> chunks;
   for (const auto &entry : regions)
   {
-    MapChunk *chunk = map->region(entry.second, false);
-    if (chunk)
+    if (MapChunk *chunk = map->region(entry.second, false))
     {
-      keys.push_back(entry.second.x);
-      keys.push_back(entry.second.y);
-      keys.push_back(entry.second.z);
+      keys.insert(keys.end(), { entry.second.x, entry.second.y, entry.second.z });
       chunks.push_back(chunk);
     }
   }
-  for (int id = 0; id < OHMHIP_LID_COUNT; ++id)
+  for (int id = 0; id < OHMHIP_LID_COUNT && !chunks.empty(); ++id)
   {
     const int host_layer = hostLayer(id);
-    if (!(config.layers & OHMHIP_LAYER_BIT(id)) || host_layer < 0)
+    if (!(core.layers() & OHMHIP_LAYER_BIT(id)) || host_layer < 0)
     {
       continue;
     }
@@ -266,35 +147,23 @@ bool HipMapBinding::uploadHostEdits()
       buffers.emplace_back(chunk->voxel_blocks[size_t(host_layer)].get());
       srcs.push_back(buffers.back().voxelMemory());
     }
-    last_status = ohmhip_map_write_regions(hip, id, keys.data(), chunks.size(), srcs.data());
-    if (last_status != OHMHIP_OK)
+    if (!core.uploadBlocks(id, keys.data(), chunks.size(), srcs.data()))
     {
-      logutil::error("ohmhip_map_write_regions failed: ", ohmhip_error_string(last_status), "\n");
       return false;
     }
   }
-  synced_stamp = map->stamp();
+  core.uploadsDone(map->stamp());
   return true;
 }
 
 bool HipMapBinding::download(const std::vector<int> &layer_ids, bool clear_dirty)
 {
-  if (!hip)
+  std::vector<int16_t> keys;
+  if (!core.dirtyRegions(keys))
   {
     return false;
   }
-  size_t count = 0;
-  last_status = ohmhip_map_dirty_regions(hip, nullptr, 0, &count);
-  if (last_status != OHMHIP_OK)
-  {
-    return false;
-  }
-  std::vector<int16_t> keys(3 * std::max<size_t>(count, 1));
-  last_status = ohmhip_map_dirty_regions(hip, keys.data(), count, &count);
-  if (last_status != OHMHIP_OK)
-  {
-    return false;
-  }
+  const size_t count = keys.size() / 3;
   std::vector<MapChunk *> chunks(count);
   for (size_t i = 0; i < count; ++i)
   {
@@ -302,14 +171,10 @@ bool HipMapBinding::download(const std::vector<int> &layer_ids, bool clear_dirty
   }
   const glm::ivec3 dim(map->regionVoxelDimensions());
   const uint64_t stamp = count ? map->touch() : map->stamp();
-  for (int id = 0; id < OHMHIP_LID_COUNT; ++id)
+  for (int id = 0; id < OHMHIP_LID_COUNT && count; ++id)
   {
     const int host_layer = hostLayer(id);
-    if (!(config.layers & OHMHIP_LAYER_BIT(id)) || host_layer < 0 || count == 0)
-    {
-      continue;
-    }
-    if (!layer_ids.empty() && std::find(layer_ids.begin(), layer_ids.end(), id) == layer_ids.end())
+    if (!core.downloadsLayer(id, layer_ids) || host_layer < 0)
     {
       continue;
     }
@@ -321,10 +186,8 @@ bool HipMapBinding::download(const std::vector<int> &layer_ids, bool clear_dirty
       buffers.emplace_back(chunk->voxel_blocks[size_t(host_layer)].get());
       dsts.push_back(buffers.back().voxelMemory());
     }
-    last_status = ohmhip_map_read_regions(hip, id, keys.data(), count, dsts.data());
-    if (last_status != OHMHIP_OK)
+    if (!core.downloadBlocks(id, keys.data(), count, dsts.data()))
     {
-      logutil::error("ohmhip_map_read_regions failed: ", ohmhip_error_string(last_status), "\n");
       return false;
     }
     // Stamp protocol of GpuLayerCache::syncToMainMemory (ohmgpu/GpuLayerCache.cpp:685-694) and the post-sync handler
@@ -333,20 +196,14 @@ bool HipMapBinding::download(const std::vector<int> &layer_ids, bool clear_dirty
     {
       chunk->dirty_stamp = stamp;
       chunk->touched_stamps[size_t(host_layer)].store(stamp, std::memory_order_relaxed);
-      if (id == OHMHIP_LID_OCCUPANCY || id == OHMHIP_LID_TSDF)
+      if (ohmhip_adaptor::layerCarriesFirstValid(id))
       {
         chunk->invalidateFirstValidIndex();
         chunk->searchAndUpdateFirstValid(dim);
       }
     }
   }
-  if (clear_dirty)
-  {
-    last_status = ohmhip_map_clear_dirty(hip);
-  }
-  // What we just wrote is not a CPU-side edit.
-  synced_stamp = map->stamp();
-  return last_status == OHMHIP_OK;
+  return core.downloadsDone(clear_dirty, map->stamp());
 }
 
 GpuMapDetail::~GpuMapDetail()

@@ -21,14 +21,15 @@ DRIVER = os.path.join(os.path.dirname(ohm_amd.LIB_PATH), "gpumap_driver")
 ID_TO_NAME = {v[0]: k for k, v in LAYERS.items()}
 
 
-def run_driver(mode, resolution, batch, rays, n_layers):
-    assert os.path.exists(DRIVER), "gpumap_driver missing: run __graft_entry__.build()"
+def run_driver(mode, resolution, batch, rays, n_layers, driver=None):
+    driver = driver or DRIVER
+    assert os.path.exists(driver), "%s missing: run __graft_entry__.build()" % os.path.basename(driver)
     with tempfile.TemporaryDirectory() as tmp:
         rp, op = os.path.join(tmp, "rays.bin"), os.path.join(tmp, "out.bin")
         with open(rp, "wb") as f:
             f.write(struct.pack("<Q", rays.shape[0]))
             f.write(np.ascontiguousarray(rays, dtype=np.float64).tobytes())
-        res = subprocess.run([DRIVER, mode, repr(resolution), str(batch), rp, op], capture_output=True, text=True,
+        res = subprocess.run([driver, mode, repr(resolution), str(batch), rp, op], capture_output=True, text=True,
                              timeout=300)
         assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
         data = open(op, "rb").read()

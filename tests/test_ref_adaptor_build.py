@@ -1,9 +1,12 @@
 """f1: the reference's own GpuMap / GpuNdtMap / GpuTsdfMap / GpuCache member definitions on this backend
 (ohm_amd/host/ref_adaptor), built against the reference checkout by scripts/build_ref_adaptor.sh -- which says, unit by
-unit, what it compiled and what it did not.  The three translation units that need no glm (device selection, the gputil
-backend) and the reference's own gpuEventList.cpp compile on every box with the checkout: asserted here.  The five that
-include an ohm header which includes glm are compiled where glm exists; where it does not they are listed as NOT COMPILED
-and the second test reports `skipped: glm absent`.  No stand-in for glm is ever written."""
+unit, what it compiled and what it did not.  The four translation units that need no glm (device selection, the gputil
+backend, and since round 6 the binding core that holds the adaptor's logic: private/HipBindingCore.cpp, GPU-tested by
+tests/test_gpu_binding_core.py) and the reference's own gpuEventList.cpp compile on every box with the checkout: asserted
+here.  The five that include an ohm header which includes glm -- glue that names ohm / glm types -- are compiled where glm
+exists; where it does not they are listed as NOT COMPILED with their size, and the second test reports `skipped: glm
+absent`.  No stand-in for glm is ever written."""
+import re
 import os
 import subprocess
 
@@ -23,14 +26,19 @@ def _build(out_dir):
 def test_units_that_need_no_glm_compile_against_the_reference_headers(tmp_path):
     res = _build(tmp_path / "ref_adaptor")
     assert res.returncode in (0, 77), (res.stdout[-3000:], res.stderr[-3000:])
-    for name in ("OhmGpu.o", "gputil_hip_gputilHip.o", "gputil_hip_gputilHipBuffer.o", "gpuEventList.o"):
+    for name in ("OhmGpu.o", "gputil_hip_gputilHip.o", "gputil_hip_gputilHipBuffer.o", "private_HipBindingCore.o",
+                 "gpuEventList.o"):
         assert os.path.getsize(tmp_path / "ref_adaptor" / "obj" / name) > 0, name
     assert "FAILED" not in res.stdout
     if res.returncode == 77:
         # every unit that was not compiled is named, with the header it stops at
         for unit in GLM_UNITS:
             assert f"NOT COMPILED  {unit}" in res.stdout
-        assert "5 of 8 adaptor translation units not compiled" in res.stdout
+        assert "5 of 9 adaptor translation units not compiled" in res.stdout
+        # ... and the script says how much source that is; the glue must stay glue (round 5: ~1 270 lines with the logic)
+        m = re.search(r"UNCOMPILED SOURCE: (\d+) lines \((\d+) statements\)", res.stdout)
+        assert m, res.stdout[-2000:]
+        assert int(m.group(2)) <= 520, m.group(0)
 
 
 def test_ohm_half_of_the_adaptor_builds_when_glm_is_present(tmp_path):
@@ -40,6 +48,21 @@ def test_ohm_half_of_the_adaptor_builds_when_glm_is_present(tmp_path):
         assert reason, res.stdout
         pytest.skip(reason[0])
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-6000:])
-    assert "COMPILED: 9 objects" in res.stdout
+    assert "COMPILED: 10 objects" in res.stdout
     for name in ("GpuMap.o", "GpuNdtMap.o", "GpuTsdfMap.o", "GpuCache.o", "private_HipMapBinding.o"):
         assert os.path.getsize(tmp_path / "ref_adaptor" / "obj" / name) > 0
+
+
+def test_core_layer_names_are_the_references():
+    """The glm-free core names host layers by the strings default_layer::*LayerName() return (ohm/DefaultLayer.cpp:29-67):
+    pinned against the reference's source where the checkout exists."""
+    ref = "/root/reference/ohm/DefaultLayer.cpp"
+    if not os.path.exists(ref):
+        pytest.skip("no reference checkout on this box")
+    text = open(ref).read()
+    core = open(os.path.join(ROOT, "ohm_amd", "host", "ref_adaptor", "private", "HipBindingCore.cpp")).read()
+    body = core[core.index("const char *hostLayerName"):core.index("int cacheIdToLayer")]
+    names = re.findall(r'return "([a-z_]+)";', body)
+    assert len(names) == 9, names
+    for name in names:
+        assert 'return "%s";' % name in text, name
