@@ -23,6 +23,21 @@
 extern "C" {
 #endif
 
+/* CORE ABI.  The header has grown to 87 entry points over six rounds; a reference-side binding of ohm::GpuMap /
+ * GpuNdtMap / GpuTsdfMap / GpuCache needs FIFTEEN of them.  The list below is exact: it is every ohmhip_* call made by
+ * ohm_amd/host/ref_adaptor/private/HipBindingCore.cpp, the compiled and GPU-tested logic of the Level-2 adaptor
+ * (INTEGRATION.md), and tests/test_cabi.py keeps the two in step.
+ *   OHMHIP_CORE_ABI: ohmhip_error_string ohmhip_map_config_default ohmhip_map_create ohmhip_map_destroy
+ *   OHMHIP_CORE_ABI: ohmhip_map_update_config ohmhip_map_integrate_rays ohmhip_map_integrate_rays_filtered ohmhip_map_sync
+ *   OHMHIP_CORE_ABI: ohmhip_map_write_regions ohmhip_map_dirty_regions ohmhip_map_read_regions ohmhip_map_clear_dirty
+ *   OHMHIP_CORE_ABI: ohmhip_map_clear ohmhip_map_remove_regions ohmhip_map_cache_stats
+ * (the gputil::Device / Queue / Event / Buffer backend adds group 1 below; ohmhip_map_integrate_rays_device and
+ * ohmhip_transform_samples serve GpuTransformSamples callers.)  Everything else is optional: residency limit and spill,
+ * region listings and zero-copy views, LineKeysQueryGpu, multi-GPU (group 3).  Entry points that only tune or measure
+ * -- knobs found useful while optimising, nothing a binding has to know -- carry OHMHIP_EXPERIMENTAL: they may change
+ * or go without notice. */
+#define OHMHIP_EXPERIMENTAL
+
 #define OHMHIP_OK 0
 #define OHMHIP_ERR_INVALID_ARG (-1)
 #define OHMHIP_ERR_NO_DEVICE (-2)
@@ -249,7 +264,7 @@ int ohmhip_map_integrate_rays_filtered(ohmhip_map_t map, const double *rays, siz
  * still reports its own *integrated: the ray filter's verdict is evaluated on the host while the rays are staged, with
  * the arithmetic the device uses.  An error of a deferred batch (pool exhausted ...) surfaces at the call that launches
  * it.  Default min_rays: 65536; 0 launches every call's batch in that call. */
-int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
+OHMHIP_EXPERIMENTAL int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
 /* Large host batches, opt-in: with enable != 0 a host-pointer call that is a device batch on its own returns as soon
  * as its rays are staged and their upload is queued; the device launch sequence -- which waits for the batch's plan
  * summary in its middle -- runs on a thread the map owns, so the caller stages its next block, and the link carries it,
@@ -259,7 +274,7 @@ int ohmhip_map_set_batch_coalescing(ohmhip_map_t map, size_t min_rays);
  * returned by the NEXT call on the map that settles it -- any entry point but the staging part of integrate_rays; the
  * rays of the call that reports it stay queued.  Everything that observes the map waits for the launch first, so
  * results do not depend on the setting.  Default: off. */
-int ohmhip_map_set_async_launch(ohmhip_map_t map, int enable);
+OHMHIP_EXPERIMENTAL int ohmhip_map_set_async_launch(ohmhip_map_t map, int enable);
 /* Same with rays (and optional intensities/timestamps) already resident in device memory.  The arrays must be COMPLETE
  * when the call is made (not merely enqueued on some stream): the map reads them on streams of its own.  Calls below
  * the coalescing threshold are collected like small host batches (round 3): their arrays are copied device to device
@@ -334,7 +349,7 @@ int ohmhip_map_set_memory_limit(ohmhip_map_t map, uint64_t bytes);
  * batch touches the regions of all its calls at once). */
 int ohmhip_map_set_spill_to_host(ohmhip_map_t map, int enable);
 /* The background write-back of the spill path (see WRITE-BACK above), opt-in: off by default. */
-int ohmhip_map_set_spill_writeback(ohmhip_map_t map, int enable);
+OHMHIP_EXPERIMENTAL int ohmhip_map_set_spill_writeback(ohmhip_map_t map, int enable);
 /* Wait for all queued work (GpuMap::syncVoxels fence half, ohmgpu/GpuMap.cpp:308-324). */
 int ohmhip_map_sync(ohmhip_map_t map);
 int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);
@@ -347,7 +362,7 @@ int ohmhip_map_last_stats(ohmhip_map_t map, ohmhip_batch_stats *stats);
  * walk kernel it mostly waits for CUs), ms[2] the region walk kernel, ms[3] sample ordering + ordered apply.
  * hipEvents on the map's streams (the gputil::Event / Queue::mark() bookkeeping of ohmgpu/GpuMap.cpp:1036-1191 serves
  * the same purpose); waits for that batch only.  Lets a caller time a run of batches without synchronising after each. */
-int ohmhip_map_batch_timings(ohmhip_map_t map, uint32_t batches_back, float ms[4]);
+OHMHIP_EXPERIMENTAL int ohmhip_map_batch_timings(ohmhip_map_t map, uint32_t batches_back, float ms[4]);
 /* What the phase times are read from (round 5).  The end of a batch's binning, sample ordering, walk and apply phases and
  * of its plan are the STOP EVENTS of the kernels themselves (hipExtLaunchKernelGGL: bound to the kernel's completion
  * signal, free), so ms[0] (as the interval between consecutive batches' ends; for a batch on its own: plan end -> batch
@@ -357,14 +372,14 @@ int ohmhip_map_batch_timings(ohmhip_map_t map, uint32_t batches_back, float ms[4
  * (scripts/probes/event_probe.hip) -- round 4 paid eight of them per batch, 5 % of a C1 batch.  They are therefore
  * recorded only with phase timing on (this call, OHMHIP_PHASE_TIMING=1): ms[1], and ms[0] of a batch on its own as first
  * kernel start -> last kernel end, need it and read 0 / the shorter span otherwise.  Default: off. */
-int ohmhip_map_set_phase_timing(ohmhip_map_t map, int enable);
+OHMHIP_EXPERIMENTAL int ohmhip_map_set_phase_timing(ohmhip_map_t map, int enable);
 /* The per-batch device buffers (ray set-up records, ray-region segments, sample keys, sort scratch) are grown by the
  * batch that first needs them -- a few hipMalloc calls, each a device synchronisation, inside that call.  The reference's
  * GpuMap constructor sizes its key / ray buffers for `expected_element_count` up front (ohmgpu/GpuMap.cpp:429-470); this is
  * the counterpart: size everything a batch of `ray_count` rays needs now (the deferred-event list: 16 per ray, at most
  * 2^27 events).  Optional; batches of any size still work, and the host mirrors treat a failing reservation as "grow on
  * demand", not as an error. */
-int ohmhip_map_reserve_rays(ohmhip_map_t map, size_t ray_count);
+OHMHIP_EXPERIMENTAL int ohmhip_map_reserve_rays(ohmhip_map_t map, size_t ray_count);
 /* OccupancyMap::firstRayTime / setFirstRayTime (ohm/OccupancyMap.h:342-351): the time base the touch-time layer is
  * encoded against (milliseconds since it, ohm/VoxelTouchTimeCompute.h:24-37).  Like the reference the map takes it from
  * the first time stamp it is ever given; set it explicitly where that is not the map's to decide -- the ranks of a
@@ -377,13 +392,13 @@ int ohmhip_map_first_ray_time(ohmhip_map_t map, double *time);
  * of ohmhip_map_integrate_rays_device count LAUNCHES with this, not calls -- a buffer handed to the call that made the
  * count L is free once the count has reached L + 2 and a later integrate call has returned (or after ohmhip_map_sync).
  * Does not flush collected rays. */
-int ohmhip_map_batches_launched(ohmhip_map_t map, uint64_t *count);
+OHMHIP_EXPERIMENTAL int ohmhip_map_batches_launched(ohmhip_map_t map, uint64_t *count);
 /* Maps whose regions are cut into tiles (LARGE REGIONS above): rays, among those that passed the filter, with an end in
  * a region the reference still addresses (|region| <= 32767) but whose tile coordinates leave the key's 16-bit fields.
  * Such a ray is not walked and, when it is the sample that lies out there, its sample is dropped -- the one place results
  * differ from the CPU mappers run with the same region size; this count (since the map was created, rejected batches
  * excluded) lets a caller see that it happened.  Always 0 for regions of up to 32768 voxels.  Flushes collected rays. */
-int ohmhip_map_rays_beyond_tiles(ohmhip_map_t map, uint64_t *count);
+OHMHIP_EXPERIMENTAL int ohmhip_map_rays_beyond_tiles(ohmhip_map_t map, uint64_t *count);
 
 /* Region table (replaces GpuLayerCache::lookup, ohmgpu/GpuLayerCache.cpp:104-119). keys = int16 xyz triples. */
 int ohmhip_map_region_count(ohmhip_map_t map, size_t *count);

@@ -548,8 +548,10 @@ struct BatchRun
           ta.traversal_acc = m->d_traversal_acc;
           ta.unit_bits = traversalUnitBits(m->mc.resolution);
           ta.refill_min_idle = 16;  // (8: +8 %, 32: the same, measured on C1)
-          hipExtLaunchKernelGGL(k_region_traversal, dim3(info.n_chunks), dim3(kWalkThreads), traversalLdsBytes(m->mc),
-                                s, nullptr, tev[3], 0, ta);
+          ta.chunk_cursor = batchEventCount(m) + 3;  // (k_plan zeroes it; the stop-flag replay that shares the word runs later)
+          ta.n_chunks = info.n_chunks;
+          hipExtLaunchKernelGGL(k_region_traversal, dim3(std::min<uint32_t>(info.n_chunks, m->walk_workgroups)),
+                                dim3(kWalkThreads), traversalLdsBytes(m->mc), s, nullptr, tev[3], 0, ta);
         }
         mark(3);
         if (occupancy_mode)

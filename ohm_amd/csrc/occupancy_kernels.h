@@ -1110,6 +1110,7 @@ __global__ void __launch_bounds__(1024)
     *next_info = BatchInfo{};
     event_count[0] = 0;  // deferred events
     event_count[1] = 0;  // walk chunk cursor
+    event_count[3] = 0;  // traversal pass' chunk cursor (the stop-flag replay clears the word again before it uses it)
     __threadfence_system();
   }
 }

@@ -35,6 +35,11 @@ struct TraversalArgs
   unsigned long long *traversal_acc;  ///< [slot][voxel] sums of this batch in units of 1 / kTraversalScale metres
   int unit_bits;                      ///< tile unit = 2^-unit_bits metres, <= 28 (traversalUnitBits)
   int refill_min_idle;
+  /// Persistent workgroups (round 6), like k_region_walk: one per CU, the first chunk is the workgroup's own index, the
+  /// following ones come from this device-wide cursor (zeroed by k_plan) -- the list is ordered largest first, so the
+  /// launch ends on its smallest chunks instead of on whatever the hardware's round-robin over the XCDs left for last.
+  uint32_t *chunk_cursor;
+  uint32_t n_chunks;
 };
 
 /// Largest tile unit exponent for which a single visit (at most a voxel diagonal long) stays below 2^31 units.
@@ -50,7 +55,7 @@ inline int traversalUnitBits(double resolution)
 
 inline size_t traversalLdsBytes(const MapConst &mc)
 {
-  return (size_t(mc.region_voxels) + 16u) * sizeof(uint32_t);
+  return (size_t(mc.region_voxels) + 16u) * sizeof(uint32_t);  // tile + [0] segment cursor, [1..8] idle words, [9] next chunk
 }
 
 __global__ void __launch_bounds__(kWalkThreads) k_region_traversal(TraversalArgs args)
@@ -59,7 +64,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_traversal(TraversalArgs
   const MapConst &mc = args.mc;
   const uint32_t n_voxels = uint32_t(mc.region_voxels);
   uint32_t *l_cursor = l_tile + n_voxels;
-  const Chunk chunk = args.chunks[blockIdx.x];
+  for (uint32_t chunk_index = blockIdx.x; chunk_index < args.n_chunks;)
+  {
+  const Chunk chunk = args.chunks[chunk_index];
   for (uint32_t i = threadIdx.x; i < n_voxels; i += blockDim.x)
   {
     l_tile[i] = 0;
@@ -67,6 +74,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_traversal(TraversalArgs
   if (threadIdx.x == 0)
   {
     *l_cursor = 0;
+    l_cursor[9] = gridDim.x + atomicAdd(args.chunk_cursor, 1u);  // the chunk after this one (fetched under the walk)
   }
   __syncthreads();
 
@@ -224,6 +232,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_traversal(TraversalArgs
       atomicAdd(&acc[i], (unsigned long long)(sum) << flush_shift);
     }
   }
+  chunk_index = __builtin_amdgcn_readfirstlane(l_cursor[9]);
+  __syncthreads();  // (the tile and the cursor words are reused by the next chunk)
+  }  // chunks
 }
 }  // namespace ohmhip
 

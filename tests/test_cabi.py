@@ -88,3 +88,18 @@ def test_null_and_out_of_range_arguments_are_rejected():
     assert L.lib.ohmhip_region_owner(None, 4, 0, 2, owners.ctypes.data) == invalid
     assert L.lib.ohmhip_region_owner(keys.ctypes.data, 4, 0, 2, owners.ctypes.data) == L.OK
     assert L.lib.ohmhip_region_owner(None, 0, 0, 2, None) == L.OK
+
+
+def test_core_abi_list_is_what_the_binding_core_calls():
+    """include/ohmhip.h names the (at most 20) entry points a reference-side binding needs: exactly the ohmhip_* calls of
+    the compiled binding core (ohm_amd/host/ref_adaptor/private/HipBindingCore.cpp) plus ohmhip_error_string for the glue's
+    log lines; tuning / measurement knobs are tagged OHMHIP_EXPERIMENTAL and are never among them."""
+    header = open(os.path.join(ROOT, "include", "ohmhip.h")).read()
+    core = sorted(set(sum((ln.split(":", 1)[1].split() for ln in header.splitlines() if "OHMHIP_CORE_ABI:" in ln), [])))
+    assert 10 <= len(core) <= 20, core
+    src = open(os.path.join(ROOT, "ohm_amd", "host", "ref_adaptor", "private", "HipBindingCore.cpp")).read()
+    called = sorted(set(re.findall(r"\b(ohmhip_[a-z_0-9]+)\s*\(", src)))
+    assert sorted(set(called) | {"ohmhip_error_string"}) == core
+    experimental = set(re.findall(r"OHMHIP_EXPERIMENTAL\s+int\s+(ohmhip_[a-z_0-9]+)", header))
+    assert len(experimental) >= 6 and not (experimental & set(core))
+    assert set(core) <= set(_declared_symbols())
