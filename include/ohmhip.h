@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-/* CORE ABI.  The header has grown to 87 entry points over six rounds; a reference-side binding of ohm::GpuMap /
+/* CORE ABI.  The header has grown to 86 entry points over six rounds; a reference-side binding of ohm::GpuMap /
  * GpuNdtMap / GpuTsdfMap / GpuCache needs FIFTEEN of them.  The list below is exact: it is every ohmhip_* call made by
  * ohm_amd/host/ref_adaptor/private/HipBindingCore.cpp, the compiled and GPU-tested logic of the Level-2 adaptor
  * (INTEGRATION.md), and tests/test_cabi.py keeps the two in step.
