@@ -403,3 +403,28 @@ def test_stop_on_first_occupied_with_a_traversal_layer(gpu):
         plain.integrate_occupancy(rays, flags=0)
     assert any(not np.allclose(plain.chunks()[key]["traversal"], c["traversal"], rtol=1e-5, atol=1e-6)
                for key, c in om.chunks().items() if key in plain.chunks())
+
+
+def test_exclude_ray_skewed_batch_strides_over_the_apply_tiles(gpu):
+    """with kRfExcludeRay no region has a chunk, so every region that receives samples is on k_plan's
+    apply-hits list, and k_apply_lists is launched over (listed regions) x (256-sample tiles of the DENSEST region).  A
+    skewed batch -- thousands of regions, one of them with 10^5 samples -- makes that product exceed the cap of the
+    sample part's grid (2^20 workgroups; the product used to BE the grid, in 32 bits): the workgroups now stride over
+    the pairs.  700 000 rays, presented twice (the second call replays samples onto the values the first left), bit exact."""
+    n_wide, n_dense = 600_000, 100_000
+    wide = synth.random_rays(n_wide, extent=24.0, seed=31, origin_spread=1.0)     # ~3400 regions of 3.2 m
+    dense = synth.random_rays(n_dense, extent=1.5, seed=32, origin_spread=0.2)    # all in the regions about the origin
+    rays = np.concatenate([wide, dense])
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm = GpuMap(map_)
+    om = make_oracle(map_)
+    for _ in range(2):
+        assert gm.integrateRays(rays, ray_update_flags=RayFlag.kRfExcludeRay) == 2 * (n_wide + n_dense)
+        om.integrate_occupancy(rays, flags=int(RayFlag.kRfExcludeRay))
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True)
+    assert_parity(stats)
+    # the cap was exceeded: listed regions x tiles of the densest one (> 12 500 samples in one region is enough for
+    # 3 000 regions; the dense cluster puts several times that into the regions about the origin)
+    dense_region = max(int(np.isfinite(c["occupancy"]).sum()) for c in map_.chunks.values())
+    assert stats["regions_gpu"] >= 3000 and dense_region > 1000, (stats["regions_gpu"], dense_region)
