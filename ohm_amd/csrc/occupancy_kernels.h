@@ -23,22 +23,6 @@
 #ifndef OHMHIP_OCCUPANCY_KERNELS_H
 #define OHMHIP_OCCUPANCY_KERNELS_H
 
-#ifndef OHMHIP_COLD_HINTS
-#define OHMHIP_COLD_HINTS 3  // k_region_walk: branch hints on the rare blocks of the loop (1: exact step, 2: lane refill)
-#endif
-#ifndef OHMHIP_WALK_VGPR_CONSTS
-#define OHMHIP_WALK_VGPR_CONSTS 0  // k_region_walk: wave-uniform constants of the step held in VGPRs
-#endif
-#ifndef OHMHIP_WALK_FLAG_SUPERSET
-#define OHMHIP_WALK_FLAG_SUPERSET 0  // k_region_walk: one cheap test per trip for "some lane met a flagged voxel"
-#endif
-#ifndef OHMHIP_BIN_FUSE_STEPS
-#define OHMHIP_BIN_FUSE_STEPS 1  // k_ray_bin: sample key emitted in the segment loop (one RayWalk load per ray)
-#endif
-#ifndef OHMHIP_LTAB_HASH24
-#define OHMHIP_LTAB_HASH24 1  // binning kernels: LDS region table hashed with three 24-bit multiplies (0: the 64-bit hash)
-#endif
-
 #include "secondary_device.h"
 #include "walk_device.h"
 
@@ -311,14 +295,10 @@ struct LdsRegionTableT
 /// workgroup's regions are a compact neighbourhood, odd multipliers spread neighbours over the table.
 __device__ inline uint32_t ltabHash(uint64_t key, uint32_t mask)
 {
-#if OHMHIP_LTAB_HASH24
   const uint32_t lo = uint32_t(key);
   const uint32_t h = __umul24(lo & 0xffffu, 0x9E3Bu) ^ __umul24(lo >> 16, 0x85EBu) ^
                      __umul24(uint32_t(key >> 32) & 0xffffu, 0xC2B3u);
   return (h ^ (h >> 11)) & mask;
-#else
-  return hashRegionKey(key, mask);
-#endif
 }
 
 /// Find or insert `key`; returns the entry index or kLtabSize when the table is full (caller falls back to global).
@@ -1213,12 +1193,6 @@ __global__ void __launch_bounds__(kBinThreads)
       hit_keys[pos] = hk;
     }
   };
-#if !OHMHIP_BIN_FUSE_STEPS
-  for (uint32_t ray = first + threadIdx.x; ray < last; ray += blockDim.x)
-  {
-    emitSample(ray, walks[ray]);
-  }
-#endif
   // Step 3: scatter, rays visited by descending extent (see RayOrder).
   __shared__ RayOrder order;
   const uint32_t n_local = last - first;
@@ -1231,9 +1205,7 @@ __global__ void __launch_bounds__(kBinThreads)
   {
     const uint32_t ray = first + order.perm[idx];
     const RayWalk rw = walks[ray];
-#if OHMHIP_BIN_FUSE_STEPS
     emitSample(ray, rw);  // (the ray's record is loaded once for both its sample key and its segments)
-#endif
     const RayFix rf = rayFix(mc, rw);
     forEachSegment(mc, rw, true, [&](uint64_t key, const SegmentEntry &entry) {
       const uint32_t e = ltabFind(tab, key, tab_mask);
@@ -1662,31 +1634,13 @@ constexpr uint32_t kLengthClasses = 128;      ///< segment length histogram bins
 /// therefore stored with the bank bits XOR-ed with the y / z bits of the index (a permutation inside every 32-word row).
 __device__ inline uint32_t tileWord(uint32_t w)
 {
-#ifdef OHMHIP_ABL_NOSWZ
-  return w;
-#else
   return w ^ (((w >> 5) ^ (w >> 10)) & 31u);
-#endif
-}
-
-/// The same with the swizzle's bank mask (31 << 2) handed in -- the walk loop keeps it in a VGPR.
-__device__ inline uint32_t tileAddressMasked(uint32_t va, uint32_t bank_mask)
-{
-#ifdef OHMHIP_ABL_NOSWZ
-  return va & ~3u;
-#else
-  return (va & ~3u) ^ (((va >> 5) ^ (va >> 10)) & bank_mask);
-#endif
 }
 
 /// Byte address of the tile word holding the u16 entry at byte offset `va` (= 2 x voxel index).
 __device__ inline uint32_t tileAddress(uint32_t va)
 {
-#ifdef OHMHIP_ABL_NOSWZ
-  return va & ~3u;
-#else
   return (va & ~3u) ^ ((((va >> 5) ^ (va >> 10)) & (31u << 2)));
-#endif
 }
 
 /// Resolve one deferred miss event: find the first sample of the same voxel with a larger ray index; the miss counts
@@ -2302,16 +2256,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     const int ray_shift = args.ray_shift;
     const int refill_min_idle = args.refill_min_idle;
     const bool refill_only = kTrace && (args.dbg & 16u) != 0;
-#if OHMHIP_WALK_VGPR_CONSTS
-    // (a VALU instruction with an SGPR source issues at half rate on gfx950 -- profiles/r04_valu_probe.txt -- so the
-    // step's wave-uniform constants sit in VGPRs)
-    uint32_t fix_margin = mc.fix_margin;
-    asm volatile("" : "+v"(fix_margin));
-    uint32_t bank_mask = 31u << 2;
-    asm volatile("" : "+v"(bank_mask));
-#else
     const uint32_t fix_margin = mc.fix_margin;
-#endif
     const uint32_t idle_address = uint32_t(reinterpret_cast<char *>(l_idle + lane) - reinterpret_cast<char *>(lds));
 
     // Per-lane walk state (all named scalars: no run-time indexed arrays).
@@ -2322,13 +2267,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     uint32_t ray = 0;
     uint32_t skip = 0;      // kSpecial only: first voxel is not visited (kRfExcludeOrigin)
     uint32_t end_last = 0;  // kSpecial only: the segment's last voxel is the ray's end voxel
-#ifdef OHMHIP_ABL_RANK
-    // Timing-only stand-in for the "rank" formulation of a step (profiles/r05_rank_probe.txt): the voxel of crossing k
-    // of one axis from two reciprocal multiplies and floors in fp32, no dependence on the previous step's compare.
-    // The constants are made up from the segment record (results are WRONG; lengths and the tile traffic are real).
-    float rk_k = 0.0f, rk_fa = 0.0f, rk_da = 0.0f, rk_ib = 0.0f, rk_cb = 0.0f, rk_ic = 0.0f, rk_cc = 0.0f;
-    float rk_sa = 0.0f, rk_sb = 0.0f, rk_sc = 0.0f, rk_base = 0.0f, rk_unc = 0.0f;
-#endif
     uint32_t qcount = 0;     // wave-uniform
     bool exhausted = false;  // wave-uniform
     uint32_t dbg_iters = 0, dbg_active = 0, dbg_refills = 0, dbg_fm = 0, dbg_slow = 0;  // wave-uniform (kTrace)
@@ -2349,11 +2287,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       // ---- refill idle lanes (wave-uniform decision) ------------------------------------------------------------------
       const unsigned long long am = __ballot(left > 0);
       const int n_idle = 64 - __popcll(am);
-#if OHMHIP_COLD_HINTS & 2
       if (__builtin_expect(n_idle >= refill_threshold, 0))
-#else
-      if (n_idle >= refill_threshold)
-#endif
       {
         if (exhausted)
         {
@@ -2397,20 +2331,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
             end_last = (rb.w & kSegEnd) ? 1u : 0u;
           }
           left = refill_only ? 0 : left;
-#ifdef OHMHIP_ABL_RANK
-          rk_k = 0.0f;
-          rk_fa = float(f0) * 0x1p-27f;
-          rk_da = float(d0) * 0x1p-27f;
-          rk_ib = __builtin_amdgcn_rcpf(float(d1 | 1u) * 0x1p-27f);
-          rk_cb = 1.0f - float(f1) * 0x1p-27f * rk_ib;
-          rk_ic = __builtin_amdgcn_rcpf(float(d2 | 1u) * 0x1p-27f);
-          rk_cc = 1.0f - float(f2) * 0x1p-27f * rk_ic;
-          rk_sa = float(sx);
-          rk_sb = float(sy);
-          rk_sc = float(sz);
-          rk_base = float(va);
-          rk_unc = 0.0f;
-#endif
         }
         if (!prefetched)
         {
@@ -2442,19 +2362,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         const bool at_end = kSpecial && end_last && left == 1;
         const bool visit = kSpecial ? (left > 0 && (at_end || !skip)) : (left > 0);
         visited[u] = va;
-#ifdef OHMHIP_ABL_NOLDS
-        olds[u] = 0;
-#elif defined(OHMHIP_ABL_LINEAR)
-        olds[u] = tileAdd(((lane + (uint32_t(left) & 255u) * 64u) & 16383u) << 2, shiftOne(va << 3));
-#elif defined(OHMHIP_ABL_RANDOM)
-        olds[u] = tileAdd((((va * 2654435761u) ^ (ray * 0x9E3779B1u)) >> 16) & 0xfffcu, shiftOne(va << 3));
-#else
-#if OHMHIP_WALK_VGPR_CONSTS
-        olds[u] = tileAdd(visit ? tileAddressMasked(va, bank_mask) : idle_address, shiftOne(va << 3));
-#else
         olds[u] = tileAdd(visit ? tileAddress(va) : idle_address, shiftOne(va << 3));
-#endif
-#endif
         if (kSpecial)
         {
           skip = 0;
@@ -2465,36 +2373,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           dbg_active += uint32_t(__popcll(__ballot(visit)));
         }
 
-#ifdef OHMHIP_ABL_RANK
-        {
-          const float t_cross = __builtin_fmaf(rk_k, rk_da, rk_fa);
-          const float xb = __builtin_fmaf(t_cross, rk_ib, rk_cb);
-          const float xc = __builtin_fmaf(t_cross, rk_ic, rk_cc);
-          const float fb = __builtin_floorf(xb);
-          const float fc = __builtin_floorf(xc);
-          rk_unc = __builtin_fmaxf(rk_unc, __builtin_fmaxf(__builtin_fabsf(xb - fb - 0.5f), __builtin_fabsf(xc - fc - 0.5f)));
-          const float nb = __builtin_amdgcn_fmed3f(fb, 0.0f, 31.0f);
-          const float nc = __builtin_amdgcn_fmed3f(fc, 0.0f, 31.0f);
-          const float idxf = __builtin_fmaf(nb, rk_sb, __builtin_fmaf(nc, rk_sc, __builtin_fmaf(rk_k, rk_sa, rk_base)));
-          // (optimistic: the uncertainty test once per trip)
-          const unsigned long long slow = (u == kWalkUnroll - 1) ? __ballot(left > 1 && rk_unc > 0.49999f) : 0ull;
-          if (__builtin_expect(slow != 0, 0))
-          {
-            int axis = 1;
-            if ((slow >> lane) & 1ull)
-            {
-              uint32_t r = ray;
-              asm volatile("" : "+v"(r));
-              axis = exactNextAxis(mc, args.walks[r], region_x, region_y, region_z, va >> 1);
-              rk_unc = 0.0f;
-            }
-            rk_k += float(axis);
-          }
-          va = uint32_t(int(idxf)) & 0xfffeu;
-          rk_k += 1.0f;
-          left -= 1;
-        }
-#else
         int stride;
         {
           // ---- one walk step from the fixed-point predictor (see Segment), taken by every lane.  The smallest
@@ -2504,27 +2382,14 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
           const uint32_t fmin = umin3(f0, f1, f2);
           const uint32_t fmed = umed3(f0, f1, f2);
           const uint32_t limit = min(fmed, kFixMaxDelta);
-#if OHMHIP_WALK_VGPR_CONSTS
-          const uint32_t lead = addSat(fmin, fix_margin);
-#else
           const uint32_t lead = addSatUniform(fmin, fix_margin);
-#endif
           const unsigned long long certain = __builtin_amdgcn_uicmp(lead, limit, kIcmpUlt);
           unsigned long long a0 = __builtin_amdgcn_uicmp(f0, fmin, kIcmpEq);
           unsigned long long a2 = __builtin_amdgcn_uicmp(f2, fmin, kIcmpEq);
-#ifdef OHMHIP_ABL_NOSLOW
-          const unsigned long long slow = 0;
-          (void)certain;
-#else
           // (a lane on its segment's LAST voxel takes a step nobody uses -- its predictors are parked when the ray ends
           // there, which would send every ray of a TSDF / end-point-as-free batch through the exact path once for nothing)
           const unsigned long long slow = __ballot(left > 1) & ~certain;
-#endif
-#if OHMHIP_COLD_HINTS & 1
           if (__builtin_expect(slow != 0, 0))
-#else
-          if (slow)
-#endif
           {
             int axis = 1;
             if ((slow >> lane) & 1ull)
@@ -2552,7 +2417,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         }
         va += uint32_t(stride);
         left -= 1;
-#endif
       }
 
       // ---- deferred ordering of misses on masked voxels.  The returned tile words are consumed after the trip's last
@@ -2563,25 +2427,6 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       {
         olds[u] = waitTile(olds[u]);  // (the first one waits; LDS operations return in order)
       }
-#ifdef OHMHIP_ABL_NOFLAG
-      if (olds[0] == 0x12345u)
-      {
-        ++qcount;
-      }
-      if (false)
-#endif
-#if OHMHIP_WALK_FLAG_SUPERSET
-      // One test for the whole trip: did ANY returned word carry a flag bit (its voxel's or the voxel's sharing the
-      // word)?  A superset of the lanes that met a flagged voxel, two full-rate instructions and one compare for the
-      // trip instead of a bit-field extract and a compare per step.
-      uint32_t any_flag_bits = olds[0];
-#pragma unroll
-      for (int u = 1; u < kWalkUnroll; ++u)
-      {
-        any_flag_bits |= olds[u];
-      }
-      if (__ballot((any_flag_bits & ((kTileFlag << 16) | kTileFlag)) != 0u))
-#endif
 #pragma unroll
       for (int u = 0; u < kWalkUnroll; ++u)
       {

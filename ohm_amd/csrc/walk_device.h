@@ -9,10 +9,6 @@
 
 #include "ohmhip_internal.h"
 
-#ifndef OHMHIP_STEPS_FAST
-#define OHMHIP_STEPS_FAST 1  // stepsBefore: the count from the quotient alone when it is far from every integer
-#endif
-
 namespace ohmhip
 {
 __device__ inline double dInf()
@@ -183,7 +179,6 @@ __device__ inline int stepsBefore(double init, double delta, double rdelta, int 
   if (delta > 0 && delta < dInf())
   {
     const double x = (ta - init) * rdelta;
-#if OHMHIP_STEPS_FAST
     // In real arithmetic T_b(i) <= ta  <=>  i - 1 <= x.  The fp64 values the exact predicate compares -- T_b(i) =
     // fl(init + fl(delta * (i - 1))) against ta -- differ from that by rounding of at most 2^-51 * (i + |init| / delta)
     // steps, and x itself carries three roundings (2^-51 * |x|): for |x| < 2^20 and |init| <= 4 delta both stay below
@@ -197,7 +192,6 @@ __device__ inline int stepsBefore(double init, double delta, double rdelta, int 
       const int count = int(whole) + 1;
       return (x < 0) ? 0 : ((count > total) ? total : count);
     }
-#endif
     // T_b(i) <= ta  <=>  i - 1 <= x
     n = (x < 0) ? 0 : ((x >= double(total)) ? total : int(x) + 1);
     n = (n > total) ? total : n;
