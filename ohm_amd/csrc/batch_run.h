@@ -54,6 +54,9 @@ struct BatchRun
   uint32_t sort_covers = 0;  ///< the per-region sort launched so far orders regions of up to this many samples
   bool batch_end_marked = false;  ///< tev[4] is the stop event of the batch's last kernel already
 
+  /// Samples of a region the walk kernel's shape stages in LDS (WalkFull / WalkHalf).
+  uint32_t walkLdsHits() const { return uint32_t(m->walk_half ? WalkHalf::kLdsHits : WalkFull::kLdsHits); }
+
   /// The batch recorded (or bound to a kernel) event k of its ring entry.
   void mark(int k) { m->tev_mask[ring] = uint8_t(m->tev_mask[ring] | (1u << k)); }
 
@@ -92,7 +95,7 @@ struct BatchRun
     // on more CUs, measured in round 6: 123 -> 112 us per call, while 65 536-ray batches LOSE 20 % with that floor)
     const uint32_t chunk_floor = (n_rays <= 16384u) ? std::min<uint32_t>(m->min_chunk_segments, 512u) : m->min_chunk_segments;
     while (batch_chunk_segments > chunk_floor &&
-           expected_segments / batch_chunk_segments < 3ull * m->walk_workgroups)
+           expected_segments / batch_chunk_segments < 3ull * m->walkSlots())
     {
       batch_chunk_segments /= 2;
     }
@@ -253,7 +256,7 @@ struct BatchRun
     // recorded behind that copy.)
     hipExtLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, f, nullptr, tev[5], 0, regionTable(m), batchScratch(m),
                           batchChunks(m), m->chunk_capacity, batch_chunk_segments, m->h_info_dev,
-                          m->d_info + next_info_index, batchEventCount(m), occ_inline ? uint32_t(kLdsHits) : 0u);
+                          m->d_info + next_info_index, batchEventCount(m), occ_inline ? walkLdsHits() : 0u);
     mark(5);
     m->info_clean = true;
     hipEvent_t plan_done = tev[5];
@@ -521,21 +524,37 @@ struct BatchRun
         // voxel that is walked -- kRfEndPointAsFree, clipped rays, TSDF -- is simply one more voxel of the ray's last
         // segment.)
         const bool special = (ray_flags & OHMHIP_RF_EXCLUDE_ORIGIN) != 0;
-        const dim3 wgrid(std::min<uint32_t>(info.n_chunks, m->walk_workgroups)), wblock(kWalkThreads);
-        const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments);
+        const dim3 wgrid(std::min<uint32_t>(info.n_chunks, m->walkSlots()));
+        const dim3 wblock(m->walk_half ? WalkHalf::kThreads : WalkFull::kThreads);
+        const size_t wlds = walkLdsBytes(m->mc, m->chunk_segments, m->walk_half);
         // tev[3] -- the end of the walk phase -- is the stop event of the phase's last kernel.
         hipEvent_t walk_stop = traversal_pass ? nullptr : tev[3];
-        if (special)
+        if (m->walk_half)
         {
-          hipExtLaunchKernelGGL((k_region_walk<true, false>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
+          if (special)
+          {
+            hipExtLaunchKernelGGL((k_region_walk<true, false, WalkHalf>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
+          }
+          else if (trace)
+          {
+            hipExtLaunchKernelGGL((k_region_walk<false, true, WalkHalf>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
+          }
+          else
+          {
+            hipExtLaunchKernelGGL((k_region_walk<false, false, WalkHalf>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
+          }
+        }
+        else if (special)
+        {
+          hipExtLaunchKernelGGL((k_region_walk<true, false, WalkFull>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
         }
         else if (trace)
         {
-          hipExtLaunchKernelGGL((k_region_walk<false, true>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
+          hipExtLaunchKernelGGL((k_region_walk<false, true, WalkFull>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
         }
         else
         {
-          hipExtLaunchKernelGGL((k_region_walk<false, false>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
+          hipExtLaunchKernelGGL((k_region_walk<false, false, WalkFull>), wgrid, wblock, wlds, s, nullptr, walk_stop, 0, wa);
         }
         if (traversal_pass)
         {
@@ -558,7 +577,7 @@ struct BatchRun
         {
           // Deferred misses reach the global event list only from regions whose samples do not fit the walk's LDS
           // staging (lds_resolve in k_region_walk): no such region, no list to resolve, no launch.
-          if (info.max_region_hits > uint32_t(kLdsHits))
+          if (info.max_region_hits > walkLdsHits())
           {
             hipLaunchKernelGGL(k_flagged_events, dim3(4096), dim3(256), 0, s, batchScratch(m), events, event_capacity,
                                batchEventCount(m), sorted, m->d_miss_counts,

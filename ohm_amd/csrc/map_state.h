@@ -228,6 +228,10 @@ struct ohmhip_map_s
   DevBuf stop_a, stop_b;  ///< kRfStopOnFirstOccupied: per-ray stop positions (current / candidate)
   uint32_t *d_event_count = nullptr;  ///< per parity: [0] deferred event count, [1] walk kernel chunk cursor, [2] replay group count, [3] stop iteration flag
   uint32_t walk_workgroups = 256;     ///< persistent walk workgroups: one per CU
+  /// Regions / tiles of at most 4 096 voxels (16^3) are walked by the WalkHalf shape of k_region_walk: 512-thread workgroups with
+  /// half of everything, two per CU (occupancy_kernels.h; OHMHIP_WALK_HALF=0 keeps the full shape for A/B runs).
+  bool walk_half = false;
+  uint32_t walkSlots() const { return walk_workgroups * (walk_half ? 2u : 1u); }  ///< persistent walk workgroups of a launch
   unsigned long long *d_dbg = nullptr;  ///< 8 debug counters (OHMHIP_DEBUG_FLAGS & 64)
   double first_ray_time = -1.0;  ///< OccupancyMap::firstRayTime() (ohm/OccupancyMap.cpp:343-347)
   uint32_t event_demand = 0;

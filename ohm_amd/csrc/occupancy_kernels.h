@@ -1919,13 +1919,33 @@ constexpr uint32_t kWalkCursorWords = 24;  ///< l_cursor[]: see k_region_walk
 #define OHMHIP_WALK_UNROLL 2
 #endif
 constexpr int kWalkUnroll = OHMHIP_WALK_UNROLL;  ///< walk steps per loop trip (see the loop)
+
+/// Shape of a walk workgroup.  WalkFull is the one the design was tuned on: 1024 threads own a CU with a 32 768-voxel
+/// tile.  WalkHalf (round 6) can serve regions / tiles of up to 16 384 voxels with everything halved -- threads, tile,
+/// staged samples, segments per chunk -- so that TWO workgroups share a CU (at most 80.7 of 81.9 KB of LDS each, 8 waves of
+/// 128 VGPRs each): one's prologue and epilogue run under the other's walk loop.  The per-thread shares (segments and
+/// samples prefetched per thread, tile words per thread in the epilogue) are the same in both.  The host picks it for
+/// regions of at most 4 096 voxels (16^3: -10 % per batch), where it was measured to pay (ohmhip_map.hip).
+template <int kThreadsT, int kTileVoxelsT, int kLdsHitsT, uint32_t kSegmentsT, int kQueueCapT, int kMinWavesPerEuT>
+struct WalkGeometry
+{
+  static constexpr int kMinWavesPerEu = kMinWavesPerEuT;  ///< __launch_bounds__: 4 keeps WalkHalf at 128 VGPRs (two workgroups per CU)
+  static constexpr int kThreads = kThreadsT;
+  static constexpr int kWaves = kThreadsT / 64;
+  static constexpr int kTileVoxels = kTileVoxelsT;  ///< largest region / tile the shape serves
+  static constexpr int kLdsHits = kLdsHitsT;        ///< samples of a region staged in LDS
+  static constexpr uint32_t kSegments = kSegmentsT; ///< segments per chunk (LDS order array)
+  static constexpr int kQueueCap = kQueueCapT;      ///< deferred events per wave
+};
+using WalkFull = WalkGeometry<kWalkThreads, 1 << kHitVoxelBits, kLdsHits, kMaxChunkSegments, kQueueCap, 1>;
+using WalkHalf = WalkGeometry<kWalkThreads / 2, (1 << kHitVoxelBits) / 2, kLdsHits / 2, kMaxChunkSegments / 2, 96, 4>;
 /// kSpecial: the batch contains rays whose end voxel is part of the walk (clipped / kRfEndPointAsFree / TSDF) or
 /// kRfExcludeOrigin.  The common case (kSpecial == false) keeps those predicates out of the hot loop: every iteration
 /// of an active lane is a miss.
 /// kTrace: development instrumentation (OHMHIP_DEBUG_FLAGS 64 / 128): per-chunk time stamps and loop counters.  Compiled
 /// out of the production instantiations.
-template <bool kSpecial, bool kTrace>
-__global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
+template <bool kSpecial, bool kTrace, typename G = WalkFull>
+__global__ void __launch_bounds__(G::kThreads, G::kMinWavesPerEu) k_region_walk(WalkArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const MapConst &mc = args.mc;
@@ -1936,11 +1956,11 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   const uint32_t mask_words = uint32_t(mc.region_voxels + 31) >> 5;
   uint32_t *l_counts = lds;
   uint2 *l_queues = reinterpret_cast<uint2 *>(lds + ((count_words + 31u) & ~31u));  // (whole rows: see tileWord)
-  unsigned long long *l_hits = reinterpret_cast<unsigned long long *>(l_queues + kWalkWaves * kQueueCap);
-  uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + kLdsHits);  // [kLdsHits] u16 interval counters
+  unsigned long long *l_hits = reinterpret_cast<unsigned long long *>(l_queues + G::kWaves * G::kQueueCap);
+  uint32_t *l_intervals = reinterpret_cast<uint32_t *>(l_hits + G::kLdsHits);  // [G::kLdsHits] u16 interval counters
   // l_cursor[0]: segment cursor, [1]: a fetched chunk's index, [2..5]: its record, [6..7]: its samples, [8..9]: its
   // region key; [12..21]: a second record (start-up only)
-  uint32_t *l_cursor = l_intervals + kLdsHits / 2;
+  uint32_t *l_cursor = l_intervals + G::kLdsHits / 2;
   uint32_t *l_hist = l_cursor + kWalkCursorWords;
   uint32_t *l_idle = l_hist + kLengthClasses;  // [64] scratch words: where a lane with nothing to visit aims its LDS add
   uint16_t *l_index = reinterpret_cast<uint16_t *>(l_idle + 64);  // [kIndexBuckets + 2] first staged sample per bucket
@@ -1978,8 +1998,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   // registers -- issued behind the first lane refill of chunk N, so the loads complete under the walk and the next
   // prologue starts without a memory round trip -- and thread 0 claims chunk N + 2 while the other waves finish their
   // loop.
-  constexpr int kSegPerThread = int(kMaxChunkSegments) / kWalkThreads;
-  constexpr int kHitsPerThread = kLdsHits / kWalkThreads;
+  constexpr int kSegPerThread = int(G::kSegments) / G::kThreads;
+  constexpr int kHitsPerThread = G::kLdsHits / uint32_t(G::kThreads);
   struct ChunkRecord
   {
     uint32_t index, slot, seg_begin, seg_end, hash_index, hb, he, key_lo, key_hi;
@@ -2006,12 +2026,12 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
   // of predicated so the loads share one basic block.
   auto prefetchChunk = [&](const ChunkRecord &r) {
     const uint32_t n_hits = r.he - r.hb;
-    if (!defer_all && n_hits && n_hits <= uint32_t(kLdsHits))
+    if (!defer_all && n_hits && n_hits <= uint32_t(G::kLdsHits))
     {
 #pragma unroll
       for (int j = 0; j < kHitsPerThread; ++j)
       {
-        pf_hits[j] = args.sorted_hits[r.hb + min(threadIdx.x + uint32_t(j) * kWalkThreads, n_hits - 1u)];
+        pf_hits[j] = args.sorted_hits[r.hb + min(threadIdx.x + uint32_t(j) * uint32_t(G::kThreads), n_hits - 1u)];
       }
     }
     pf_mask = args.hit_mask[size_t(r.slot) * mask_words + min(threadIdx.x, mask_words - 1u)];
@@ -2019,7 +2039,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
     for (int j = 0; j < kSegPerThread; ++j)
     {
-      pf_vox[j] = args.segments[r.seg_begin + min(threadIdx.x + uint32_t(j) * kWalkThreads, n - 1u)].vox;
+      pf_vox[j] = args.segments[r.seg_begin + min(threadIdx.x + uint32_t(j) * uint32_t(G::kThreads), n - 1u)].vox;
     }
   };
   // The first two records, fetched by two waves at once.
@@ -2067,7 +2087,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // ---- inputs are in registers already (prefetchChunk).
     // The region's sorted sample keys are staged in LDS so deferred misses can be ordered against them at LDS latency.
     const uint32_t n_region_hits = he - hb;
-    const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(kLdsHits);
+    const bool lds_resolve = !defer_all && n_region_hits <= uint32_t(G::kLdsHits);
     unsigned long long my_hits[kHitsPerThread];
 #pragma unroll
     for (int j = 0; j < kHitsPerThread; ++j)
@@ -2103,7 +2123,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     // Tile entries start at zero count with the voxel's mask flag in the top bit: one mask word covers 16 tile words,
     // half a row of the tile, which tileWord() maps onto half a row again: the 4-word groups permuted by the high bits
     // of the row's XOR constant, the words inside a group by its low two bits.
-    for (uint32_t w = threadIdx.x; w < mask_words; w += kWalkThreads)
+    for (uint32_t w = threadIdx.x; w < mask_words; w += uint32_t(G::kThreads))
     {
       const uint32_t mword = args.flag_all ? 0xffffffffu : ((w == threadIdx.x) ? my_mask : g_mask[w]);
       const uint32_t swizzle = tileWord(w * 16u) ^ (w * 16u);
@@ -2152,7 +2172,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
     for (int j = 0; j < kSegPerThread; ++j)
     {
-      if (threadIdx.x + uint32_t(j) * kWalkThreads < n_seg)
+      if (threadIdx.x + uint32_t(j) * uint32_t(G::kThreads) < n_seg)
       {
         atomicAdd(&l_hist[lens[j]], 1u);
       }
@@ -2162,7 +2182,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
       for (int j = 0; j < kHitsPerThread; ++j)
       {
-        const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
+        const uint32_t i = threadIdx.x + uint32_t(j) * uint32_t(G::kThreads);
         if (i < n_region_hits)
         {
           l_hits[i] = my_hits[j];
@@ -2184,7 +2204,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
       for (int j = 0; j < kHitsPerThread; ++j)
       {
-        const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
+        const uint32_t i = threadIdx.x + uint32_t(j) * uint32_t(G::kThreads);
         if (i < n_region_hits)
         {
           auto bucketOf = [](unsigned long long key) {
@@ -2227,7 +2247,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
     for (int j = 0; j < kSegPerThread; ++j)
     {
-      const uint32_t i = threadIdx.x + uint32_t(j) * kWalkThreads;
+      const uint32_t i = threadIdx.x + uint32_t(j) * uint32_t(G::kThreads);
       if (i < n_seg)
       {
         l_order[atomicAdd(&l_hist[lens[j]], 1u)] = uint16_t(i);
@@ -2249,7 +2269,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 
     const unsigned lane = laneId();
     const unsigned wave = threadIdx.x >> 6;
-    uint2 *queue = l_queues + wave * kQueueCap;
+    uint2 *queue = l_queues + wave * G::kQueueCap;
     const int dimx = mc.dim[0];
     const int dimxy = mc.dim[0] * mc.dim[1];
     const unsigned long long slot_bits = (unsigned long long)chunk.slot << kHitSlotShift;
@@ -2446,7 +2466,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
             queue[pos] = make_uint2(visited[u] >> 1, ray);
           }
           qcount += uint32_t(__popcll(fm));
-          if (qcount > uint32_t(kQueueCap - 64))
+          if (qcount > uint32_t(G::kQueueCap - 64))
           {
             flushQueue(queue, qcount, lane, slot_bits, ray_shift, lds_resolve, l_hits, l_index, n_region_hits,
                        l_intervals, l_counts, args.events, args.event_capacity, args.event_count, defer_all, args.bs,
@@ -2511,7 +2531,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
                              (chunk.hash_index & 0x80000000u);
     if (lds_resolve && !inline_hits)
     {
-      for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
+      for (uint32_t i = threadIdx.x; i < n_region_hits; i += uint32_t(G::kThreads))
       {
         const uint32_t c = (l_intervals[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
         if (c)
@@ -2537,7 +2557,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       // Load pass / update pass, so the loads of the voxels a thread updates are in flight together (a load -> update ->
       // store loop would pay the memory latency once per touched word, and nothing else runs on this CU to hide it);
       // in two halves, which keeps the kernel's register peak below the walk loop's budget.
-      constexpr uint32_t kWordsPerThread = (1u << kHitVoxelBits) / 2u / kWalkThreads / 2u;
+      constexpr uint32_t kWordsPerThread = uint32_t(G::kTileVoxels) / 2u / uint32_t(G::kThreads) / 2u;
       const bool even_voxels = (mc.region_voxels & 1) == 0;
       for (uint32_t half = 0; half < 2u; ++half)
       {
@@ -2546,7 +2566,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
       for (uint32_t j = 0; j < kWordsPerThread; ++j)
       {
-        const uint32_t i = threadIdx.x + (half * kWordsPerThread + j) * kWalkThreads;
+        const uint32_t i = threadIdx.x + (half * kWordsPerThread + j) * uint32_t(G::kThreads);
         const uint32_t flagged_w = (i < count_words) ? l_counts[tileWord(i)] : 0u;
         uint32_t w = flagged_w;
         // Keep only the entries applied here: unflagged voxels with a count.
@@ -2582,7 +2602,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
       for (uint32_t j = 0; j < kWordsPerThread; ++j)
       {
-        const uint32_t i = threadIdx.x + (half * kWordsPerThread + j) * kWalkThreads;
+        const uint32_t i = threadIdx.x + (half * kWordsPerThread + j) * uint32_t(G::kThreads);
         const uint32_t w = words[j];
         if (w)
         {
@@ -2617,7 +2637,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
         // Ordered replay of the region's samples, one lane per voxel with samples (the head of its run in the sorted
         // list): misses before each sample from the interval counters, the sample, the trailing misses from the tile.
         // These voxels are disjoint from the ones the passes above wrote.
-        for (uint32_t i = threadIdx.x; i < n_region_hits; i += kWalkThreads)
+        for (uint32_t i = threadIdx.x; i < n_region_hits; i += uint32_t(G::kThreads))
         {
           const unsigned long long key = l_hits[i];
           const unsigned long long group = key >> kHitRayBits;
@@ -2661,14 +2681,14 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
       // straight from LDS; flagged voxels are replayed from their events.
       float2 *g_tsdf = reinterpret_cast<float2 *>(args.tsdf) + size_t(chunk.slot) * size_t(mc.region_voxels);
       constexpr uint32_t kTsdfBatch = 4;
-      for (uint32_t first = threadIdx.x; first < count_words; first += kTsdfBatch * kWalkThreads)
+      for (uint32_t first = threadIdx.x; first < count_words; first += kTsdfBatch * uint32_t(G::kThreads))
       {
         uint32_t words[kTsdfBatch];
         float2 values[2 * kTsdfBatch];
 #pragma unroll
         for (uint32_t j = 0; j < kTsdfBatch; ++j)
         {
-          const uint32_t i = first + j * kWalkThreads;
+          const uint32_t i = first + j * uint32_t(G::kThreads);
           uint32_t w = (i < count_words) ? l_counts[tileWord(i)] : 0u;
           w = (w & kTileFlag) ? (w & 0xffff0000u) : w;
           w = (w & (kTileFlag << 16)) ? (w & 0x0000ffffu) : w;
@@ -2687,7 +2707,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
 #pragma unroll
         for (uint32_t j = 0; j < kTsdfBatch; ++j)
         {
-          const uint32_t i = first + j * kWalkThreads;
+          const uint32_t i = first + j * uint32_t(G::kThreads);
           const uint32_t n0 = words[j] & kTileCountMask;
           const uint32_t n1 = (words[j] >> 16) & kTileCountMask;
           if (n0)
@@ -2713,7 +2733,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_region_walk(WalkArgs args)
     }
     // Flush the tile: integer adds, so the merge across chunks of one region is order independent.  (NDT / TSDF:
     // entries of masked voxels are skipped -- their visits travel as events.)
-    for (uint32_t i = threadIdx.x; i < count_words; i += kWalkThreads)
+    for (uint32_t i = threadIdx.x; i < count_words; i += uint32_t(G::kThreads))
     {
       const uint32_t w = l_counts[tileWord(i)];
       if (w & (kTileCountMask | (kTileCountMask << 16)))

@@ -259,19 +259,45 @@ try
   {
     m->min_chunk_segments = uint32_t(std::max(64, std::min(int(kMaxChunkSegments), std::atoi(env))));
   }
+  // Small regions (16^3: at most an eighth of the tile the full shape serves) are walked by half-size workgroups, two
+  // per CU.  Measured with the C1 sweep (scripts/half_probe.py, profiles/r06_notes.md): 16^3 regions 1.40 against 1.55 ms
+  // per batch; 16 x 16 x 32 regions 1.23 against 1.20 (a wash); 32 x 32 x 16 regions 1.14 against 0.96 -- those hold
+  // nearly as many segments as 32^3 ones, the half shape's 4096-segment chunks split most of them, and split regions
+  // pay the global count round trip.  (OHMHIP_WALK_HALF_VOXELS moves the threshold for A/B runs.)
+  uint32_t half_voxels = uint32_t(WalkHalf::kTileVoxels) / 4u;
+  if (const char *env = std::getenv("OHMHIP_WALK_HALF_VOXELS"))
+  {
+    half_voxels = uint32_t(std::max(0, std::min(int(WalkHalf::kTileVoxels), std::atoi(env))));
+  }
+  m->walk_half = uint32_t(mc.region_voxels) <= half_voxels;
+  if (const char *env = std::getenv("OHMHIP_WALK_HALF"))
+  {
+    m->walk_half = m->walk_half && std::atoi(env) != 0;
+  }
+  if (m->walk_half)
+  {
+    m->chunk_segments = std::min<uint32_t>(m->chunk_segments, WalkHalf::kSegments);
+    m->min_chunk_segments = std::min<uint32_t>(m->min_chunk_segments, WalkHalf::kSegments / 4u);
+  }
   // The walk kernel keeps a region's count tile, the staged samples and the chunk's segment order in LDS (about
-  // 150 KiB of the CU's 160 KiB for 32^3 regions): the chunk size gives way if the region tile is large.
-  while (walkLdsBytes(mc, m->chunk_segments) > size_t(160) * 1024 && m->chunk_segments > 64)
+  // 150 KiB of the CU's 160 KiB for 32^3 regions; half of that twice for the half shape): the chunk size gives way if
+  // the region tile is large.
+  const size_t lds_limit = m->walk_half ? size_t(80) * 1024 : size_t(160) * 1024;
+  while (walkLdsBytes(mc, m->chunk_segments, m->walk_half) > lds_limit && m->chunk_segments > 64)
   {
     m->chunk_segments /= 2;
   }
-  const size_t lds_bytes = walkLdsBytes(mc, m->chunk_segments);
-  const void *walk_kernels[3] = { reinterpret_cast<const void *>(k_region_walk<false, false>),
-                                  reinterpret_cast<const void *>(k_region_walk<true, false>),
-                                  reinterpret_cast<const void *>(k_region_walk<false, true>) };
-  for (const void *kernel : walk_kernels)
+  const size_t lds_bytes = walkLdsBytes(mc, m->chunk_segments, m->walk_half);
+  const void *walk_kernels_full[3] = { reinterpret_cast<const void *>(k_region_walk<false, false, WalkFull>),
+                                       reinterpret_cast<const void *>(k_region_walk<true, false, WalkFull>),
+                                       reinterpret_cast<const void *>(k_region_walk<false, true, WalkFull>) };
+  const void *walk_kernels_half[3] = { reinterpret_cast<const void *>(k_region_walk<false, false, WalkHalf>),
+                                       reinterpret_cast<const void *>(k_region_walk<true, false, WalkHalf>),
+                                       reinterpret_cast<const void *>(k_region_walk<false, true, WalkHalf>) };
+  const void *const *walk_kernels = m->walk_half ? walk_kernels_half : walk_kernels_full;
+  for (int k = 0; k < 3; ++k)
   {
-    if ((err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
+    if ((err = hipFuncSetAttribute(walk_kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != 0)
     {
       return fail(err);
     }
@@ -307,7 +333,14 @@ try
     wa.chunk_cursor = batchEventCount(m) + 1;
     for (hipStream_t stream : { m->stream, m->front_stream })
     {
-      hipLaunchKernelGGL((k_region_walk<true, false>), dim3(1), dim3(kWalkThreads), lds_bytes, stream, wa);
+      if (m->walk_half)
+      {
+        hipLaunchKernelGGL((k_region_walk<true, false, WalkHalf>), dim3(1), dim3(WalkHalf::kThreads), lds_bytes, stream, wa);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_region_walk<true, false, WalkFull>), dim3(1), dim3(WalkFull::kThreads), lds_bytes, stream, wa);
+      }
       if ((err = hipMemsetAsync(batchEventCount(m), 0, 2 * sizeof(uint32_t), stream)) != 0 ||
           (err = hipStreamSynchronize(stream)) != 0)
       {

@@ -573,15 +573,21 @@ using SortConfig =
 
 constexpr size_t kDbgWords = 16 + size_t(kTraceChunks) * kTraceWords;
 
-size_t walkLdsBytes(const MapConst &mc, uint32_t chunk_segments)
+template <typename G>
+size_t walkLdsBytesOf(const MapConst &mc, uint32_t chunk_segments)
 {
   // [count tile, padded to 16 B][per-wave queues][staged sample keys][interval counters][cursor + pad]
   // [length histogram][segment order, u16 each]
   const size_t count_words = (size_t((mc.region_voxels + 1) / 2) + 31u) & ~size_t(31);  // whole 32-word rows (tileWord)
-  return (count_words + size_t(2 * kWalkWaves * kQueueCap) + size_t(2 * kLdsHits) + size_t(kLdsHits / 2) +
+  return (count_words + size_t(2 * G::kWaves * G::kQueueCap) + size_t(2 * G::kLdsHits) + size_t(G::kLdsHits / 2) +
           kWalkCursorWords + 64 + (kIndexBuckets + 2) / 2 +
           kLengthClasses + (chunk_segments + 1) / 2) *
          sizeof(uint32_t);
+}
+
+size_t walkLdsBytes(const MapConst &mc, uint32_t chunk_segments, bool half = false)
+{
+  return half ? walkLdsBytesOf<WalkHalf>(mc, chunk_segments) : walkLdsBytesOf<WalkFull>(mc, chunk_segments);
 }
 
 __global__ void k_clear_counts(MapConst mc, RegionTable rt, BatchScratch bs, uint32_t *__restrict__ miss_counts)
