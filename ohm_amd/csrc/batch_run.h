@@ -53,6 +53,10 @@ struct BatchRun
   uint32_t direct_segments = 0;
   uint32_t sort_covers = 0;  ///< the per-region sort launched so far orders regions of up to this many samples
   bool batch_end_marked = false;  ///< tev[4] is the stop event of the batch's last kernel already
+  /// NDT / TSDF: the event sort and the replay were launched on a speculated event count (the previous batch's plus head
+  /// room; k_pad_events); the true count is on its way to the host and is looked at once the replay has been launched.
+  bool events_speculated = false;
+  uint32_t spec_events = 0;
 
   /// Samples of a region the walk kernel's shape stages in LDS (WalkFull / WalkHalf).
   uint32_t walkLdsHits() const { return uint32_t(m->walk_half ? WalkHalf::kLdsHits : WalkFull::kLdsHits); }
@@ -472,7 +476,7 @@ struct BatchRun
     return OHMHIP_OK;
   }
 
-  int walk()
+  int walk(int first_attempt = 0)
   {
     // Single-chunk regions are applied by the walk kernel straight from LDS (plain log-odds misses only).
     direct_occ = (occupancy_mode || mode == OHMHIP_MODE_NDT_OM) ? static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]) :
@@ -481,7 +485,7 @@ struct BatchRun
     n_events = 0;
     if (info.n_chunks)
     {
-      for (int walk_attempt = 0; walk_attempt < 4; ++walk_attempt)
+      for (int walk_attempt = first_attempt; walk_attempt < 4; ++walk_attempt)
       {
         if (walk_attempt > 0)
         {
@@ -590,7 +594,21 @@ struct BatchRun
           }
           break;
         }
-        // NDT / TSDF: the host needs the event count to size the sort; an overflowing list is re-walked.
+        // NDT / TSDF: the event sort is sized by the event count.  A batch that follows another one does not wait for
+        // its own: the sort and the replay are launched on the previous batch's count plus head room, the list padded
+        // up to that by k_pad_events (which also sends the true count to the host), and the count is checked once the
+        // replay has been launched (settleSpeculatedEvents) -- the host round trip idled the device for 26 us per C2
+        // batch.  (Not the stop-flag replay: its scans wait for the host anyway.)
+        if (!stop_mode && walk_attempt == 0 && m->event_demand > 0 && event_capacity > 0)
+        {
+          spec_events = uint32_t(std::min<uint64_t>(event_capacity, uint64_t(m->event_demand) + m->event_demand / 8u + 4096u));
+          hipExtLaunchKernelGGL(k_pad_events, dim3(256), dim3(256), 0, s, nullptr, m->ev[5], 0, events, batchEventCount(m),
+                                spec_events, reinterpret_cast<uint32_t *>(m->h_info_dev + 1));
+          events_speculated = true;
+          n_events = spec_events;
+          break;
+        }
+        // Otherwise the host needs the count now; an overflowing list is re-walked.
         OHMHIP_CHECK(hipMemcpyAsync(&m->h_info[1], batchEventCount(m), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         OHMHIP_CHECK(hipStreamSynchronize(s));
         n_events = *reinterpret_cast<const uint32_t *>(&m->h_info[1]);
@@ -599,21 +617,7 @@ struct BatchRun
         {
           break;
         }
-        // Overflow: undo the count flush, grow the key buffers (sample keys must be regenerated) and walk again.
-        hipLaunchKernelGGL(k_clear_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m),
-                           batchScratch(m), m->d_miss_counts);
-        const size_t total = size_t(n_rays) + size_t(n_events) + (size_t(n_events) >> 3) + 1024;
-        OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * total, false, s));
-        OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * total, false, s));
-        keys_a = static_cast<unsigned long long *>(m->hit_keys_a.ptr);
-        keys_b = static_cast<unsigned long long *>(m->hit_keys_b.ptr);
-        sorted = keys_b;
-        events = keys_a + n_rays;
-        event_capacity = uint32_t(std::min<size_t>(total - n_rays, 0xfffffff0u - n_rays));
-        // k_ray_bin also fills the segment buckets: only the sample keys are rewritten here (cursors already reset).
-        OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), s));
-        hipLaunchKernelGGL(k_rekey_samples, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
-                           static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays, keys_a, ray_shift);
+        OHMHIP_CHECK(recoverEventOverflow());
         if (walk_attempt == 3)
         {
           return OHMHIP_ERR_INTERNAL;
@@ -625,6 +629,27 @@ struct BatchRun
       OHMHIP_CHECK(hipEventRecord(tev[3], s));
       mark(3);
     }
+    return OHMHIP_OK;
+  }
+
+  /// The walk produced more events (n_events) than the list holds: undo the count flush, grow the key buffers (sample
+  /// keys must be regenerated); the caller walks again.
+  int recoverEventOverflow()
+  {
+    hipLaunchKernelGGL(k_clear_counts, dim3(info.n_touched), dim3(256), 0, s, m->mc, regionTable(m), batchScratch(m),
+                       m->d_miss_counts);
+    const size_t total = size_t(n_rays) + size_t(n_events) + (size_t(n_events) >> 3) + 1024;
+    OHMHIP_CHECK(m->hit_keys_a.ensure(sizeof(unsigned long long) * total, false, s));
+    OHMHIP_CHECK(m->hit_keys_b.ensure(sizeof(unsigned long long) * total, false, s));
+    keys_a = static_cast<unsigned long long *>(m->hit_keys_a.ptr);
+    keys_b = static_cast<unsigned long long *>(m->hit_keys_b.ptr);
+    sorted = keys_b;
+    events = keys_a + n_rays;
+    event_capacity = uint32_t(std::min<size_t>(total - n_rays, 0xfffffff0u - n_rays));
+    // k_ray_bin also fills the segment buckets: only the sample keys are rewritten here (cursors already reset).
+    OHMHIP_CHECK(hipMemsetAsync(m->d_info + m->info_index, 0, sizeof(BatchInfo), s));
+    hipLaunchKernelGGL(k_rekey_samples, dim3(ray_blocks), dim3(256), 0, s, m->mc, regionTable(m),
+                       static_cast<const RayWalk *>(batchWalks(m).ptr), n_rays, keys_a, ray_shift);
     return OHMHIP_OK;
   }
 
@@ -683,13 +708,19 @@ struct BatchRun
     return OHMHIP_OK;
   }
 
-  int replayEvents()
+  /// Order the events (samples included) per voxel in ray order and launch the mode's replay kernel.  With
+  /// events_speculated the kernels that consume the list carry the guard (true count, speculated count).
+  uint32_t *replay_heads = nullptr;
+  uint32_t replay_blocks = 0;
+  int sortAndReplay()
   {
     const size_t total = size_t(n_rays) + size_t(n_events);
+    const uint32_t *guard_count = events_speculated ? batchEventCount(m) : nullptr;
+    const uint32_t guard_limit = events_speculated ? spec_events : 0u;
     // The device-wide one-sweep radix sort.  Round 5 built two replacements that order the keys without it -- bucket by
     // voxel row (histogram, scan, scatter), then an LDS bitonic sort per unit of <= 4096 keys, with the replay either
     // fused into that kernel or run by the kernels below --, both bit exact, neither faster: C2 1.09 ms against 1.05,
-    // C3 11.2 against 10.3 (profiles/r05_event_buckets.txt).  Per-key global atomics of the two bucketing
+    // C3 11.2 against 10.3 (profiles/r05_event_buckets.txt; history 4.2).  Per-key global atomics of the two bucketing
     // passes cost what the sort's passes cost, and the fused replay loses the occupancy the long voxel chains need.
     size_t sort_bytes = 0;
     OHMHIP_CHECK(rocprim::radix_sort_keys<SortConfig>(nullptr, sort_bytes, keys_a, keys_b, total, 0, sortEndBit(m), s));
@@ -700,18 +731,70 @@ struct BatchRun
     // NDT: one lane per voxel group -- compact the group heads, then replay grid-stride over them (a voxel's event
     // list is long there and the maths heavy; a lane per event with the non-heads exiting ran at a few live lanes
     // per wave).
-    uint32_t *heads = nullptr;
+    replay_heads = nullptr;
     uint32_t *n_heads = batchEventCount(m) + 2;
-    uint32_t replay_blocks = uint32_t((total + 127) / 128);
+    replay_blocks = uint32_t((total + 127) / 128);
     if (ndt_mode)
     {
       OHMHIP_CHECK(m->group_heads.ensure(sizeof(uint32_t) * total, false, s));
-      heads = static_cast<uint32_t *>(m->group_heads.ptr);
+      replay_heads = static_cast<uint32_t *>(m->group_heads.ptr);
       OHMHIP_CHECK(hipMemsetAsync(n_heads, 0, sizeof(uint32_t), s));
       hipLaunchKernelGGL(k_group_heads, dim3(uint32_t((total + kHeadsPerBlock - 1) / kHeadsPerBlock)), dim3(256), 0, s,
-                         sorted, uint32_t(total), heads, n_heads);
+                         sorted, uint32_t(total), replay_heads, n_heads, guard_count, guard_limit);
       replay_blocks = uint32_t(std::min<size_t>(replay_blocks, size_t(m->walk_workgroups) * 32u));
     }
+    if (ndt_mode)
+    {
+      const bool tm = mode == OHMHIP_MODE_NDT_TM;
+      hipLaunchKernelGGL(k_replay_ndt, dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
+                         uint32_t(total), d_rays, d_intensities,
+                         static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
+                         static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]),
+                         static_cast<float *>(m->layers[OHMHIP_LID_COVARIANCE]),
+                         tm ? static_cast<float *>(m->layers[OHMHIP_LID_INTENSITY]) : nullptr,
+                         tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr, sec,
+                         static_cast<const RayWalk *>(batchWalks(m).ptr), replay_heads, n_heads, guard_count, guard_limit);
+    }
+    else if (tsdf_mode)
+    {
+      hipLaunchKernelGGL(k_replay_tsdf, dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
+                         uint32_t(total), d_rays, static_cast<float *>(m->layers[OHMHIP_LID_TSDF]), replay_heads, n_heads,
+                         guard_count, guard_limit);
+    }
+    return OHMHIP_OK;
+  }
+
+  /// The true event count of a batch whose sort and replay were launched on a speculated one has reached the host (it
+  /// left the device right behind the walk, long before the replay ends: the wait costs nothing).  Usually it fits
+  /// and nothing remains to do; otherwise the guarded kernels did nothing, and the sort and the replay are repeated with
+  /// the exact size -- after a re-walk with a larger list when even that overflowed.
+  int settleSpeculatedEvents()
+  {
+    OHMHIP_CHECK(hipEventSynchronize(m->ev[5]));
+    const uint32_t actual = *reinterpret_cast<const volatile uint32_t *>(&m->h_info[1]);
+    m->event_demand = actual;
+    if (actual <= spec_events)
+    {
+      return OHMHIP_OK;
+    }
+    events_speculated = false;
+    n_events = actual;
+    if (actual > event_capacity)
+    {
+      OHMHIP_CHECK(recoverEventOverflow());
+      OHMHIP_CHECK(walk(1));  // (not speculated: attempts after the first wait for their count)
+    }
+    return sortAndReplay();
+  }
+
+  int replayEvents()
+  {
+    OHMHIP_CHECK(sortAndReplay());
+    if (events_speculated)
+    {
+      OHMHIP_CHECK(settleSpeculatedEvents());
+    }
+    const size_t total = size_t(n_rays) + size_t(n_events);
     if (stop_mode)
     {
       // Per-ray stop positions by iteration (k_stop_replay): a scan that moves no ray's stop is the sequential result.
@@ -757,14 +840,6 @@ struct BatchRun
     else if (ndt_mode)
     {
       const bool tm = mode == OHMHIP_MODE_NDT_TM;
-      hipLaunchKernelGGL(k_replay_ndt, dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
-                         uint32_t(total), d_rays, d_intensities,
-                         static_cast<float *>(m->layers[OHMHIP_LID_OCCUPANCY]),
-                         static_cast<uint32_t *>(m->layers[OHMHIP_LID_MEAN]),
-                         static_cast<float *>(m->layers[OHMHIP_LID_COVARIANCE]),
-                         tm ? static_cast<float *>(m->layers[OHMHIP_LID_INTENSITY]) : nullptr,
-                         tm ? static_cast<uint32_t *>(m->layers[OHMHIP_LID_HIT_MISS]) : nullptr, sec,
-                         static_cast<const RayWalk *>(batchWalks(m).ptr), heads, n_heads);
       if (info.n_touched)
       {
         hipLaunchKernelGGL(k_apply_counts, dim3(info.n_touched), dim3(1024), 0, s, m->mc, regionTable(m),
@@ -774,18 +849,13 @@ struct BatchRun
                            sec.traversal, sec.traversal ? m->d_traversal_acc : nullptr);
       }
     }
-    else
+    else if (info.n_touched)
     {
-      hipLaunchKernelGGL(k_replay_tsdf, dim3(replay_blocks), dim3(128), 0, s, m->mc, regionTable(m), sorted,
-                         uint32_t(total), d_rays, static_cast<float *>(m->layers[OHMHIP_LID_TSDF]), heads, n_heads);
-      if (info.n_touched)
-      {
-        hipLaunchKernelGGL(k_apply_counts_tsdf, dim3(info.n_touched * kTsdfApplyParts), dim3(256), 0, s, m->mc, regionTable(m),
-                           batchScratch(m), m->d_miss_counts, m->d_hit_mask,
-                           static_cast<float *>(m->layers[OHMHIP_LID_TSDF]), direct_segments);
-        hipLaunchKernelGGL(k_batch_reset, dim3((info.n_touched + 255u) / 256u), dim3(256), 0, s, batchScratch(m),
-                           info.n_touched);
-      }
+      hipLaunchKernelGGL(k_apply_counts_tsdf, dim3(info.n_touched * kTsdfApplyParts), dim3(256), 0, s, m->mc, regionTable(m),
+                         batchScratch(m), m->d_miss_counts, m->d_hit_mask,
+                         static_cast<float *>(m->layers[OHMHIP_LID_TSDF]), direct_segments);
+      hipLaunchKernelGGL(k_batch_reset, dim3((info.n_touched + 255u) / 256u), dim3(256), 0, s, batchScratch(m),
+                         info.n_touched);
     }
     return OHMHIP_OK;
   }

@@ -35,10 +35,43 @@ __device__ inline void voxelCentreOf(const MapConst &mc, const RegionTable &rt, 
 /// each loop over a whole group).  Wave-aggregated append; the order of the list does not matter.
 constexpr uint32_t kHeadsPerBlock = 2048;  ///< events scanned by one k_group_heads workgroup (256 threads x 8)
 
+/// Round 6: the NDT / TSDF event sort is launched on the PREVIOUS batch's event count (plus head room) instead of waiting
+/// for this batch's to reach the host -- 26 us of idle device per C2 batch.  This kernel, behind the walk, pads the event
+/// list from the true count up to the speculated one with kHitInvalid keys (they sort to the end and every consumer skips
+/// them) and sends the true count to pinned host memory; the kernels that consume the sorted list take the pair
+/// (event_count, event_limit) and do NOTHING when the true count exceeded the speculation -- the host, which has read the
+/// count by then, repeats the sort and the replay with the exact size (batch_run.h: settleSpeculatedEvents).
+__global__ void __launch_bounds__(256)
+  k_pad_events(unsigned long long *__restrict__ events, const uint32_t *__restrict__ event_count, uint32_t spec_events,
+               uint32_t *__restrict__ host_event_count)
+{
+  const uint32_t n = *event_count;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    *host_event_count = n;
+    __threadfence_system();
+  }
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = min(n, spec_events) + blockIdx.x * blockDim.x + threadIdx.x; i < spec_events; i += stride)
+  {
+    events[i] = kHitInvalid;
+  }
+}
+
+/// True when a speculatively sized event list turned out too short: the caller (a kernel) leaves without side effects.
+__device__ inline bool speculationFailed(const uint32_t *__restrict__ event_count, uint32_t event_limit)
+{
+  return event_count != nullptr && *event_count > event_limit;
+}
+
 __global__ void __launch_bounds__(256)
   k_group_heads(const unsigned long long *__restrict__ sorted, uint32_t n_events, uint32_t *__restrict__ heads,
-                uint32_t *__restrict__ n_heads)
+                uint32_t *__restrict__ n_heads, const uint32_t *__restrict__ event_count, uint32_t event_limit)
 {
+  if (speculationFailed(event_count, event_limit))
+  {
+    return;
+  }
   // Heads are collected in LDS and the workgroup reserves its output range with ONE global atomic (the counter is a
   // single address: one atomic per wave serialises the whole launch on it).
   __shared__ uint32_t s_list[kHeadsPerBlock];
@@ -240,8 +273,13 @@ __global__ void __launch_bounds__(128)
                const double *__restrict__ rays, const float *__restrict__ intensities, float *__restrict__ occupancy,
                uint32_t *__restrict__ mean_layer, float *__restrict__ cov_layer, float *__restrict__ intensity_layer,
                uint32_t *__restrict__ hit_miss_layer, SecondaryLayers sec, const RayWalk *__restrict__ walks,
-               const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads)
+               const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads,
+               const uint32_t *__restrict__ event_count, uint32_t event_limit)
 {
+  if (speculationFailed(event_count, event_limit))
+  {
+    return;
+  }
   // One lane per voxel group (k_group_heads), grid-stride.
   const NdtLayers ly{ occupancy, mean_layer, cov_layer, intensity_layer, hit_miss_layer };
   const uint32_t head_count = *n_heads;
@@ -290,8 +328,12 @@ __device__ inline void replayTsdfGroup(const MapConst &mc, const RegionTable &rt
 __global__ void __launch_bounds__(128)
   k_replay_tsdf(MapConst mc, RegionTable rt, const unsigned long long *__restrict__ sorted, uint32_t n_events,
                 const double *__restrict__ rays, float *__restrict__ tsdf_layer, const uint32_t *__restrict__ heads,
-                const uint32_t *__restrict__ n_heads)
+                const uint32_t *__restrict__ n_heads, const uint32_t *__restrict__ event_count, uint32_t event_limit)
 {
+  if (speculationFailed(event_count, event_limit))
+  {
+    return;
+  }
   // Grid-stride over the compacted voxel-group heads (k_group_heads) or, with heads == nullptr, over all events with
   // the non-heads skipped (TSDF groups are short: the compaction pass costs more than it saves there).
   const uint32_t head_count = heads ? *n_heads : n_events;
