@@ -243,3 +243,36 @@ def test_event_list_overflow_rewalk_applies_nothing_twice(gpu, monkeypatch):
     assert_parity(stats)
     stats, gm, om = run_tsdf(rays[:24000], batch=6000)
     assert_parity(stats)
+
+
+@pytest.mark.parametrize("kind", ["ndt", "tsdf"])
+def test_event_sort_speculation_miss_repeats_with_the_exact_size(gpu, kind):
+    """Round 6: from the second batch on, the event sort and the replay are launched on the PREVIOUS batch's event count
+    plus head room (k_pad_events; the kernels that consume the sorted list do nothing when the true count exceeded the
+    speculation, and the host repeats sort and replay with the exact size).  Batches growing tenfold force the miss, batches
+    shrinking tenfold the padding; results must be those of the oracle either way (NDT 1e-5, TSDF bit exact)."""
+    sizes = [1500, 40000, 3000, 60000, 60000, 500]
+    rays = [synth.rays_c2(n=n, seed=300 + k) for k, n in enumerate(sizes)]
+    if kind == "ndt":
+        map_ = OccupancyMap(0.2, (32, 32, 32), layers=("occupancy",))
+        gm = GpuNdtMap(map_)
+        om = make_oracle(map_)
+        om.set_ndt(sensor_noise=gm.sensor_noise, sample_threshold=gm.sample_threshold,
+                   adaptation_rate=gm.adaptation_rate, reinit_threshold=gm.reinitialise_covariance_threshold,
+                   reinit_count=gm.reinitialise_covariance_point_count)
+    else:
+        map_ = OccupancyMap(0.1, (32, 32, 32), layers=("tsdf",))
+        gm = GpuTsdfMap(map_)
+        om = make_oracle(map_)
+        om.set_tsdf(max_weight=gm.tsdf_options[0], trunc=gm.tsdf_options[1], dropoff=gm.tsdf_options[2],
+                    sparsity=gm.tsdf_options[3])
+    gm.setBatchCoalescing(0)
+    for chunk in rays:
+        assert gm.integrateRays(chunk) == chunk.shape[0]
+        if kind == "ndt":
+            om.integrate_ndt(chunk)
+        else:
+            om.integrate_tsdf(chunk)
+    gm.syncVoxels()
+    stats = compare_maps(om.chunks(), map_.chunks, list(map_.layers), rel=1e-5, exact_float=(kind == "tsdf"))
+    assert_parity(stats)
