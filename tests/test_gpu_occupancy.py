@@ -57,6 +57,25 @@ def test_populate_large_batched(gpu):
     assert_parity(stats)
 
 
+def test_populate_large_full_size_one_device_batch_per_call(gpu):
+    """GpuMapTest.cpp:354 PopulateLarge at its full size -- 131 072 rays within +-25 m, presented 2 048 rays per call -- with
+    batch coalescing OFF, so that every call is a device batch of its own (64 of them: the small-batch launch shapes, 512-segment
+    walk chunks, and the speculative binning of every batch on the previous one's buffers).  Bit exact."""
+    rays = synth.random_rays(131072, extent=25.0, seed=13)
+    map_ = OccupancyMap(0.1, (32, 32, 32), layers=("occupancy",))
+    gm = GpuMap(map_)
+    gm.setBatchCoalescing(0)
+    om = make_oracle(map_)
+    launched = gm.batchesLaunched()
+    for i in range(0, rays.shape[0], 2 * 2048):
+        chunk = rays[i:i + 2 * 2048]
+        assert gm.integrateRays(chunk) == chunk.shape[0]
+        om.integrate_occupancy(chunk)
+    assert gm.batchesLaunched() - launched == 64
+    gm.syncVoxels()
+    assert_parity(compare_maps(om.chunks(), map_.chunks, ["occupancy"], exact_float=True))
+
+
 def test_lidar_contention_with_mean(gpu):
     # Many rays through shared voxels from one origin (the contended case) + voxel mean layer.
     rays = synth.rays_c1(n=60000, max_range=12.0)
