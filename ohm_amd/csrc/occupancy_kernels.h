@@ -1542,7 +1542,12 @@ __device__ inline float occMissN(const MapConst &mc, unsigned ray_flags, float x
     // Without the exclusion flags only the FIRST miss can meet an unobserved voxel; every later one is occMiss() of an
     // observed value, which is these three operations (same operations, same order: bit identical) -- a voxel that is
     // not yet at the clamp pays them up to ~10 times per batch (a map the sensor is moving through).
-    float nx = occMiss(mc, ray_flags, x);
+    // The first miss is occMiss() with the exclusion flags known to be clear: its three flag selects and the free / occupied
+    // classification drop out, the remaining operations are the same in the same order (bit identical; -3 us per C1 batch).
+    const bool unobserved = x == fInf();
+    const float base = unobserved ? 0.0f : x;
+    const float first_adj = (unobserved || (mc.sat_min < x && x < mc.sat_max)) ? mc.miss_value : 0.0f;
+    float nx = fmaxf(mc.min_value, base + first_adj);
     if (nx == x)
     {
       return x;
